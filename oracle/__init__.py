@@ -1,0 +1,185 @@
+"""oracle — CPU checker for the HIP engine.  TEST INFRASTRUCTURE.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
+this package.  The product package never does, and has no CPU fallback.
+
+``oracle.lib()`` loads ``oracle/_build/liboracle.so`` (the plain-C restatement in
+``slam_oracle.c`` / ``slam_oracle_pf.c``, built by ``make -C oracle``) and the thin numpy
+wrappers below call it.  Parity status is documented in ``slam_oracle.h``: rows A1-A8 are pinned
+against the compiled reference (``tests/test_oracle_vs_reference.py``); the particle-filter
+stages have no reference counterpart and are "parity unpinned".
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+HERE = Path(__file__).resolve().parent
+BUILD = HERE / "_build"
+REF = HERE / "_ref"
+
+_f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
+_i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+_u32p = np.ctypeslib.ndpointer(dtype=np.uint32, flags="C_CONTIGUOUS")
+_u64p = np.ctypeslib.ndpointer(dtype=np.uint64, flags="C_CONTIGUOUS")
+
+
+class GridMeta(C.Structure):
+    """Mirror of ``orc_grid_meta`` (slam_oracle.h)."""
+
+    _fields_ = [
+        ("rows", C.c_int),
+        ("cols", C.c_int),
+        ("ld", C.c_int),
+        ("pixel", C.c_float),
+        ("min_x", C.c_float),
+        ("min_y", C.c_float),
+    ]
+
+
+def build(ref: bool = True) -> None:
+    """Compile the oracle (and, when /root/reference exists, the reference harness)."""
+    targets = ["all"] + (["ref"] if ref else [])
+    subprocess.run(["make", "-s", "-C", str(HERE), *targets], check=True)
+
+
+_LIB = None
+
+
+def lib() -> C.CDLL:
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    so = BUILD / "liboracle.so"
+    if not so.exists():
+        build(ref=False)
+    L = C.CDLL(str(so))
+    P = C.POINTER
+    L.orc_beam_angles.argtypes = [C.c_float, C.c_float, C.c_int, _f32p]
+    L.orc_clean_scan.argtypes = [_f32p, _f32p, C.c_int, C.c_float, C.c_int, _f32p, _f32p]
+    L.orc_clean_scan.restype = C.c_int
+    L.orc_transform.argtypes = [_f32p, _f32p, C.c_int, _f32p, _f32p, _f32p]
+    L.orc_local_map.argtypes = [_f32p, _f32p, C.c_int, _f32p, _f32p, C.c_int, C.c_float, _f32p, _f32p]
+    L.orc_local_map.restype = C.c_int
+    L.orc_rasterise.argtypes = [_f32p, _f32p, C.c_int, C.c_float, C.c_int, C.c_int, _i32p, P(GridMeta)]
+    for name in ("orc_edt_gather", "orc_edt_scatter", "orc_edt_window"):
+        getattr(L, name).argtypes = [_i32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_float]
+    L.orc_score_pose.argtypes = [P(GridMeta), _f32p, _f32p, _f32p, C.c_int, C.c_float, C.c_float, C.c_float,
+                                 C.c_float, C.c_void_p, P(C.c_int)]
+    L.orc_score_pose.restype = C.c_float
+    L.orc_score_poses.argtypes = [P(GridMeta), _f32p, _f32p, _f32p, C.c_int, _f32p, _f32p, _f32p, C.c_int, _f32p, _i32p]
+    L.orc_fastmatch.argtypes = [P(GridMeta), _f32p, _f32p, _f32p, C.c_int, _f32p, _f32p, _f32p, _f32p, P(C.c_int),
+                                P(C.c_float)]
+    _LIB = L
+    return L
+
+
+# ------------------------------------------------------------------ numpy-level helpers
+
+
+def meta(rows: int, cols: int, ld: int, pixel: float, min_x: float, min_y: float) -> GridMeta:
+    return GridMeta(int(rows), int(cols), int(ld), np.float32(pixel), np.float32(min_x), np.float32(min_y))
+
+
+def beam_angles(angle_min: float, angle_inc: float, n: int) -> np.ndarray:
+    out = np.empty(n, np.float32)
+    lib().orc_beam_angles(angle_min, angle_inc, n, out)
+    return out
+
+
+def clean_scan(ranges, angles, range_min=0.023, usable=24):
+    n = len(ranges)
+    x = np.empty(n, np.float32)
+    y = np.empty(n, np.float32)
+    m = lib().orc_clean_scan(np.ascontiguousarray(ranges, np.float32), np.ascontiguousarray(angles, np.float32), n,
+                             range_min, usable, x, y)
+    return x[:m].copy(), y[:m].copy()
+
+
+def transform(x, y, pose):
+    tx = np.empty(len(x), np.float32)
+    ty = np.empty(len(x), np.float32)
+    lib().orc_transform(np.ascontiguousarray(x, np.float32), np.ascontiguousarray(y, np.float32), len(x),
+                        np.ascontiguousarray(pose, np.float32), tx, ty)
+    return tx, ty
+
+
+def local_map(map_x, map_y, tx, ty, border=1.0):
+    lx = np.empty(max(len(map_x), 1), np.float32)
+    ly = np.empty(max(len(map_x), 1), np.float32)
+    m = lib().orc_local_map(np.ascontiguousarray(map_x, np.float32), np.ascontiguousarray(map_y, np.float32),
+                            len(map_x), np.ascontiguousarray(tx, np.float32), np.ascontiguousarray(ty, np.float32),
+                            len(tx), border, lx, ly)
+    return lx[:m].copy(), ly[:m].copy()
+
+
+def rasterise(px, py, pixel, ld):
+    grid = np.empty((ld, ld), np.int32)
+    m = GridMeta()
+    lib().orc_rasterise(np.ascontiguousarray(px, np.float32), np.ascontiguousarray(py, np.float32), len(px), pixel, ld,
+                        ld, grid, C.byref(m))
+    return grid, m
+
+
+def edt(occ: np.ndarray, rows: int, cols: int, cap: float = 10.0, variant: str = "window", out=None) -> np.ndarray:
+    """EDT of ``occ[:rows, :cols]`` (int32, row-major, leading dimension occ.shape[1])."""
+    occ = np.ascontiguousarray(occ, np.int32)
+    if out is None:
+        out = np.zeros(occ.shape, np.float32)
+    getattr(lib(), "orc_edt_" + variant)(occ, out, occ.shape[1], rows, cols, cap)
+    return out
+
+
+def score_pose(m: GridMeta, edt_grid, bx, by, x, y, ct, st):
+    """-> (score, count, hits[count]) for one pose with the given heading cos/sin."""
+    hits = np.empty(len(bx), np.float32)
+    cnt = C.c_int(0)
+    s = lib().orc_score_pose(C.byref(m), np.ascontiguousarray(edt_grid, np.float32),
+                             np.ascontiguousarray(bx, np.float32), np.ascontiguousarray(by, np.float32), len(bx),
+                             x, y, ct, st, hits.ctypes.data_as(C.c_void_p), C.byref(cnt))
+    return np.float32(s), cnt.value, hits[: cnt.value].copy()
+
+
+def score_poses(m: GridMeta, edt_grid, bx, by, x, y, theta):
+    n = len(x)
+    score = np.empty(n, np.float32)
+    count = np.empty(n, np.int32)
+    lib().orc_score_poses(C.byref(m), np.ascontiguousarray(edt_grid, np.float32), np.ascontiguousarray(bx, np.float32),
+                          np.ascontiguousarray(by, np.float32), len(bx), np.ascontiguousarray(x, np.float32),
+                          np.ascontiguousarray(y, np.float32), np.ascontiguousarray(theta, np.float32), n, score, count)
+    return score, count
+
+
+def fastmatch(m: GridMeta, edt_grid, bx, by, pose, res):
+    """-> (pose[3], best_hits (full scratch, nbeams long), best_hits_size, best_score)"""
+    out = np.empty(3, np.float32)
+    hits = np.zeros(max(len(bx), 1), np.float32)
+    n = C.c_int(0)
+    sc = C.c_float(0)
+    lib().orc_fastmatch(C.byref(m), np.ascontiguousarray(edt_grid, np.float32), np.ascontiguousarray(bx, np.float32),
+                        np.ascontiguousarray(by, np.float32), len(bx), np.ascontiguousarray(pose, np.float32),
+                        np.ascontiguousarray(res, np.float32), out, hits, C.byref(n), C.byref(sc))
+    return out, hits, n.value, np.float32(sc.value)
+
+
+def libm_cos_sin(theta):
+    """cosf/sinf of the platform libm — what the reference itself calls for its headings."""
+    m = C.CDLL("libm.so.6")
+    m.cosf.restype = C.c_float
+    m.cosf.argtypes = [C.c_float]
+    m.sinf.restype = C.c_float
+    m.sinf.argtypes = [C.c_float]
+    th = np.atleast_1d(np.asarray(theta, np.float32))
+    return (np.array([m.cosf(float(t)) for t in th], np.float32), np.array([m.sinf(float(t)) for t in th], np.float32))
+
+
+def run_tool(name: str, *args, **kw) -> subprocess.CompletedProcess:
+    """Run one of the oracle's own executables (gen_dataset, main_cpu)."""
+    exe = BUILD / name
+    if not exe.exists():
+        build(ref=False)
+    return subprocess.run([str(exe), *map(str, args)], check=True, **kw)

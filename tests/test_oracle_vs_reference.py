@@ -1,0 +1,175 @@
+"""Pins the CPU oracle (oracle/slam_oracle.c) against golden vectors captured from the compiled,
+unmodified reference.  Everything here is bit-exact: rows A1-A8 are float32
+arithmetic in a fixed order plus integer index work.
+
+Reference lines being pinned (relative to /root/reference/Subsystem_1/):
+  A1 main.c:22-30   A2 main.c:45-95   A3 main.c:97-118   A4 main.c:155-198   A5 main.c:271-354
+  A6 main.c:223-269 / main_accelerated.c:215-283   A7 main.c:381-809   A8 main.c:825-990
+"""
+import hashlib
+import json
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, bits
+
+NB = 1079
+
+
+def test_a1_frame_parser(orc, golden, tmp_path):
+    import ctypes as C
+
+    L = orc.lib()
+    libc = C.CDLL("libc.so.6")
+    libc.fopen.restype = C.c_void_p
+    libc.fopen.argtypes = [C.c_char_p, C.c_char_p]
+    libc.fclose.argtypes = [C.c_void_p]
+    L.orc_parse_frame.argtypes = [C.c_void_p, np.ctypeslib.ndpointer(np.float32), C.c_int]
+    L.orc_parse_frame.restype = C.c_int
+    f = libc.fopen(str(GOLDEN / "frames_head.csv").encode(), b"r")
+    buf = np.zeros(NB, np.float32)
+    assert L.orc_parse_frame(f, buf, NB) == NB
+    assert np.array_equal(bits(buf), bits(golden["ranges_0"]))
+    # next two frames parse, the fourth hits EOF: nothing converted, old content kept
+    assert L.orc_parse_frame(f, buf, NB) == NB
+    assert L.orc_parse_frame(f, buf, NB) == NB
+    keep = buf.copy()
+    assert L.orc_parse_frame(f, buf, NB) == 0
+    assert np.array_equal(bits(buf), bits(keep))
+    libc.fclose(f)
+
+
+def test_a2_angles_and_scan_cleanup(orc, golden):
+    ang = orc.beam_angles(-2.351831, 0.004363, NB)
+    assert np.array_equal(bits(ang), bits(golden["angles"]))
+    # the table is a running float sum, not a0 + k*inc: make sure the fixture can tell them apart
+    closed_form = (np.float32(-2.351831) + np.arange(NB, dtype=np.float32) * np.float32(0.004363)).astype(np.float32)
+    assert not np.array_equal(bits(closed_form), bits(ang))
+    for fr in (0, 41, 400):
+        x, y = orc.clean_scan(golden[f"ranges_{fr}"], ang)
+        assert len(x) == len(golden[f"scan_x_{fr}"]) < NB   # dropouts / over-range were removed
+        assert np.array_equal(bits(x), bits(golden[f"scan_x_{fr}"]))
+        assert np.array_equal(bits(y), bits(golden[f"scan_y_{fr}"]))
+
+
+def test_a2_gate_edges(orc):
+    ang = np.zeros(6, np.float32)
+    r = np.array([0.0229, 0.023, 24.0, 24.000002, np.nan, -1.0], np.float32)
+    x, _ = orc.clean_scan(r, ang)
+    # kept: exactly range_min, exactly 24, NaN (both comparisons false)
+    assert len(x) == 3 and x[0] == np.float32(0.023) and x[1] == np.float32(24.0) and np.isnan(x[2])
+
+
+def test_a3_transform(orc, golden):
+    tx, ty = orc.transform(golden["scan_x_41"], golden["scan_y_41"], golden["state_pose"])
+    assert np.array_equal(bits(tx), bits(golden["state_tx"]))
+    assert np.array_equal(bits(ty), bits(golden["state_ty"]))
+
+
+def test_a4_local_map(orc, golden):
+    lx, ly = orc.local_map(golden["state_map_x"], golden["state_map_y"], golden["state_tx"], golden["state_ty"], 1.0)
+    assert np.array_equal(bits(lx), bits(golden["state_local_x"]))
+    assert np.array_equal(bits(ly), bits(golden["state_local_y"]))
+
+
+@pytest.mark.parametrize("which,pixel,ld", [(0, 0.2, 200), (1, 0.1, 400)])
+def test_a5_rasterise(orc, golden, which, pixel, ld):
+    grid, m = orc.rasterise(golden["state_local_x"], golden["state_local_y"], pixel, ld)
+    rows, cols, gld = golden[f"state_meta_{which}"]
+    pix, minx, miny = golden[f"state_metaf_{which}"]
+    assert (m.rows, m.cols, m.ld) == (rows, cols, gld)
+    assert np.array_equal(bits([m.pixel, m.min_x, m.min_y]), bits([pix, minx, miny]))
+    assert np.array_equal(grid[:rows, :cols], golden[f"state_occ_{which}"].astype(np.int32))
+    assert not grid[rows:, :].any() and not grid[:, cols:].any()
+
+
+EDT_CASES = ["empty", "single", "sparse_nonsquare", "dense", "full", "tall_fine", "max_coarse", "max_fine"]
+
+
+@pytest.mark.parametrize("case", EDT_CASES)
+@pytest.mark.parametrize("variant", ["gather", "scatter", "window"])
+def test_a6_edt(orc, golden, case, variant):
+    occ_rc = golden[f"edt_{case}_occ"].astype(np.int32)
+    rows, cols = occ_rc.shape
+    if variant != "window" and rows * cols > 150 * 150:
+        pytest.skip("O(cells^2) formulation: pinned on the small cases only")
+    ld = 400 if golden[f"edt_{case}_which"][0] else 200
+    occ = np.zeros((ld, ld), np.int32)
+    occ[:rows, :cols] = occ_rc
+    out = np.full((ld, ld), -1.0, np.float32)
+    orc.edt(occ, rows, cols, 10.0, variant, out=out)
+    assert np.array_equal(bits(out[:rows, :cols]), bits(golden[f"edt_{case}_out"]))
+    # cells outside the used rectangle are never written
+    assert np.all(out[rows:, :] == -1.0) and np.all(out[:, cols:] == -1.0)
+
+
+@pytest.mark.parametrize("which", [0, 1])
+def test_a6_edt_on_slam_state(orc, golden, which):
+    occ_rc = golden[f"state_occ_{which}"].astype(np.int32)
+    rows, cols = occ_rc.shape
+    for variant in ("scatter", "window"):
+        out = orc.edt(occ_rc, rows, cols, 10.0, variant)
+        assert np.array_equal(bits(out), bits(golden[f"state_edt_{which}"]))
+
+
+def _grid(orc, golden, which):
+    rows, cols, ld = (int(v) for v in golden[f"state_meta_{which}"])
+    pix, minx, miny = golden[f"state_metaf_{which}"]
+    full = np.zeros((ld, ld), np.float32)
+    full[:rows, :cols] = golden[f"state_edt_{which}"]
+    return orc.meta(rows, cols, ld, pix, minx, miny), full
+
+
+@pytest.mark.parametrize("which", [0, 1])
+def test_a7_single_pose_scores(orc, golden, which):
+    m, edt = _grid(orc, golden, which)
+    bx, by = golden["scan_x_41"], golden["scan_y_41"]
+    poses = golden["score_poses"]
+    n_all_out = 0
+    for k, p in enumerate(poses):
+        s, n, hits = orc.score_pose(m, edt, bx, by, p[0], p[1], golden["score_ct"][k], golden["score_st"][k])
+        assert n == golden[f"score_cnt_{which}"][k]
+        assert bits(s) == bits(golden[f"score_val_{which}"][k])
+        assert np.array_equal(bits(hits), bits(golden[f"score_hits_{which}"][k][:n]))
+        n_all_out += n == 0
+    assert n_all_out >= 1   # the fixture holds an all-out-of-bounds pose (score 0 = "perfect", Q5)
+    # batch form with libm trig of theta must agree on this machine
+    sc, cn = orc.score_poses(m, edt, bx, by, poses[:, 0].copy(), poses[:, 1].copy(), poses[:, 2].copy())
+    assert np.array_equal(cn, golden[f"score_cnt_{which}"])
+    assert np.array_equal(bits(sc), bits(golden[f"score_val_{which}"]))
+
+
+def test_a7_fastmatch_calls(orc, golden):
+    bx, by = golden["scan_x_41"], golden["scan_y_41"]
+    for k in range(len(golden["fm_which"])):
+        m, edt = _grid(orc, golden, int(golden["fm_which"][k]))
+        pose, hits, nbest, _ = orc.fastmatch(m, edt, bx, by, golden["fm_guess"][k], golden["fm_res"][k])
+        assert np.array_equal(bits(pose), bits(golden["fm_pose"][k])), k
+        assert nbest == golden["fm_nbest"][k]
+        nlast = golden["fm_nlast"][k]
+        # Q2: the hit buffer belongs to the LAST candidate, its length to the BEST
+        assert np.array_equal(bits(hits[:nlast]), bits(golden["fm_hits"][k][:nlast]))
+
+
+def _sha256(p):
+    h = hashlib.sha256()
+    with open(p, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 20), b""):
+            h.update(blk)
+    return h.hexdigest()
+
+
+@pytest.mark.parametrize("name,frames,variant", [("parity", 1000, 2), ("loop", 3480, 1)])
+def test_a8_whole_program_pose_log_and_map(orc, tmp_path, name, frames, variant):
+    """main_cpu (the restatement as a program) vs the stdout / map file of the reference programs:
+    parity = Subsystem_1/main.c (1000 frames), loop = Subsystem_1/main_accelerated.c (3480)."""
+    info = json.loads((GOLDEN / "datasets.json").read_text())[name]
+    csv = tmp_path / f"{name}.csv"
+    orc.run_tool("gen_dataset", csv, *info["gen_args"])
+    assert _sha256(csv) == info["sha256"], "gen_dataset is not bit-reproducible on this machine"
+    r = orc.run_tool("main_cpu", csv, frames, NB, variant, tmp_path / "map.csv", capture_output=True, text=True)
+    poses = [ln for ln in r.stdout.splitlines() if ln.startswith("pose =")]
+    assert "\n".join(poses) + "\n" == (GOLDEN / f"{name}_pose.txt").read_text()
+    assert (tmp_path / "map.csv").read_bytes() == (GOLDEN / f"{name}_map.csv").read_bytes()
