@@ -1,0 +1,279 @@
+"""MI355X-native scan-matching / particle-filter engine — Python binding of the C ABI.
+
+The product is the shared library ``lib/libslam_hip.so`` (hand-written HIP kernels for gfx950 behind
+the plain-C interface of ``include/slam_hip.h``).  This module is only a ctypes view of that ABI so
+that tests, ``bench.py`` and Python hosts can call it; the C host program under ``host/`` links the
+same library directly.  There is NO CPU fallback: importing works without a GPU (so the build check
+can load the library and verify its symbols), but creating an ``Engine`` raises when no gfx950 device
+is present, and a missing library raises at import of the symbols.
+
+Reference mapping (paths relative to the reference repository):
+  Engine.edt_host / grid_upload  <- euclidean_distance_transform{,2}  Subsystem_1/main_accelerated.c:215-283
+  Engine.fastmatch               <- FastMatch / FastMatch2            Subsystem_1/main.c:381-809
+  Engine.score_poses*            <- the per-pose body of FastMatch    Subsystem_1/main.c:459-518
+  motion / EKF / weights / resample: no reference counterpart
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+import numpy as np
+
+PKG_DIR = Path(__file__).resolve().parent
+LIB_PATH = PKG_DIR / "lib" / "libslam_hip.so"
+HEADER_PATH = PKG_DIR.parent / "include" / "slam_hip.h"
+
+SLAM_OK = 0
+SLAM_MAX_BEAMS = 4096
+SLAM_MAX_OBS = 8192
+EKF_OBS_CHUNK = 32
+
+
+class SlamError(RuntimeError):
+    def __init__(self, status: int, where: str, detail: str = ""):
+        self.status = status
+        super().__init__(f"{where}: {status_string(status)} ({status})" + (f": {detail}" if detail else ""))
+
+
+class GridMeta(C.Structure):
+    """``slam_grid_meta`` — rows, cols, ld, pixel, min_x, min_y (reference: MyGrid, main.c:200-213)."""
+
+    _fields_ = [("rows", C.c_int32), ("cols", C.c_int32), ("ld", C.c_int32), ("pixel", C.c_float),
+                ("min_x", C.c_float), ("min_y", C.c_float)]
+
+
+_vp, _i, _i64, _u64, _u32, _f = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_uint32, C.c_float
+_fp = C.POINTER(C.c_float)
+
+# name -> (restype, argtypes); every entry point include/slam_hip.h declares
+SIGNATURES = {
+    "slam_abi_version": (_i, []),
+    "slam_status_string": (C.c_char_p, [_i]),
+    "slam_last_error": (C.c_char_p, [_vp]),
+    "slam_engine_create": (_i, [_i, C.POINTER(_vp)]),
+    "slam_engine_destroy": (_i, [_vp]),
+    "slam_engine_set_stream": (_i, [_vp, _vp]),
+    "slam_engine_sync": (_i, [_vp]),
+    "slam_edt_dev": (_i, [_vp, _vp, _i, _i, _i, _f, _vp]),
+    "slam_edt_host": (_i, [_vp, _vp, _i, _i, _i, _f, _vp]),
+    "slam_grid_upload_host": (_i, [_vp, _i, _vp, C.POINTER(GridMeta), _f, _vp]),
+    "slam_grid_set_dev": (_i, [_vp, _i, _vp, C.POINTER(GridMeta)]),
+    "slam_scan_upload_host": (_i, [_vp, _vp, _vp, _i]),
+    "slam_scan_set_dev": (_i, [_vp, _vp, _vp, _i]),
+    "slam_score_poses_cs_dev": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    "slam_score_poses_dev": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _vp]),
+    "slam_score_poses_cs_host": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    "slam_score_poses_host": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _vp]),
+    "slam_pose_hits_host": (_i, [_vp, _i, _f, _f, _f, _f, _vp, C.POINTER(C.c_int32)]),
+    "slam_fastmatch_host": (_i, [_vp, _i, _fp, _fp, _fp, _vp, C.POINTER(C.c_int32), _fp]),
+    "slam_motion_sample_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _fp, _fp, _u64, _u32]),
+    "slam_obs_upload_host": (_i, [_vp, _vp, _vp, _vp, _i, _i]),
+    "slam_ekf_update_dev": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _i, _f, _vp]),
+    "slam_logweight_dev": (_i, [_vp, _vp, _vp, _f, _i, _vp, _vp]),
+    "slam_quantise_weights_dev": (_i, [_vp, _vp, _vp, _i, _vp, _vp]),
+    "slam_prefix_sum_dev": (_i, [_vp, _vp, _i, _vp]),
+    "slam_offspring_offsets_dev": (_i, [_vp, _vp, _i, _u64, _u64, _u64, _i64, _vp]),
+    "slam_ancestors_dev": (_i, [_vp, _vp, _i64, _i64, _i, _vp]),
+    "slam_comb_offset": (_u64, [_u64, _u32, _u64]),
+    "slam_gather_f32_dev": (_i, [_vp, _vp, _vp, _i, _vp]),
+    "slam_gather_map_dev": (_i, [_vp, _vp, _vp, _i64, _i64, _i, _i, _i, _vp, _i]),
+}
+
+_LIB = None
+
+
+def load_library() -> C.CDLL:
+    """Load libslam_hip.so and bind every C-ABI symbol.  Raises if the library or a symbol is missing."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not LIB_PATH.exists():
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: the HIP engine has not been built (run `python -c 'import __graft_entry__ as g; "
+            "g.build()'` or `make -C hardware-acceleration-of-lidar-slam_amd/csrc`).  There is no CPU fallback.")
+    lib = C.CDLL(str(LIB_PATH))
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)   # AttributeError if the library does not export it
+        fn.restype = res
+        fn.argtypes = args
+    _LIB = lib
+    return lib
+
+
+def status_string(status: int) -> str:
+    return load_library().slam_status_string(status).decode()
+
+
+def _ptr(a):
+    """Device pointer of a torch tensor / raw int, host pointer of a numpy array, or None."""
+    if a is None:
+        return None
+    if isinstance(a, int):
+        return C.c_void_p(a)
+    if isinstance(a, np.ndarray):
+        return C.c_void_p(a.ctypes.data)
+    return C.c_void_p(a.data_ptr())
+
+
+def _np(a, dtype):
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+def _f3(v):
+    return (C.c_float * 3)(*[float(np.float32(x)) for x in v])
+
+
+class Engine:
+    """One engine per GPU / host thread (``slam_engine``)."""
+
+    def __init__(self, device: int = 0):
+        self.lib = load_library()
+        h = C.c_void_p()
+        rc = self.lib.slam_engine_create(device, C.byref(h))
+        if rc != SLAM_OK:
+            raise SlamError(rc, "slam_engine_create")
+        self.h = h
+        self.nbeams = 0
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.slam_engine_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def _ck(self, rc, where):
+        if rc != SLAM_OK:
+            raise SlamError(rc, where, self.lib.slam_last_error(self.h).decode())
+
+    def set_stream(self, stream_ptr):
+        self._ck(self.lib.slam_engine_set_stream(self.h, C.c_void_p(stream_ptr) if stream_ptr else None), "set_stream")
+
+    def sync(self):
+        self._ck(self.lib.slam_engine_sync(self.h), "sync")
+
+    # ---------------------------------------------------------------- host-buffer level (drop-in)
+    def edt_host(self, occ: np.ndarray, rows: int, cols: int, cap: float = 10.0, out: np.ndarray | None = None):
+        occ = _np(occ, np.int32)
+        if out is None:
+            out = np.zeros(occ.shape, np.float32)
+        assert out.flags.c_contiguous and out.dtype == np.float32 and out.shape == occ.shape
+        self._ck(self.lib.slam_edt_host(self.h, _ptr(occ), occ.shape[1], rows, cols, cap, _ptr(out)), "edt_host")
+        return out
+
+    def grid_upload(self, slot: int, occ: np.ndarray, meta: GridMeta, cap: float = 10.0, want_edt: bool = False):
+        occ = _np(occ, np.int32)
+        assert occ.ndim == 2 and occ.shape[1] == meta.ld and occ.shape[0] >= meta.rows
+        out = np.zeros(occ.shape, np.float32) if want_edt else None
+        self._ck(self.lib.slam_grid_upload_host(self.h, slot, _ptr(occ), C.byref(meta), cap, _ptr(out)), "grid_upload")
+        return out
+
+    def grid_set_dev(self, slot: int, d_edt, meta: GridMeta):
+        self._ck(self.lib.slam_grid_set_dev(self.h, slot, _ptr(d_edt), C.byref(meta)), "grid_set_dev")
+
+    def scan_upload(self, bx, by):
+        bx, by = _np(bx, np.float32), _np(by, np.float32)
+        assert bx.shape == by.shape and bx.ndim == 1
+        self._ck(self.lib.slam_scan_upload_host(self.h, _ptr(bx), _ptr(by), len(bx)), "scan_upload")
+        self.nbeams = len(bx)
+
+    def scan_set_dev(self, d_bx, d_by, nbeams: int):
+        self._ck(self.lib.slam_scan_set_dev(self.h, _ptr(d_bx), _ptr(d_by), nbeams), "scan_set_dev")
+        self.nbeams = nbeams
+
+    def score_poses_cs_host(self, slot, x, y, ct, st):
+        x, y, ct, st = (_np(a, np.float32) for a in (x, y, ct, st))
+        score = np.empty(len(x), np.float32)
+        count = np.empty(len(x), np.int32)
+        self._ck(self.lib.slam_score_poses_cs_host(self.h, slot, _ptr(x), _ptr(y), _ptr(ct), _ptr(st), len(x),
+                                                   _ptr(score), _ptr(count)), "score_poses_cs_host")
+        return score, count
+
+    def score_poses_host(self, slot, x, y, theta):
+        x, y, theta = (_np(a, np.float32) for a in (x, y, theta))
+        score = np.empty(len(x), np.float32)
+        count = np.empty(len(x), np.int32)
+        self._ck(self.lib.slam_score_poses_host(self.h, slot, _ptr(x), _ptr(y), _ptr(theta), len(x), _ptr(score),
+                                                _ptr(count)), "score_poses_host")
+        return score, count
+
+    def pose_hits(self, slot, x, y, ct, st):
+        hits = np.zeros(max(self.nbeams, 1), np.float32)
+        n = C.c_int32(0)
+        self._ck(self.lib.slam_pose_hits_host(self.h, slot, x, y, ct, st, _ptr(hits), C.byref(n)), "pose_hits")
+        return hits[: n.value].copy(), n.value
+
+    def fastmatch(self, slot, pose, res):
+        """-> (pose[3], hit buffer (nbeams long; live prefix = last candidate's hits), best_hits_size, best_score)"""
+        out = (C.c_float * 3)()
+        hits = np.zeros(max(self.nbeams, 1), np.float32)
+        n = C.c_int32(-1)
+        sc = C.c_float(0)
+        self._ck(self.lib.slam_fastmatch_host(self.h, slot, _f3(pose), _f3(res), out, _ptr(hits), C.byref(n),
+                                              C.byref(sc)), "fastmatch")
+        return np.array(list(out), np.float32), hits, n.value, np.float32(sc.value)
+
+    # ---------------------------------------------------------------- device level (async on the engine stream)
+    def edt_dev(self, d_occ, ld, rows, cols, cap, d_out):
+        self._ck(self.lib.slam_edt_dev(self.h, _ptr(d_occ), ld, rows, cols, cap, _ptr(d_out)), "edt_dev")
+
+    def score_poses_dev(self, slot, d_x, d_y, d_th, n, d_score, d_count):
+        self._ck(self.lib.slam_score_poses_dev(self.h, slot, _ptr(d_x), _ptr(d_y), _ptr(d_th), n, _ptr(d_score),
+                                               _ptr(d_count)), "score_poses_dev")
+
+    def score_poses_cs_dev(self, slot, d_x, d_y, d_ct, d_st, n, d_score, d_count):
+        self._ck(self.lib.slam_score_poses_cs_dev(self.h, slot, _ptr(d_x), _ptr(d_y), _ptr(d_ct), _ptr(d_st), n,
+                                                  _ptr(d_score), _ptr(d_count)), "score_poses_cs_dev")
+
+    def motion_sample_dev(self, src, anc, dst, n, first_id, dp, sigma, seed, frame):
+        """src / dst: triples (x, y, theta) of device arrays."""
+        self._ck(self.lib.slam_motion_sample_dev(self.h, _ptr(src[0]), _ptr(src[1]), _ptr(src[2]), _ptr(anc),
+                                                 _ptr(dst[0]), _ptr(dst[1]), _ptr(dst[2]), n, first_id, _f3(dp),
+                                                 _f3(sigma), seed, frame), "motion_sample_dev")
+
+    def obs_upload(self, landmark_id, zx, zy, nlandmarks):
+        ids, zx, zy = _np(landmark_id, np.int32), _np(zx, np.float32), _np(zy, np.float32)
+        self._ck(self.lib.slam_obs_upload_host(self.h, _ptr(ids), _ptr(zx), _ptr(zy), len(ids), nlandmarks),
+                 "obs_upload")
+
+    def ekf_update_dev(self, d_map_in, d_map_out, plane_stride, ld_map, nlandmarks, d_x, d_y, d_th, d_anc, n, meas_var,
+                       d_loglik):
+        self._ck(self.lib.slam_ekf_update_dev(self.h, _ptr(d_map_in), _ptr(d_map_out), plane_stride, ld_map, nlandmarks,
+                                              _ptr(d_x), _ptr(d_y), _ptr(d_th), _ptr(d_anc), n, meas_var,
+                                              _ptr(d_loglik)), "ekf_update_dev")
+
+    def logweight_dev(self, d_score, d_loglik, gain, n, d_logw, d_max):
+        self._ck(self.lib.slam_logweight_dev(self.h, _ptr(d_score), _ptr(d_loglik), gain, n, _ptr(d_logw), _ptr(d_max)),
+                 "logweight_dev")
+
+    def quantise_weights_dev(self, d_logw, d_max, n, d_wq, d_sum):
+        self._ck(self.lib.slam_quantise_weights_dev(self.h, _ptr(d_logw), _ptr(d_max), n, _ptr(d_wq), _ptr(d_sum)),
+                 "quantise_weights_dev")
+
+    def prefix_sum_dev(self, d_wq, n, d_cdf):
+        self._ck(self.lib.slam_prefix_sum_dev(self.h, _ptr(d_wq), n, _ptr(d_cdf)), "prefix_sum_dev")
+
+    def offspring_offsets_dev(self, d_cdf, n, base, total, comb_u, n_total, d_first):
+        self._ck(self.lib.slam_offspring_offsets_dev(self.h, _ptr(d_cdf), n, base, total, comb_u, n_total,
+                                                     _ptr(d_first)), "offspring_offsets_dev")
+
+    def ancestors_dev(self, d_first_all, n_total, slot0, nslots, d_anc):
+        self._ck(self.lib.slam_ancestors_dev(self.h, _ptr(d_first_all), n_total, slot0, nslots, _ptr(d_anc)),
+                 "ancestors_dev")
+
+    def gather_f32_dev(self, d_src, d_idx, n, d_dst):
+        self._ck(self.lib.slam_gather_f32_dev(self.h, _ptr(d_src), _ptr(d_idx), n, _ptr(d_dst)), "gather_f32_dev")
+
+    def gather_map_dev(self, d_in, d_out, in_stride, out_stride, ld_in, ld_out, nlandmarks, d_idx, n):
+        self._ck(self.lib.slam_gather_map_dev(self.h, _ptr(d_in), _ptr(d_out), in_stride, out_stride, ld_in, ld_out,
+                                              nlandmarks, _ptr(d_idx), n), "gather_map_dev")
+
+
+def comb_offset(seed: int, frame: int, total: int) -> int:
+    return int(load_library().slam_comb_offset(seed, frame, total))
+
+
+def grid_meta(rows, cols, ld, pixel, min_x, min_y) -> GridMeta:
+    return GridMeta(int(rows), int(cols), int(ld), float(np.float32(pixel)), float(np.float32(min_x)),
+                    float(np.float32(min_y)))

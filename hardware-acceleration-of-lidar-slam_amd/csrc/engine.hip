@@ -1,0 +1,662 @@
+// engine.hip — implementation of the C ABI declared in include/slam_hip.h.
+//
+// The engine owns what the reference keeps in file-scope globals — the two occupancy/EDT grids
+// (`occ_grid`, Subsystem_1/main.c:200-213), the current scan (`scan`, main.c:60-69) and the matcher
+// result scratch (`FastMatchParameters`, main.c:374-379) — but as device-resident buffers behind an
+// opaque handle, the shape of the `accel` handle of the reference's FPGA variant
+// (Submodule_2/Hadrware_acclereated.cpp:842-845).  There is no CPU fallback anywhere in this file.
+
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <new>
+#include <vector>
+
+#include "kernels.h"
+
+using namespace slam;
+
+namespace {
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        const size_t want = bytes + bytes / 4 + 256;
+        hipError_t err = hipMalloc(&p, want);
+        if (err == hipSuccess) cap = want;
+        return err;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <class T> T* as() const { return static_cast<T*>(p); }
+};
+
+struct GridSlot {
+    bool ready = false;
+    slam_grid_meta meta{};
+    const float* d_edt = nullptr;   // owned (edt_buf) or adopted
+    DevBuf occ_buf, edt_buf;
+};
+
+constexpr int kLattice = 27;
+// device/host staging layout of one FastMatch call (floats):
+//   in : X[27] Y[27] CT[27] ST[27] LAST[4]
+//   out: SCORE[27] COUNT[27] NLAST[1] HITS[SLAM_MAX_BEAMS]
+constexpr int kFmIn = 4 * kLattice + 4;
+constexpr int kFmOut = 2 * kLattice + 1 + SLAM_MAX_BEAMS;
+
+}  // namespace
+
+struct slam_engine {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    char err[512] = { 0 };
+
+    GridSlot grid[SLAM_MAX_GRID_SLOTS];
+
+    const float *d_bx = nullptr, *d_by = nullptr;   // owned (scan_buf) or adopted
+    int nbeams = -1;
+    DevBuf scan_buf;
+
+    // observation list of the current frame
+    DevBuf obs_buf;   // ids[MAX_OBS] zx[MAX_OBS] zy[MAX_OBS] unobs[...]
+    int nobs = -1, nunobs = 0, obs_nlandmarks = 0;
+    const int32_t *d_obs_id = nullptr, *d_unobs_id = nullptr;
+    const float *d_obs_zx = nullptr, *d_obs_zy = nullptr;
+
+    DevBuf fm_buf;             // kFmIn + kFmOut floats
+    float* h_fm = nullptr;     // pinned mirror
+    DevBuf scratch;            // per-call temporaries of the *_dev stages
+    DevBuf host_io[6];         // temporaries of the *_host convenience calls
+};
+
+namespace {
+
+int fail_hip(slam_engine* e, hipError_t err, const char* what)
+{
+    if (e) snprintf(e->err, sizeof e->err, "%s: %s", what, hipGetErrorString(err));
+    (void)hipGetLastError();   // clear the sticky error so later calls can proceed
+    return SLAM_ERR_HIP;
+}
+
+#define HIP_TRY(call)                                              \
+    do {                                                           \
+        hipError_t err__ = (call);                                 \
+        if (err__ != hipSuccess) return fail_hip(e, err__, #call); \
+    } while (0)
+
+#define ENTER(e)                                 \
+    do {                                         \
+        if (!(e)) return SLAM_ERR_INVALID_ARG;   \
+        HIP_TRY(hipSetDevice((e)->device));      \
+    } while (0)
+
+bool slot_ok(int slot) { return slot >= 0 && slot < SLAM_MAX_GRID_SLOTS; }
+
+bool meta_ok(const slam_grid_meta* m)
+{
+    return m && m->rows >= 0 && m->cols >= 0 && m->ld >= m->cols && m->pixel > 0.0f &&
+           (int64_t)m->rows * m->ld < (int64_t)0x7fffffff;
+}
+
+ScoreGrid score_grid(const GridSlot& g)
+{
+    ScoreGrid s;
+    s.edt = g.d_edt;
+    s.rows = g.meta.rows;
+    s.cols = g.meta.cols;
+    s.ld = g.meta.ld;
+    s.ipix = 1 / g.meta.pixel;   // main.c:383 — one float division on the host
+    s.min_x = g.meta.min_x;
+    s.min_y = g.meta.min_y;
+    return s;
+}
+
+int check_score_inputs(slam_engine* e, int slot)
+{
+    if (!slot_ok(slot)) return SLAM_ERR_INVALID_ARG;
+    if (!e->grid[slot].ready || e->nbeams < 0) return SLAM_ERR_NOT_READY;
+    return SLAM_OK;
+}
+
+// host-side Philox4x32-10 for the comb offset
+void philox_host(uint32_t c[4], uint32_t k0, uint32_t k1)
+{
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+        c[0] = n0; c[1] = (uint32_t)p1; c[2] = n2; c[3] = (uint32_t)p0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int slam_abi_version(void) { return SLAM_ABI_VERSION; }
+
+const char* slam_status_string(int status)
+{
+    switch (status) {
+    case SLAM_OK: return "ok";
+    case SLAM_ERR_NO_DEVICE: return "no usable gfx950 device";
+    case SLAM_ERR_INVALID_ARG: return "invalid argument";
+    case SLAM_ERR_HIP: return "HIP runtime error";
+    case SLAM_ERR_NOT_READY: return "stage inputs not provided yet";
+    case SLAM_ERR_CAPACITY: return "capacity exceeded";
+    default: return "unknown status";
+    }
+}
+
+const char* slam_last_error(const slam_engine* e) { return e ? e->err : ""; }
+
+int slam_engine_create(int device, slam_engine** out)
+{
+    if (!out) return SLAM_ERR_INVALID_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
+        (void)hipGetLastError();
+        return SLAM_ERR_NO_DEVICE;
+    }
+    hipDeviceProp_t prop;
+    if (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&prop, device) != hipSuccess) {
+        (void)hipGetLastError();
+        return SLAM_ERR_NO_DEVICE;
+    }
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return SLAM_ERR_NO_DEVICE;   // code objects are gfx950-only
+    slam_engine* e = new (std::nothrow) slam_engine();
+    if (!e) return SLAM_ERR_HIP;
+    e->device = device;
+    if (hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking) != hipSuccess ||
+        e->fm_buf.ensure(sizeof(float) * (kFmIn + kFmOut)) != hipSuccess ||
+        hipHostMalloc((void**)&e->h_fm, sizeof(float) * (kFmIn + kFmOut), hipHostMallocDefault) != hipSuccess ||
+        e->scan_buf.ensure(sizeof(float) * 2 * SLAM_MAX_BEAMS) != hipSuccess) {
+        (void)hipGetLastError();
+        slam_engine_destroy(e);
+        return SLAM_ERR_NO_DEVICE;
+    }
+    e->stream = e->own_stream;
+    *out = e;
+    return SLAM_OK;
+}
+
+int slam_engine_destroy(slam_engine* e)
+{
+    if (!e) return SLAM_OK;
+    (void)hipSetDevice(e->device);
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    for (auto& g : e->grid) {
+        g.occ_buf.release();
+        g.edt_buf.release();
+    }
+    e->scan_buf.release();
+    e->obs_buf.release();
+    e->fm_buf.release();
+    e->scratch.release();
+    for (auto& b : e->host_io) b.release();
+    if (e->h_fm) (void)hipHostFree(e->h_fm);
+    if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
+    delete e;
+    return SLAM_OK;
+}
+
+int slam_engine_set_stream(slam_engine* e, void* hip_stream)
+{
+    ENTER(e);
+    e->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : e->own_stream;
+    return SLAM_OK;
+}
+
+int slam_engine_sync(slam_engine* e)
+{
+    ENTER(e);
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return SLAM_OK;
+}
+
+/* ------------------------------------------------------------------ EDT */
+
+int slam_edt_dev(slam_engine* e, const int32_t* d_occ, int ld, int rows, int cols, float cap, float* d_out)
+{
+    ENTER(e);
+    if (!d_occ || !d_out || rows < 0 || cols < 0 || ld < cols || !(cap >= 0.0f)) return SLAM_ERR_INVALID_ARG;
+    if (ceilf(cap) > (float)EDT_MAX_RADIUS) return SLAM_ERR_CAPACITY;
+    HIP_TRY(launch_edt(e->stream, d_occ, ld, rows, cols, cap, d_out));
+    return SLAM_OK;
+}
+
+int slam_edt_host(slam_engine* e, const int32_t* occ, int ld, int rows, int cols, float cap, float* out)
+{
+    ENTER(e);
+    if (!occ || !out || rows < 0 || cols < 0 || ld < cols || !(cap >= 0.0f)) return SLAM_ERR_INVALID_ARG;
+    if (ceilf(cap) > (float)EDT_MAX_RADIUS) return SLAM_ERR_CAPACITY;
+    if (rows == 0 || cols == 0) return SLAM_OK;
+    const size_t cells = (size_t)rows * ld;
+    HIP_TRY(e->host_io[0].ensure(cells * sizeof(int32_t)));
+    HIP_TRY(e->host_io[1].ensure(cells * sizeof(float)));
+    HIP_TRY(hipMemcpyAsync(e->host_io[0].p, occ, cells * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(launch_edt(e->stream, e->host_io[0].as<int32_t>(), ld, rows, cols, cap, e->host_io[1].as<float>()));
+    // only the rows x cols rectangle belongs to the caller's output (cells outside keep their content, Q7)
+    HIP_TRY(hipMemcpy2DAsync(out, (size_t)ld * sizeof(float), e->host_io[1].p, (size_t)ld * sizeof(float),
+                             (size_t)cols * sizeof(float), (size_t)rows, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return SLAM_OK;
+}
+
+/* ------------------------------------------------------------------ grids + scan */
+
+int slam_grid_upload_host(slam_engine* e, int slot, const int32_t* occ, const slam_grid_meta* meta, float cap,
+                          float* edt_out)
+{
+    ENTER(e);
+    if (!slot_ok(slot) || !occ || !meta_ok(meta) || !(cap >= 0.0f)) return SLAM_ERR_INVALID_ARG;
+    if (ceilf(cap) > (float)EDT_MAX_RADIUS) return SLAM_ERR_CAPACITY;
+    GridSlot& g = e->grid[slot];
+    const size_t cells = (size_t)(meta->rows > 0 ? meta->rows : 1) * meta->ld;
+    HIP_TRY(g.occ_buf.ensure(cells * sizeof(int32_t)));
+    HIP_TRY(g.edt_buf.ensure(cells * sizeof(float)));
+    if (meta->rows > 0) {
+        HIP_TRY(hipMemcpyAsync(g.occ_buf.p, occ, (size_t)meta->rows * meta->ld * sizeof(int32_t), hipMemcpyHostToDevice,
+                               e->stream));
+        HIP_TRY(launch_edt(e->stream, g.occ_buf.as<int32_t>(), meta->ld, meta->rows, meta->cols, cap,
+                           g.edt_buf.as<float>()));
+    }
+    g.meta = *meta;
+    g.d_edt = g.edt_buf.as<float>();
+    g.ready = true;
+    if (edt_out && meta->rows > 0 && meta->cols > 0) {
+        HIP_TRY(hipMemcpy2DAsync(edt_out, (size_t)meta->ld * sizeof(float), g.edt_buf.p,
+                                 (size_t)meta->ld * sizeof(float), (size_t)meta->cols * sizeof(float),
+                                 (size_t)meta->rows, hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+    }
+    return SLAM_OK;
+}
+
+int slam_grid_set_dev(slam_engine* e, int slot, const float* d_edt, const slam_grid_meta* meta)
+{
+    ENTER(e);
+    if (!slot_ok(slot) || !d_edt || !meta_ok(meta)) return SLAM_ERR_INVALID_ARG;
+    GridSlot& g = e->grid[slot];
+    g.meta = *meta;
+    g.d_edt = d_edt;
+    g.ready = true;
+    return SLAM_OK;
+}
+
+int slam_scan_upload_host(slam_engine* e, const float* bx, const float* by, int nbeams)
+{
+    ENTER(e);
+    if (nbeams < 0 || (nbeams > 0 && (!bx || !by))) return SLAM_ERR_INVALID_ARG;
+    if (nbeams > SLAM_MAX_BEAMS) return SLAM_ERR_CAPACITY;
+    float* d = e->scan_buf.as<float>();
+    if (nbeams > 0) {
+        HIP_TRY(hipMemcpyAsync(d, bx, sizeof(float) * nbeams, hipMemcpyHostToDevice, e->stream));
+        HIP_TRY(hipMemcpyAsync(d + SLAM_MAX_BEAMS, by, sizeof(float) * nbeams, hipMemcpyHostToDevice, e->stream));
+    }
+    e->d_bx = d;
+    e->d_by = d + SLAM_MAX_BEAMS;
+    e->nbeams = nbeams;
+    return SLAM_OK;
+}
+
+int slam_scan_set_dev(slam_engine* e, const float* d_bx, const float* d_by, int nbeams)
+{
+    ENTER(e);
+    if (nbeams < 0 || (nbeams > 0 && (!d_bx || !d_by))) return SLAM_ERR_INVALID_ARG;
+    if (nbeams > SLAM_MAX_BEAMS) return SLAM_ERR_CAPACITY;
+    e->d_bx = d_bx;
+    e->d_by = d_by;
+    e->nbeams = nbeams;
+    return SLAM_OK;
+}
+
+/* ------------------------------------------------------------------ score */
+
+int slam_score_poses_cs_dev(slam_engine* e, int slot, const float* d_x, const float* d_y, const float* d_ct,
+                            const float* d_st, int nposes, float* d_score, int32_t* d_count)
+{
+    ENTER(e);
+    if (nposes < 0 || (nposes > 0 && (!d_x || !d_y || !d_ct || !d_st || !d_score || !d_count)))
+        return SLAM_ERR_INVALID_ARG;
+    if (int rc = check_score_inputs(e, slot)) return rc;
+    HIP_TRY(launch_score_poses(e->stream, score_grid(e->grid[slot]), e->d_bx, e->d_by, e->nbeams, d_x, d_y, d_ct, d_st,
+                               nposes, d_score, d_count));
+    return SLAM_OK;
+}
+
+int slam_score_poses_dev(slam_engine* e, int slot, const float* d_x, const float* d_y, const float* d_theta,
+                         int nposes, float* d_score, int32_t* d_count)
+{
+    ENTER(e);
+    if (nposes < 0 || (nposes > 0 && (!d_x || !d_y || !d_theta || !d_score || !d_count))) return SLAM_ERR_INVALID_ARG;
+    if (int rc = check_score_inputs(e, slot)) return rc;
+    HIP_TRY(launch_score_poses(e->stream, score_grid(e->grid[slot]), e->d_bx, e->d_by, e->nbeams, d_x, d_y, d_theta,
+                               nullptr, nposes, d_score, d_count));
+    return SLAM_OK;
+}
+
+static int score_host_common(slam_engine* e, int slot, const float* x, const float* y, const float* a,
+                             const float* b, int nposes, float* score, int32_t* count)
+{
+    if (nposes < 0 || (nposes > 0 && (!x || !y || !a || !score || !count))) return SLAM_ERR_INVALID_ARG;
+    if (int rc = check_score_inputs(e, slot)) return rc;
+    if (nposes == 0) return SLAM_OK;
+    const size_t bytes = sizeof(float) * (size_t)nposes;
+    const float* src[4] = { x, y, a, b };
+    for (int k = 0; k < 6; ++k) HIP_TRY(e->host_io[k].ensure(bytes));
+    for (int k = 0; k < 4; ++k)
+        if (src[k]) HIP_TRY(hipMemcpyAsync(e->host_io[k].p, src[k], bytes, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(launch_score_poses(e->stream, score_grid(e->grid[slot]), e->d_bx, e->d_by, e->nbeams,
+                               e->host_io[0].as<float>(), e->host_io[1].as<float>(), e->host_io[2].as<float>(),
+                               b ? e->host_io[3].as<float>() : nullptr, nposes, e->host_io[4].as<float>(),
+                               e->host_io[5].as<int32_t>()));
+    HIP_TRY(hipMemcpyAsync(score, e->host_io[4].p, bytes, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipMemcpyAsync(count, e->host_io[5].p, bytes, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return SLAM_OK;
+}
+
+int slam_score_poses_cs_host(slam_engine* e, int slot, const float* x, const float* y, const float* ct,
+                             const float* st, int nposes, float* score, int32_t* count)
+{
+    ENTER(e);
+    if (nposes > 0 && !st) return SLAM_ERR_INVALID_ARG;
+    return score_host_common(e, slot, x, y, ct, st, nposes, score, count);
+}
+
+int slam_score_poses_host(slam_engine* e, int slot, const float* x, const float* y, const float* theta, int nposes,
+                          float* score, int32_t* count)
+{
+    ENTER(e);
+    return score_host_common(e, slot, x, y, theta, nullptr, nposes, score, count);
+}
+
+int slam_pose_hits_host(slam_engine* e, int slot, float x, float y, float ct, float st, float* hits, int32_t* count)
+{
+    ENTER(e);
+    if (!hits || !count) return SLAM_ERR_INVALID_ARG;
+    if (int rc = check_score_inputs(e, slot)) return rc;
+    float* d_in = e->fm_buf.as<float>();
+    float* d_out = d_in + kFmIn;
+    float* h_in = e->h_fm;
+    float* h_out = e->h_fm + kFmIn;
+    h_in[4 * kLattice + 0] = x;
+    h_in[4 * kLattice + 1] = y;
+    h_in[4 * kLattice + 2] = ct;
+    h_in[4 * kLattice + 3] = st;
+    HIP_TRY(hipMemcpyAsync(d_in + 4 * kLattice, h_in + 4 * kLattice, 4 * sizeof(float), hipMemcpyHostToDevice,
+                           e->stream));
+    HIP_TRY(launch_pose_hits(e->stream, score_grid(e->grid[slot]), e->d_bx, e->d_by, e->nbeams, d_in + 4 * kLattice,
+                             d_out + 2 * kLattice + 1, reinterpret_cast<int32_t*>(d_out + 2 * kLattice)));
+    HIP_TRY(hipMemcpyAsync(h_out + 2 * kLattice, d_out + 2 * kLattice, sizeof(float) * (1 + (size_t)e->nbeams),
+                           hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    memcpy(count, h_out + 2 * kLattice, sizeof(int32_t));
+    if (*count > 0) memcpy(hits, h_out + 2 * kLattice + 1, sizeof(float) * (size_t)*count);
+    return SLAM_OK;
+}
+
+int slam_fastmatch_host(slam_engine* e, int slot, const float pose[3], const float res[3], float out_pose[3],
+                        float* best_hits, int32_t* best_hits_size, float* best_score)
+{
+    ENTER(e);
+    if (!pose || !res || !out_pose || !best_hits || !best_hits_size) return SLAM_ERR_INVALID_ARG;
+    if (int rc = check_score_inputs(e, slot)) return rc;
+
+    // main.c:386-387, :424-426 — the lattice is laid out once around the input pose; res[0] steps x
+    // AND y, res[2] steps theta, res[1] is never read.  Heading trig with the host libm, as the
+    // reference does (main.c:433-435).
+    const float t = res[0], r = res[2];
+    const float th[3] = { pose[2] - r, pose[2], pose[2] + r };
+    const float xs[3] = { pose[0] - t, pose[0], pose[0] + t };
+    const float ys[3] = { pose[1] - t, pose[1], pose[1] + t };
+    float* h_in = e->h_fm;
+    float* h_out = e->h_fm + kFmIn;
+    for (int a = 0; a < 3; ++a) {
+        const float c = cosf(th[a]), s = sinf(th[a]);
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) {
+                const int k = (a * 3 + i) * 3 + j;   // evaluation order theta, x, y (main.c:443-487)
+                h_in[k] = xs[i];
+                h_in[kLattice + k] = ys[j];
+                h_in[2 * kLattice + k] = c;
+                h_in[3 * kLattice + k] = s;
+            }
+    }
+    // the hit buffer ends up holding the LAST candidate's hits
+    for (int c = 0; c < 4; ++c) h_in[4 * kLattice + c] = h_in[c * kLattice + (kLattice - 1)];
+
+    float* d_in = e->fm_buf.as<float>();
+    float* d_out = d_in + kFmIn;
+    const ScoreGrid g = score_grid(e->grid[slot]);
+    HIP_TRY(hipMemcpyAsync(d_in, h_in, sizeof(float) * kFmIn, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(launch_score_poses(e->stream, g, e->d_bx, e->d_by, e->nbeams, d_in, d_in + kLattice, d_in + 2 * kLattice,
+                               d_in + 3 * kLattice, kLattice, d_out, reinterpret_cast<int32_t*>(d_out + kLattice)));
+    HIP_TRY(launch_pose_hits(e->stream, g, e->d_bx, e->d_by, e->nbeams, d_in + 4 * kLattice, d_out + 2 * kLattice + 1,
+                             reinterpret_cast<int32_t*>(d_out + 2 * kLattice)));
+    HIP_TRY(hipMemcpyAsync(h_out, d_out, sizeof(float) * (2 * kLattice + 1 + (size_t)e->nbeams), hipMemcpyDeviceToHost,
+                           e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+
+    // main.c:549-563 — strict '<' keeps the first of equal scores
+    float best = INFINITY;
+    int best_k = -1;
+    for (int k = 0; k < kLattice; ++k)
+        if (h_out[k] < best) {
+            best = h_out[k];
+            best_k = k;
+        }
+    if (best_k >= 0) {
+        out_pose[0] = h_in[best_k];
+        out_pose[1] = h_in[kLattice + best_k];
+        out_pose[2] = th[best_k / 9];
+        memcpy(best_hits_size, h_out + kLattice + best_k, sizeof(int32_t));
+    } else {   // nothing beat +inf (NaN scores): the reference returns the input pose, size untouched
+        out_pose[0] = pose[0];
+        out_pose[1] = pose[1];
+        out_pose[2] = pose[2];
+    }
+    int32_t nlast;
+    memcpy(&nlast, h_out + 2 * kLattice, sizeof nlast);
+    if (nlast > 0) memcpy(best_hits, h_out + 2 * kLattice + 1, sizeof(float) * (size_t)nlast);
+    if (best_score) *best_score = best;
+    return SLAM_OK;
+}
+
+/* ------------------------------------------------------------------ particle-filter stages */
+
+int slam_motion_sample_dev(slam_engine* e, const float* d_src_x, const float* d_src_y, const float* d_src_th,
+                           const int32_t* d_anc, float* d_x, float* d_y, float* d_th, int n, int64_t first_id,
+                           const float dp[3], const float sigma[3], uint64_t seed, uint32_t frame)
+{
+    ENTER(e);
+    if (n < 0 || first_id < 0 || !dp || !sigma ||
+        (n > 0 && (!d_src_x || !d_src_y || !d_src_th || !d_x || !d_y || !d_th)))
+        return SLAM_ERR_INVALID_ARG;
+    if (d_anc && (d_src_x == d_x || d_src_y == d_y || d_src_th == d_th)) return SLAM_ERR_INVALID_ARG;   // gather in place
+    HIP_TRY(launch_motion_sample(e->stream, d_src_x, d_src_y, d_src_th, d_anc, d_x, d_y, d_th, n, first_id, dp, sigma,
+                                 seed, frame));
+    return SLAM_OK;
+}
+
+int slam_obs_upload_host(slam_engine* e, const int32_t* landmark_id, const float* zx, const float* zy, int nobs,
+                         int nlandmarks)
+{
+    ENTER(e);
+    if (nobs < 0 || nlandmarks < 0 || (nobs > 0 && (!landmark_id || !zx || !zy))) return SLAM_ERR_INVALID_ARG;
+    if (nobs > SLAM_MAX_OBS) return SLAM_ERR_CAPACITY;
+    std::vector<char> seen((size_t)nlandmarks, 0);
+    for (int k = 0; k < nobs; ++k) {
+        const int32_t id = landmark_id[k];
+        if (id < 0 || id >= nlandmarks || seen[id]) return SLAM_ERR_INVALID_ARG;
+        seen[id] = 1;
+    }
+    std::vector<int32_t> unobs;
+    unobs.reserve((size_t)(nlandmarks - nobs));
+    for (int l = 0; l < nlandmarks; ++l)
+        if (!seen[l]) unobs.push_back(l);
+    const size_t words = 3 * (size_t)SLAM_MAX_OBS + (size_t)nlandmarks;
+    if (e->obs_buf.cap < words * 4) {
+        HIP_TRY(hipStreamSynchronize(e->stream));   // a running kernel may still read the old list
+        HIP_TRY(e->obs_buf.ensure(words * 4));
+    }
+    int32_t* d_id = e->obs_buf.as<int32_t>();
+    float* d_zx = e->obs_buf.as<float>() + SLAM_MAX_OBS;
+    float* d_zy = e->obs_buf.as<float>() + 2 * SLAM_MAX_OBS;
+    int32_t* d_un = e->obs_buf.as<int32_t>() + 3 * SLAM_MAX_OBS;
+    if (nobs > 0) {
+        HIP_TRY(hipMemcpyAsync(d_id, landmark_id, sizeof(int32_t) * nobs, hipMemcpyHostToDevice, e->stream));
+        HIP_TRY(hipMemcpyAsync(d_zx, zx, sizeof(float) * nobs, hipMemcpyHostToDevice, e->stream));
+        HIP_TRY(hipMemcpyAsync(d_zy, zy, sizeof(float) * nobs, hipMemcpyHostToDevice, e->stream));
+    }
+    if (!unobs.empty()) {
+        HIP_TRY(hipMemcpyAsync(d_un, unobs.data(), sizeof(int32_t) * unobs.size(), hipMemcpyHostToDevice, e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream));   // `unobs` is a stack-lifetime pageable buffer
+    }
+    e->d_obs_id = d_id;
+    e->d_obs_zx = d_zx;
+    e->d_obs_zy = d_zy;
+    e->d_unobs_id = d_un;
+    e->nobs = nobs;
+    e->nunobs = (int)unobs.size();
+    e->obs_nlandmarks = nlandmarks;
+    return SLAM_OK;
+}
+
+int slam_ekf_update_dev(slam_engine* e, const float* d_map_in, float* d_map_out, int64_t plane_stride, int ld_map,
+                        int nlandmarks, const float* d_x, const float* d_y, const float* d_th, const int32_t* d_anc,
+                        int n, float meas_var, float* d_loglik)
+{
+    ENTER(e);
+    if (n < 0 || nlandmarks < 0 || ld_map < n || plane_stride < (int64_t)nlandmarks * ld_map || !(meas_var > 0.0f) ||
+        (n > 0 && (!d_map_in || !d_map_out || !d_x || !d_y || !d_th || !d_loglik)))
+        return SLAM_ERR_INVALID_ARG;
+    if (d_anc && d_map_in == d_map_out) return SLAM_ERR_INVALID_ARG;
+    if (e->nobs < 0 || e->obs_nlandmarks != nlandmarks) return SLAM_ERR_NOT_READY;
+    if (n == 0) return SLAM_OK;
+    const int nchunks = (e->nobs + EKF_OBS_CHUNK - 1) / EKF_OBS_CHUNK;
+    EkfArgs a;
+    a.map_in = d_map_in;
+    a.map_out = d_map_out;
+    a.plane_stride = plane_stride;
+    a.ld = ld_map;
+    a.nlandmarks = nlandmarks;
+    a.x = d_x;
+    a.y = d_y;
+    a.th = d_th;
+    a.anc = d_anc;
+    a.n = n;
+    a.obs_id = e->d_obs_id;
+    a.obs_zx = e->d_obs_zx;
+    a.obs_zy = e->d_obs_zy;
+    a.nobs = e->nobs;
+    a.unobs_id = e->d_unobs_id;
+    a.nunobs = e->nunobs;
+    a.meas_var = meas_var;
+    a.loglik = d_loglik;
+    a.ll_part = nullptr;
+    if (nchunks > 1) {
+        HIP_TRY(e->scratch.ensure(sizeof(float) * (size_t)nchunks * (size_t)n));
+        a.ll_part = e->scratch.as<float>();
+    }
+    HIP_TRY(launch_ekf_update(e->stream, a));
+    return SLAM_OK;
+}
+
+int slam_logweight_dev(slam_engine* e, const float* d_score, const float* d_loglik, float score_gain, int n,
+                       float* d_logw, float* d_max)
+{
+    ENTER(e);
+    if (n <= 0 || !d_logw || !d_max) return SLAM_ERR_INVALID_ARG;
+    HIP_TRY(e->scratch.ensure(sizeof(float) * (size_t)logweight_scratch_elems(n)));
+    HIP_TRY(launch_logweight(e->stream, d_score, d_loglik, score_gain, n, d_logw, e->scratch.as<float>(), d_max));
+    return SLAM_OK;
+}
+
+int slam_quantise_weights_dev(slam_engine* e, const float* d_logw, const float* d_max, int n, uint64_t* d_wq,
+                              uint64_t* d_sum)
+{
+    ENTER(e);
+    if (n < 0 || !d_max || !d_sum || (n > 0 && (!d_logw || !d_wq))) return SLAM_ERR_INVALID_ARG;
+    HIP_TRY(launch_quantise_weights(e->stream, d_logw, d_max, n, d_wq, d_sum));
+    return SLAM_OK;
+}
+
+int slam_prefix_sum_dev(slam_engine* e, const uint64_t* d_wq, int n, uint64_t* d_cdf)
+{
+    ENTER(e);
+    if (n < 0 || (n > 0 && (!d_wq || !d_cdf))) return SLAM_ERR_INVALID_ARG;
+    if (n == 0) return SLAM_OK;
+    HIP_TRY(e->scratch.ensure(sizeof(uint64_t) * (size_t)prefix_sum_scratch_elems(n)));
+    HIP_TRY(launch_prefix_sum(e->stream, d_wq, n, d_cdf, e->scratch.as<uint64_t>()));
+    return SLAM_OK;
+}
+
+int slam_offspring_offsets_dev(slam_engine* e, const uint64_t* d_cdf, int n, uint64_t base, uint64_t total,
+                               uint64_t comb_u, int64_t n_total, int32_t* d_first)
+{
+    ENTER(e);
+    if (n < 0 || n_total < n || n_total > 0x7fffffff || total == 0 || (total >> 63) || comb_u >= total ||
+        (n > 0 && (!d_cdf || !d_first)))
+        return SLAM_ERR_INVALID_ARG;
+    HIP_TRY(launch_offspring_offsets(e->stream, d_cdf, n, base, total, comb_u, n_total, d_first));
+    return SLAM_OK;
+}
+
+int slam_ancestors_dev(slam_engine* e, const int32_t* d_first_all, int64_t n_total, int64_t slot0, int nslots,
+                       int32_t* d_anc)
+{
+    ENTER(e);
+    if (nslots < 0 || n_total <= 0 || slot0 < 0 || slot0 + nslots > n_total || !d_first_all || (nslots > 0 && !d_anc))
+        return SLAM_ERR_INVALID_ARG;
+    HIP_TRY(launch_ancestors(e->stream, d_first_all, n_total, slot0, nslots, d_anc));
+    return SLAM_OK;
+}
+
+uint64_t slam_comb_offset(uint64_t seed, uint32_t frame, uint64_t total)
+{
+    uint32_t c[4] = { 0u, 0u, frame, 1u /* resample stream */ };
+    philox_host(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+    const uint64_t r64 = (uint64_t)c[0] | ((uint64_t)c[1] << 32);
+    return (uint64_t)(((unsigned __int128)r64 * total) >> 64);
+}
+
+int slam_gather_f32_dev(slam_engine* e, const float* d_src, const int32_t* d_idx, int n, float* d_dst)
+{
+    ENTER(e);
+    if (n < 0 || (n > 0 && (!d_src || !d_idx || !d_dst)) || d_src == d_dst) return SLAM_ERR_INVALID_ARG;
+    HIP_TRY(launch_gather_f32(e->stream, d_src, d_idx, n, d_dst));
+    return SLAM_OK;
+}
+
+int slam_gather_map_dev(slam_engine* e, const float* d_map_in, float* d_map_out, int64_t in_plane_stride,
+                        int64_t out_plane_stride, int ld_in, int ld_out, int nlandmarks, const int32_t* d_idx, int n)
+{
+    ENTER(e);
+    if (n < 0 || nlandmarks < 0 || ld_out < n || (n > 0 && nlandmarks > 0 && (!d_map_in || !d_map_out || !d_idx)) ||
+        d_map_in == d_map_out)
+        return SLAM_ERR_INVALID_ARG;
+    HIP_TRY(launch_gather_map(e->stream, d_map_in, d_map_out, in_plane_stride, out_plane_stride, ld_in, ld_out,
+                              nlandmarks, d_idx, n));
+    return SLAM_OK;
+}
+
+}  // extern "C"

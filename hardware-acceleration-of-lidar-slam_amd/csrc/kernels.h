@@ -1,0 +1,70 @@
+// kernels.h — launchers of the gfx950 kernels, called by the C-ABI layer (engine.hip).
+// Every launcher enqueues on `stream` and returns the hipError_t of the launch; none synchronises.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/slam_hip.h"
+
+namespace slam {
+
+// ---- score_kernels.hip (reference: Subsystem_1/main.c:381-596)
+struct ScoreGrid {
+    const float* edt;   // [rows][ld]
+    int rows, cols, ld;
+    float ipix;         // 1 / pixel, computed on the host with one float division (main.c:383)
+    float min_x, min_y;
+};
+hipError_t launch_score_poses(hipStream_t stream, const ScoreGrid& g, const float* bx, const float* by, int nbeams,
+                              const float* x, const float* y, const float* th_or_ct, const float* st_or_null,
+                              int nposes, float* score, int32_t* count);
+hipError_t launch_pose_hits(hipStream_t stream, const ScoreGrid& g, const float* bx, const float* by, int nbeams,
+                            const float* pose_xycs /*4 floats on device*/, float* hits, int32_t* count);
+
+// ---- edt_kernels.hip (row A6; reference: main.c:223-269, main_accelerated.c:215-283)
+enum { EDT_MAX_RADIUS = 32 };
+hipError_t launch_edt(hipStream_t stream, const int32_t* occ, int ld, int rows, int cols, float cap, float* out);
+
+// ---- pf_kernels.hip (rows A9-A12; no reference counterpart)
+hipError_t launch_motion_sample(hipStream_t stream, const float* sx, const float* sy, const float* sth,
+                                const int32_t* anc, float* x, float* y, float* th, int n, int64_t first_id,
+                                const float dp[3], const float sigma[3], uint64_t seed, uint32_t frame);
+
+struct EkfArgs {
+    const float* map_in;
+    float* map_out;
+    int64_t plane_stride;
+    int ld, nlandmarks;
+    const float *x, *y, *th;
+    const int32_t* anc;
+    int n;
+    const int32_t* obs_id;   // device
+    const float *obs_zx, *obs_zy;
+    int nobs;
+    const int32_t* unobs_id;   // device list of landmarks without an observation (copy-through)
+    int nunobs;
+    float meas_var;
+    float* loglik;
+    float* ll_part;   // scratch [nchunks][n] (only read when nchunks > 1)
+};
+enum { EKF_OBS_CHUNK = 32 };
+hipError_t launch_ekf_update(hipStream_t stream, const EkfArgs& a);
+
+hipError_t launch_logweight(hipStream_t stream, const float* score, const float* loglik, float gain, int n,
+                            float* logw, float* block_max_scratch, float* d_max);
+int logweight_scratch_elems(int n);
+hipError_t launch_quantise_weights(hipStream_t stream, const float* logw, const float* d_max, int n, uint64_t* wq,
+                                   uint64_t* d_sum);
+
+hipError_t launch_prefix_sum(hipStream_t stream, const uint64_t* in, int n, uint64_t* out, uint64_t* block_scratch);
+int prefix_sum_scratch_elems(int n);
+hipError_t launch_offspring_offsets(hipStream_t stream, const uint64_t* cdf, int n, uint64_t base, uint64_t total,
+                                    uint64_t comb_u, int64_t n_total, int32_t* first);
+hipError_t launch_ancestors(hipStream_t stream, const int32_t* first_all, int64_t n_total, int64_t slot0, int nslots,
+                            int32_t* anc);
+hipError_t launch_gather_f32(hipStream_t stream, const float* src, const int32_t* idx, int n, float* dst);
+hipError_t launch_gather_map(hipStream_t stream, const float* in, float* out, int64_t in_stride, int64_t out_stride,
+                             int ld_in, int ld_out, int nlandmarks, const int32_t* idx, int n);
+
+}  // namespace slam

@@ -1,0 +1,495 @@
+// pf_kernels.hip — particle-filter stages around the scan matcher.
+//
+// None of these stages exists in the reference: the specification is DESIGN.md
+// + oracle/slam_oracle_pf.c, and these kernels match that specification bit for bit.  The only
+// reference anchor is the zero-noise motion step = the constant-velocity predict of
+// Subsystem_1/main.c:875-898.
+//
+// Data layout (HBM): particles are SoA float arrays; the per-particle landmark maps are five
+// planes [L][ld] (mu_x, mu_y, P_xx, P_xy, P_yy) with the particle index fastest, so a wavefront
+// reads/writes 64 consecutive particles of one landmark = 256 contiguous bytes per plane.
+// All kernels are HBM-streaming or latency-bound integer work; there is no GEMM shape here
+// (the largest matrix is 2x2), hence no MFMA.
+
+#include "det_math.h"
+#include "kernels.h"
+
+namespace slam {
+
+namespace {
+
+constexpr int kBlock = 256;
+
+// ------------------------------------------------------------------ A9: motion sample
+struct MotionConst {
+    float dp[3];
+    float sigma[3];
+};
+
+__global__ __launch_bounds__(kBlock) void motion_sample_kernel(const float* __restrict__ sx,
+                                                               const float* __restrict__ sy,
+                                                               const float* __restrict__ sth,
+                                                               const int32_t* __restrict__ anc, float* __restrict__ x,
+                                                               float* __restrict__ y, float* __restrict__ th, int n,
+                                                               uint64_t first_id, MotionConst mc, uint32_t key0,
+                                                               uint32_t key1, uint32_t frame)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t gid = first_id + (uint64_t)i;
+    const u32x4 r = philox4x32_10((uint32_t)gid, (uint32_t)(gid >> 32), frame, 0u /* motion stream */, key0, key1);
+    const float u1 = (float)((r.v[0] >> 8) + 1u) * 5.9604644775390625e-8f;
+    const float u2 = (float)(r.v[1] >> 8) * 5.9604644775390625e-8f;
+    const float u3 = (float)((r.v[2] >> 8) + 1u) * 5.9604644775390625e-8f;
+    const float u4 = (float)(r.v[3] >> 8) * 5.9604644775390625e-8f;
+    float s1, c1, s2, c2;
+    const float rad1 = sqrtf(-2.0f * det_logf(u1));
+    det_sincosf(6.2831853072f * u2, s1, c1);
+    const float rad2 = sqrtf(-2.0f * det_logf(u3));
+    det_sincosf(6.2831853072f * u4, s2, c2);
+    const float z0 = rad1 * c1, z1 = rad1 * s1, z2 = rad2 * c2;
+    const int j = anc ? anc[i] : i;
+    x[i] = (sx[j] + mc.dp[0]) + mc.sigma[0] * z0;
+    y[i] = (sy[j] + mc.dp[1]) + mc.sigma[1] * z1;
+    th[i] = (sth[j] + mc.dp[2]) + mc.sigma[2] * z2;
+}
+
+// ------------------------------------------------------------------ A10: 2x2 EKF per (particle, landmark)
+// grid = (particle tiles, observation chunks).  A thread owns one particle and walks one chunk of
+// EKF_OBS_CHUNK observations; consecutive lanes = consecutive particles, so each of the 5 loads and 5
+// stores per landmark is a 256-byte coalesced wave access.  The observation list (id, zx, zy) is
+// wave-uniform and read through the scalar path.
+__global__ __launch_bounds__(kBlock) void ekf_update_kernel(EkfArgs a)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= a.n) return;
+    const int chunk = blockIdx.y;
+    const int k0 = chunk * EKF_OBS_CHUNK;
+    const int k1 = min(k0 + EKF_OBS_CHUNK, a.nobs);
+
+    float st, ct;
+    det_sincosf(a.th[i], st, ct);
+    const float px = a.x[i], py = a.y[i];
+    const int src = a.anc ? a.anc[i] : i;
+    const float q = a.meas_var;
+    const int64_t ps = a.plane_stride;
+    const float* __restrict__ in = a.map_in;
+    float* __restrict__ out = a.map_out;
+
+    float part = 0.0f;
+#pragma unroll 4
+    for (int k = k0; k < k1; ++k) {
+        const int64_t row = (int64_t)a.obs_id[k] * a.ld;
+        const int64_t ri = row + src, wi = row + i;
+        const float mx = in[ri], my = in[ps + ri], pxx = in[2 * ps + ri], pxy = in[3 * ps + ri],
+                    pyy = in[4 * ps + ri];
+        const float zx = a.obs_zx[k], zy = a.obs_zy[k];
+        float omx, omy, oxx, oxy, oyy;
+        if (pxx < 0.0f) {   // first sighting
+            omx = px + (ct * zx + st * zy);
+            omy = py + (ct * zy - st * zx);
+            oxx = q;
+            oxy = 0.0f;
+            oyy = q;
+        } else {
+            const float dx = mx - px, dy = my - py;
+            const float vx = zx - (ct * dx - st * dy);
+            const float vy = zy - (st * dx + ct * dy);
+            const float a00 = ct * pxx - st * pxy, a01 = ct * pxy - st * pyy;
+            const float a10 = st * pxx + ct * pxy, a11 = st * pxy + ct * pyy;
+            const float s00 = (a00 * ct - a01 * st) + q;
+            const float s01 = a00 * st + a01 * ct;
+            const float s11 = (a10 * st + a11 * ct) + q;
+            const float det = s00 * s11 - s01 * s01;
+            const float idet = 1.0f / det;
+            const float i00 = s11 * idet, i01 = -s01 * idet, i11 = s00 * idet;
+            const float k00 = a00 * i00 + a10 * i01, k01 = a00 * i01 + a10 * i11;
+            const float k10 = a01 * i00 + a11 * i01, k11 = a01 * i01 + a11 * i11;
+            omx = mx + (k00 * vx + k01 * vy);
+            omy = my + (k10 * vx + k11 * vy);
+            oxx = pxx - (k00 * a00 + k01 * a10);
+            oxy = pxy - (k00 * a01 + k01 * a11);
+            oyy = pyy - (k10 * a01 + k11 * a11);
+            const float maha = vx * (i00 * vx + i01 * vy) + vy * (i01 * vx + i11 * vy);
+            part = ((part - 0.5f * maha) - 0.5f * det_logf(det)) - 1.8378770664f;
+        }
+        out[wi] = omx;
+        out[ps + wi] = omy;
+        out[2 * ps + wi] = oxx;
+        out[3 * ps + wi] = oxy;
+        out[4 * ps + wi] = oyy;
+    }
+    if (gridDim.y == 1)
+        a.loglik[i] = 0.0f + part;
+    else
+        a.ll_part[(int64_t)chunk * a.n + i] = part;
+}
+
+__global__ __launch_bounds__(kBlock) void ekf_loglik_finalize_kernel(const float* __restrict__ part, int nchunks, int n,
+                                                                     float* __restrict__ loglik)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    float total = 0.0f;
+    for (int c = 0; c < nchunks; ++c) total = total + part[(int64_t)c * n + i];
+    loglik[i] = total;
+}
+
+// landmarks without an observation: gathered copy in -> out (only for out-of-place updates)
+__global__ __launch_bounds__(kBlock) void map_copy_through_kernel(EkfArgs a)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= a.n) return;
+    const int src = a.anc ? a.anc[i] : i;
+    const int64_t ps = a.plane_stride;
+    for (int u = blockIdx.y; u < a.nunobs; u += gridDim.y) {
+        const int64_t row = (int64_t)a.unobs_id[u] * a.ld;
+#pragma unroll
+        for (int p = 0; p < 5; ++p) a.map_out[p * ps + row + i] = a.map_in[p * ps + row + src];
+    }
+}
+
+// ------------------------------------------------------------------ A11: weights
+__device__ __forceinline__ float wave_max(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+__global__ __launch_bounds__(kBlock) void logweight_kernel(const float* __restrict__ score,
+                                                           const float* __restrict__ loglik, float gain, int n,
+                                                           float* __restrict__ logw, float* __restrict__ block_max)
+{
+    __shared__ float s_max[kBlock / 64];
+    float m = -INFINITY;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        const float ll = loglik ? loglik[i] : 0.0f;
+        const float sc = score ? score[i] * gain : 0.0f;
+        const float lw = ll - sc;
+        logw[i] = lw;
+        m = lw > m ? lw : m;
+    }
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kBlock / 64; ++w) m = fmaxf(m, s_max[w]);
+        block_max[blockIdx.x] = m;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void max_finalize_kernel(const float* __restrict__ block_max, int nblocks,
+                                                              float* __restrict__ d_max)
+{
+    __shared__ float s_max[kBlock / 64];
+    float m = -INFINITY;
+    for (int i = threadIdx.x; i < nblocks; i += kBlock) m = fmaxf(m, block_max[i]);
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kBlock / 64; ++w) m = fmaxf(m, s_max[w]);
+        *d_max = m;
+    }
+}
+
+__device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t lo = __shfl_xor((uint32_t)v, o), hi = __shfl_xor((uint32_t)(v >> 32), o);
+        v += ((uint64_t)hi << 32) | lo;
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(kBlock) void quantise_weights_kernel(const float* __restrict__ logw,
+                                                                  const float* __restrict__ d_max, int n,
+                                                                  uint64_t* __restrict__ wq,
+                                                                  unsigned long long* __restrict__ d_sum)
+{
+    __shared__ uint64_t s_sum[kBlock / 64];
+    const float m = *d_max;
+    uint64_t acc = 0;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        const float w = det_expf(logw[i] - m);
+        const uint64_t q = (uint64_t)(w * 4294967296.0f);
+        wq[i] = q;
+        acc += q;
+    }
+    acc = wave_sum_u64(acc);
+    if ((threadIdx.x & 63) == 0) s_sum[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kBlock / 64; ++w) acc += s_sum[w];
+        atomicAdd(d_sum, (unsigned long long)acc);   // integer: exact and order-independent
+    }
+}
+
+// ------------------------------------------------------------------ A12: integer CDF, comb, ancestors
+constexpr int kScanItems = 8;                       // elements per thread
+constexpr int kScanTile = kBlock * kScanItems;      // 2048 elements per workgroup
+
+__device__ __forceinline__ uint64_t shfl_up_u64(uint64_t v, int d)
+{
+    const uint32_t lo = __shfl_up((uint32_t)v, d), hi = __shfl_up((uint32_t)(v >> 32), d);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// inclusive scan of one value per thread over the workgroup: wavefront scan + carry through LDS
+__device__ __forceinline__ uint64_t block_inclusive_scan(uint64_t v, uint64_t* s_wave /*[kBlock/64]*/, uint64_t& total)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint64_t up = shfl_up_u64(v, d);
+        if (lane >= d) v += up;
+    }
+    if (lane == 63) s_wave[wave] = v;
+    __syncthreads();
+    uint64_t carry = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < kBlock / 64; ++w) {
+        if (w < wave) carry += s_wave[w];
+        tot += s_wave[w];
+    }
+    total = tot;
+    __syncthreads();
+    return v + carry;
+}
+
+__global__ __launch_bounds__(kBlock) void scan_tiles_kernel(const uint64_t* __restrict__ in, int n,
+                                                            uint64_t* __restrict__ out,
+                                                            uint64_t* __restrict__ tile_total)
+{
+    __shared__ uint64_t s_wave[kBlock / 64];
+    const int base = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
+    uint64_t v[kScanItems];
+    uint64_t run = 0;
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+        const int i = base + k;
+        run += i < n ? in[i] : 0;
+        v[k] = run;
+    }
+    uint64_t total;
+    const uint64_t incl = block_inclusive_scan(run, s_wave, total);
+    const uint64_t excl = incl - run;
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+        const int i = base + k;
+        if (i < n) out[i] = v[k] + excl;
+    }
+    if (threadIdx.x == 0) tile_total[blockIdx.x] = total;
+}
+
+// exclusive scan of the tile totals, in place, by ONE workgroup (<= a few thousand tiles)
+__global__ __launch_bounds__(kBlock) void scan_totals_kernel(uint64_t* __restrict__ tile_total, int ntiles)
+{
+    __shared__ uint64_t s_wave[kBlock / 64];
+    uint64_t carry = 0;
+    for (int t0 = 0; t0 < ntiles; t0 += kBlock) {
+        const int t = t0 + threadIdx.x;
+        const uint64_t v = t < ntiles ? tile_total[t] : 0;
+        uint64_t total;
+        const uint64_t incl = block_inclusive_scan(v, s_wave, total);
+        if (t < ntiles) tile_total[t] = carry + incl - v;
+        carry += total;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void add_tile_offsets_kernel(uint64_t* __restrict__ out, int n,
+                                                                  const uint64_t* __restrict__ tile_excl)
+{
+    const uint64_t off = tile_excl[blockIdx.x];
+    const int base = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+        const int i = base + k;
+        if (i < n) out[i] += off;
+    }
+}
+
+// floor((hi:lo) / d) for hi < d < 2^63 (so the quotient fits 64 bits): restoring long division
+__device__ __forceinline__ uint64_t div128by64(uint64_t hi, uint64_t lo, uint64_t d)
+{
+    uint64_t rem = hi, q = 0;
+#pragma unroll 8
+    for (int b = 63; b >= 0; --b) {
+        rem = (rem << 1) | ((lo >> b) & 1ull);
+        if (rem >= d) {
+            rem -= d;
+            q |= 1ull << b;
+        }
+    }
+    return q;
+}
+
+__global__ __launch_bounds__(kBlock) void offspring_offsets_kernel(const uint64_t* __restrict__ cdf, int n,
+                                                                   uint64_t base, uint64_t total, uint64_t comb_u,
+                                                                   uint64_t n_total, int32_t* __restrict__ first)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t c_excl = base + (i ? cdf[i - 1] : 0ull);
+    // X = c_excl * n_total as 128 bits
+    uint64_t lo = c_excl * n_total, hi = __umul64hi(c_excl, n_total);
+    int32_t f = 0;
+    if (hi != 0 || lo > comb_u) {
+        // (X - u - 1) / total + 1
+        const uint64_t sub = comb_u + 1ull;   // comb_u < total < 2^63: no overflow
+        hi -= lo < sub ? 1ull : 0ull;
+        lo -= sub;
+        f = (int32_t)(div128by64(hi, lo, total) + 1ull);
+    }
+    first[i] = f;
+}
+
+__global__ __launch_bounds__(kBlock) void ancestors_kernel(const int32_t* __restrict__ first_all, int64_t n_total,
+                                                           int64_t slot0, int nslots, int32_t* __restrict__ anc)
+{
+    const int s = blockIdx.x * kBlock + threadIdx.x;
+    if (s >= nslots) return;
+    const int64_t j = slot0 + s;
+    int64_t lo = 0, hi = n_total;   // first index whose first slot is > j
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if ((int64_t)first_all[mid] <= j) lo = mid + 1; else hi = mid;
+    }
+    anc[s] = (int32_t)(lo - 1);
+}
+
+__global__ __launch_bounds__(kBlock) void gather_f32_kernel(const float* __restrict__ src,
+                                                            const int32_t* __restrict__ idx, int n,
+                                                            float* __restrict__ dst)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) dst[i] = src[idx[i]];
+}
+
+__global__ __launch_bounds__(kBlock) void gather_map_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                            int64_t in_stride, int64_t out_stride, int ld_in,
+                                                            int ld_out, int nlandmarks,
+                                                            const int32_t* __restrict__ idx, int n)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const int src = idx[i];
+    for (int l = blockIdx.y; l < nlandmarks; l += gridDim.y) {
+#pragma unroll
+        for (int p = 0; p < 5; ++p)
+            out[p * out_stride + (int64_t)l * ld_out + i] = in[p * in_stride + (int64_t)l * ld_in + src];
+    }
+}
+
+inline int blocks_for(int n) { return (n + kBlock - 1) / kBlock; }
+
+}  // namespace
+
+hipError_t launch_motion_sample(hipStream_t stream, const float* sx, const float* sy, const float* sth,
+                                const int32_t* anc, float* x, float* y, float* th, int n, int64_t first_id,
+                                const float dp[3], const float sigma[3], uint64_t seed, uint32_t frame)
+{
+    if (n <= 0) return hipSuccess;
+    MotionConst mc;
+    for (int k = 0; k < 3; ++k) {
+        mc.dp[k] = dp[k];
+        mc.sigma[k] = sigma[k];
+    }
+    motion_sample_kernel<<<blocks_for(n), kBlock, 0, stream>>>(sx, sy, sth, anc, x, y, th, n, (uint64_t)first_id, mc,
+                                                               (uint32_t)seed, (uint32_t)(seed >> 32), frame);
+    return hipGetLastError();
+}
+
+hipError_t launch_ekf_update(hipStream_t stream, const EkfArgs& a)
+{
+    if (a.n <= 0) return hipSuccess;
+    const int nchunks = (a.nobs + EKF_OBS_CHUNK - 1) / EKF_OBS_CHUNK;
+    if (a.map_in != a.map_out && a.nunobs > 0) {
+        const int gy = a.nunobs < 1024 ? a.nunobs : 1024;
+        map_copy_through_kernel<<<dim3(blocks_for(a.n), gy), kBlock, 0, stream>>>(a);
+    }
+    if (nchunks == 0) {
+        hipError_t err = hipMemsetAsync(a.loglik, 0, sizeof(float) * (size_t)a.n, stream);
+        return err != hipSuccess ? err : hipGetLastError();
+    }
+    ekf_update_kernel<<<dim3(blocks_for(a.n), nchunks), kBlock, 0, stream>>>(a);
+    if (nchunks > 1)
+        ekf_loglik_finalize_kernel<<<blocks_for(a.n), kBlock, 0, stream>>>(a.ll_part, nchunks, a.n, a.loglik);
+    return hipGetLastError();
+}
+
+static int capped_blocks(int n) { const int b = blocks_for(n); return b < 2048 ? b : 2048; }
+int logweight_scratch_elems(int n) { return capped_blocks(n > 0 ? n : 1); }
+
+hipError_t launch_logweight(hipStream_t stream, const float* score, const float* loglik, float gain, int n,
+                            float* logw, float* block_max_scratch, float* d_max)
+{
+    if (n <= 0) return hipSuccess;
+    const int nb = capped_blocks(n);
+    logweight_kernel<<<nb, kBlock, 0, stream>>>(score, loglik, gain, n, logw, block_max_scratch);
+    max_finalize_kernel<<<1, kBlock, 0, stream>>>(block_max_scratch, nb, d_max);
+    return hipGetLastError();
+}
+
+hipError_t launch_quantise_weights(hipStream_t stream, const float* logw, const float* d_max, int n, uint64_t* wq,
+                                   uint64_t* d_sum)
+{
+    hipError_t err = hipMemsetAsync(d_sum, 0, sizeof(uint64_t), stream);
+    if (err != hipSuccess) return err;
+    if (n <= 0) return hipSuccess;
+    quantise_weights_kernel<<<capped_blocks(n), kBlock, 0, stream>>>(logw, d_max, n, wq,
+                                                                     reinterpret_cast<unsigned long long*>(d_sum));
+    return hipGetLastError();
+}
+
+int prefix_sum_scratch_elems(int n) { return (n + kScanTile - 1) / kScanTile + 1; }
+
+hipError_t launch_prefix_sum(hipStream_t stream, const uint64_t* in, int n, uint64_t* out, uint64_t* block_scratch)
+{
+    if (n <= 0) return hipSuccess;
+    const int ntiles = (n + kScanTile - 1) / kScanTile;
+    scan_tiles_kernel<<<ntiles, kBlock, 0, stream>>>(in, n, out, block_scratch);
+    if (ntiles > 1) {
+        scan_totals_kernel<<<1, kBlock, 0, stream>>>(block_scratch, ntiles);
+        add_tile_offsets_kernel<<<ntiles, kBlock, 0, stream>>>(out, n, block_scratch);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_offspring_offsets(hipStream_t stream, const uint64_t* cdf, int n, uint64_t base, uint64_t total,
+                                    uint64_t comb_u, int64_t n_total, int32_t* first)
+{
+    if (n <= 0) return hipSuccess;
+    offspring_offsets_kernel<<<blocks_for(n), kBlock, 0, stream>>>(cdf, n, base, total, comb_u, (uint64_t)n_total,
+                                                                   first);
+    return hipGetLastError();
+}
+
+hipError_t launch_ancestors(hipStream_t stream, const int32_t* first_all, int64_t n_total, int64_t slot0, int nslots,
+                            int32_t* anc)
+{
+    if (nslots <= 0) return hipSuccess;
+    ancestors_kernel<<<blocks_for(nslots), kBlock, 0, stream>>>(first_all, n_total, slot0, nslots, anc);
+    return hipGetLastError();
+}
+
+hipError_t launch_gather_f32(hipStream_t stream, const float* src, const int32_t* idx, int n, float* dst)
+{
+    if (n <= 0) return hipSuccess;
+    gather_f32_kernel<<<blocks_for(n), kBlock, 0, stream>>>(src, idx, n, dst);
+    return hipGetLastError();
+}
+
+hipError_t launch_gather_map(hipStream_t stream, const float* in, float* out, int64_t in_stride, int64_t out_stride,
+                             int ld_in, int ld_out, int nlandmarks, const int32_t* idx, int n)
+{
+    if (n <= 0 || nlandmarks <= 0) return hipSuccess;
+    const int gy = nlandmarks < 1024 ? nlandmarks : 1024;
+    gather_map_kernel<<<dim3(blocks_for(n), gy), kBlock, 0, stream>>>(in, out, in_stride, out_stride, ld_in, ld_out,
+                                                                      nlandmarks, idx, n);
+    return hipGetLastError();
+}
+
+}  // namespace slam

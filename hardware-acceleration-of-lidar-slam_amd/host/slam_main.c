@@ -1,0 +1,162 @@
+/*
+ * slam_main — the reference's SLAM program with its hot path on the MI355X engine.
+ *
+ * Same inputs and outputs as Subsystem_1/main_accelerated.c: scan-frame CSV in ("%f," x beams per
+ * frame, main.c:22-30), "scan N" and "pose = %f  %f  %f" lines on stdout (main.c:860, :965), map
+ * points as "%f,%f" lines out (main.c:982-985).  The frame loop below mirrors main.c:825-990; the two
+ * hot stages are calls into the C ABI (include/slam_hip.h):
+ *     OccupationalGrid's two EDTs   -> slam_grid_upload_host   (replaces main_accelerated.c:215-283)
+ *     FastMatch / FastMatch2        -> slam_fastmatch_host     (replaces main.c:381-809)
+ * The grids and the scan stay resident on the GPU between the calls of one frame.
+ *
+ * usage: slam_main dataset.csv frames beams map_out.csv [angle_min angle_inc]
+ * Fails (non-zero exit) when no gfx950 GPU is available: there is no CPU fallback.
+ */
+#define _POSIX_C_SOURCE 200809L
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include "slam_frontend.h"
+
+static double now_s(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+#define CHECK(call)                                                                                     \
+    do {                                                                                                \
+        int rc__ = (call);                                                                              \
+        if (rc__ != SLAM_OK) {                                                                          \
+            fprintf(stderr, "%s failed: %s (%s)\n", #call, slam_status_string(rc__), slam_last_error(eng)); \
+            return 1;                                                                                   \
+        }                                                                                               \
+    } while (0)
+
+int main(int argc, char **argv)
+{
+    if (argc < 5) {
+        fprintf(stderr, "usage: %s dataset.csv frames beams map_out.csv [angle_min angle_inc]\n", argv[0]);
+        return 2;
+    }
+    FILE *in = fopen(argv[1], "r");
+    if (!in) { perror(argv[1]); return 1; }
+    const int frames = atoi(argv[2]);
+    const int beams = atoi(argv[3]);
+    const float angle_min = argc > 6 ? (float)atof(argv[5]) : -2.351831f;   /* main.c:47 */
+    const float angle_inc = argc > 6 ? (float)atof(argv[6]) : 0.004363f;    /* main.c:49 */
+
+    /* constants of main.c:830-839 */
+    const float coarse_step[3] = { 0.05f, 0.05f, 0.008727f };
+    const float fine_step[3] = { 0.025f, 0.025f, 0.004363f };
+    const float border = 1, pixel_coarse = 0.2f, pixel_fine = 0.1f;
+    const float key_dt = 0.3f, key_dr = 0.0872665f;
+    const float edt_cap = 10;   /* main.c:224 */
+
+    slam_engine *eng = NULL;
+    {
+        int rc = slam_engine_create(0, &eng);
+        if (rc != SLAM_OK) {
+            fprintf(stderr, "slam_engine_create: %s\n", slam_status_string(rc));
+            return 1;
+        }
+    }
+    fe_scan scan;
+    fe_points map, local;
+    fe_grid coarse, fine;
+    if (fe_scan_init(&scan, beams, angle_min, angle_inc) || fe_points_init(&map, FE_MAP_CAPACITY + beams) ||
+        fe_points_init(&local, FE_LOCAL_CAPACITY) || fe_grid_init(&coarse, FE_COARSE_LD) || fe_grid_init(&fine, FE_FINE_LD)) {
+        fprintf(stderr, "out of memory\n");
+        return 1;
+    }
+    float *hits = (float *)calloc((size_t)beams + 1, sizeof(float));
+    int32_t nhits = 0;
+
+    double t_edt = 0, t_match = 0;
+    long n_edt = 0, n_match = 0;
+    const double t_begin = now_s();
+
+    /* main.c:844-858: frame 0 at the origin seeds the map */
+    float pose[3] = { 0, 0, 0 }, prev[3] = { 0, 0, 0 };
+    fe_read_frame(in, &scan);
+    fe_clean(&scan, 0.023f, 24);
+    fe_to_world(&scan, pose);
+    memcpy(map.x, scan.wx, sizeof(float) * (size_t)scan.nscan);
+    memcpy(map.y, scan.wy, sizeof(float) * (size_t)scan.nscan);
+    map.size = scan.nscan;
+    memcpy(map.pose, pose, sizeof pose);
+    int mini_updated = 1;
+
+    for (int k = 1; k < frames; ++k) {
+        printf("scan %d\n", k + 1);
+        fe_read_frame(in, &scan);
+        fe_clean(&scan, 0.023f, 24);
+        CHECK(slam_scan_upload_host(eng, scan.bx, scan.by, scan.nscan));
+        int in_world = 0;
+        if (mini_updated) {   /* main.c:865-872 (world points from the OLD pose) */
+            fe_to_world(&scan, pose);
+            in_world = 1;
+            fe_crop(&map, &scan, border, &local);
+            if (fe_rasterise(&local, pixel_coarse, &coarse) || fe_rasterise(&local, pixel_fine, &fine)) {
+                fprintf(stderr, "frame %d: map extent exceeds the %d/%d-cell grids\n", k + 1, FE_COARSE_LD, FE_FINE_LD);
+                return 1;
+            }
+            const double t0 = now_s();
+            CHECK(slam_grid_upload_host(eng, 0, coarse.cell, &coarse.meta, edt_cap, NULL));
+            CHECK(slam_grid_upload_host(eng, 1, fine.cell, &fine.meta, edt_cap, NULL));
+            t_edt += now_s() - t0;
+            n_edt += 2;
+        }
+        /* main.c:875-898 */
+        float guess[3];
+        for (int a = 0; a < 3; ++a) guess[a] = k > 1 ? pose[a] + (pose[a] - prev[a]) : pose[a];
+        /* main.c:901-918 (coarse step on the fine grid when the map was not just rebuilt, Q4) */
+        float m1[3], m2[3];
+        const double t1 = now_s();
+        CHECK(slam_fastmatch_host(eng, mini_updated ? 0 : 1, guess, coarse_step, m1, hits, &nhits, NULL));
+        CHECK(slam_fastmatch_host(eng, 1, m1, fine_step, m2, hits, &nhits, NULL));
+        t_match += now_s() - t1;
+        n_match += 2;
+        memcpy(prev, pose, sizeof prev);
+        memcpy(pose, m2, sizeof pose);
+
+        /* main.c:928-961 */
+        if (fabsf(pose[0] - map.pose[0]) > key_dt || fabsf(pose[1] - map.pose[1]) > key_dt ||
+            fabsf(pose[2] - map.pose[2]) > key_dr) {
+            mini_updated = 1;
+            if (!in_world) fe_to_world(&scan, pose);
+            int added = 0;
+            for (int j = 0; j < nhits; ++j)   /* hits of the LAST candidate, count of the BEST (Q2) */
+                if (hits[j] > 1.5 && map.size + added < map.capacity) {
+                    map.x[map.size + added] = scan.wx[j];
+                    map.y[map.size + added] = scan.wy[j];
+                    ++added;
+                }
+            map.size += added;
+            memcpy(map.pose, pose, sizeof pose);
+        } else {
+            mini_updated = 0;
+        }
+        printf("pose = %f  %f  %f\n", pose[0], pose[1], pose[2]);
+    }
+    const double wall = now_s() - t_begin;
+    fclose(in);
+    fprintf(stderr, "frames %d  wall %.6f s  edt %.6f s / %ld calls  match %.6f s / %ld calls\n", frames, wall, t_edt,
+            n_edt, t_match, n_match);
+
+    FILE *out = fopen(argv[4], "w");
+    if (!out) { perror(argv[4]); return 1; }
+    for (int j = 0; j < map.size; ++j) fprintf(out, "%f,%f\n", map.x[j], map.y[j]);
+    fclose(out);
+
+    free(hits);
+    fe_grid_free(&coarse); fe_grid_free(&fine);
+    fe_points_free(&map); fe_points_free(&local);
+    fe_scan_free(&scan);
+    slam_engine_destroy(eng);
+    return 0;
+}

@@ -1,0 +1,198 @@
+/*
+ * slam_hip.h — C ABI of the MI355X (gfx950) scan-matching / particle-filter engine.
+ *
+ * This is the drop-in boundary for the hot path of circuitpotato/Hardware-Acceleration-of-LIDAR-SLAM:
+ * the functions below replace, one stage per call, what Subsystem_1/main_accelerated.c does in
+ *   euclidean_distance_transform / euclidean_distance_transform2   (main_accelerated.c:215-283)
+ *   FastMatch / FastMatch2                                        (main_accelerated.c:396-824)
+ * and add the particle-filter stages the north star asks for around them (motion sample,
+ * per-particle x per-landmark 2x2 EKF, weight normalisation, systematic resample), for which the
+ * reference has no code.  INTEGRATION.md shows the edits a maintainer of the
+ * reference makes to call these from main_accelerated.c.
+ *
+ * Conventions
+ *  - plain C, no C++/torch types; every function returns a slam_status (0 = OK, < 0 = error) and
+ *    never aborts or exits (the reference's functions are all `void` and print-and-continue,
+ *    main.c:15-20; we return codes instead).
+ *  - `slam_engine` is an opaque handle created once and passed to every call — the same shape as the
+ *    `accel` handle the reference's FPGA variant threads through OccupationalGrid/EDT
+ *    (Submodule_2/Hadrware_acclereated.cpp:236,260,284,842-845).  One engine per host thread / GPU;
+ *    calls on one engine are serialised on one HIP stream.
+ *  - `*_host` entry points take caller-owned HOST buffers (as the reference's functions do), copy,
+ *    launch, copy back and synchronise.  `*_dev` entry points take DEVICE pointers, are asynchronous
+ *    on the engine's stream and keep everything resident in HBM; they are what a frame loop with
+ *    many particles uses.  The boundary is crossed once per frame stage, never per element (the
+ *    reference's FPGA path crossed it once per distance, Hadrware_acclereated.cpp:223-233).
+ *  - there is NO CPU fallback: if no gfx950 device is usable the calls fail with SLAM_ERR_NO_DEVICE.
+ *  - float arithmetic of the reference-pinned stages (EDT, score) is bit-exact with the reference:
+ *    same operation order, no FMA contraction.
+ */
+#ifndef SLAM_HIP_H
+#define SLAM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SLAM_ABI_VERSION 1
+
+typedef enum {
+    SLAM_OK = 0,
+    SLAM_ERR_NO_DEVICE = -1,   /* no usable gfx950 GPU / HIP runtime error at init */
+    SLAM_ERR_INVALID_ARG = -2, /* null pointer, negative size, slot out of range, ... */
+    SLAM_ERR_HIP = -3,         /* a HIP runtime call failed; slam_last_error() has the text */
+    SLAM_ERR_NOT_READY = -4,   /* stage called before its inputs were provided (e.g. no grid in slot) */
+    SLAM_ERR_CAPACITY = -5     /* request exceeds a fixed capacity (beams, lattice size, ...) */
+} slam_status;
+
+typedef struct slam_engine slam_engine;
+
+/* Bookkeeping of one occupancy/EDT grid: the fields the reference keeps beside each grid in
+ * `MyGrid` (main.c:200-213): grid_size{rows,cols}, pixel_size, top_left_corner; `ld` is the leading
+ * dimension of the row-major storage (fixed 200 / 400 in the reference). */
+typedef struct {
+    int32_t rows, cols, ld;
+    float pixel;
+    float min_x, min_y;
+} slam_grid_meta;
+
+/* ------------------------------------------------------------------ engine lifetime */
+
+int slam_abi_version(void);
+const char *slam_status_string(int status);
+/* text of the most recent HIP error seen by this engine (empty string if none) */
+const char *slam_last_error(const slam_engine *e);
+
+/* device: HIP device ordinal.  Fails with SLAM_ERR_NO_DEVICE when there is none. */
+int slam_engine_create(int device, slam_engine **out);
+int slam_engine_destroy(slam_engine *e);
+/* Run the engine on a caller-provided hipStream_t (e.g. the framework's current stream) instead of
+ * its own; NULL restores the engine's own stream. */
+int slam_engine_set_stream(slam_engine *e, void *hip_stream);
+int slam_engine_sync(slam_engine *e);
+
+/* ------------------------------------------------------------------ EDT */
+
+/* Capped exact Euclidean distance transform of occ[0..rows)[0..cols) (row-major, leading dimension
+ * ld, non-zero = occupied): out = 0 on occupied cells, else min(cap, sqrtf(min d^2)) in cells; cells
+ * outside rows x cols are not written.  Replaces euclidean_distance_transform{,2}
+ * (main.c:223-269, main_accelerated.c:215-283). */
+int slam_edt_dev(slam_engine *e, const int32_t *d_occ, int ld, int rows, int cols, float cap, float *d_out);
+int slam_edt_host(slam_engine *e, const int32_t *occ, int ld, int rows, int cols, float cap, float *out);
+
+/* ------------------------------------------------------------------ engine-resident grids + scan
+ * (what the reference keeps in the globals `occ_grid` and `scan`) */
+
+enum { SLAM_MAX_GRID_SLOTS = 4, SLAM_MAX_BEAMS = 4096 };
+
+/* Upload an occupancy grid, build its EDT on the device and keep it as grid `slot` (0 = the coarse
+ * grid FastMatch reads, 1 = the fine grid FastMatch2 reads).  When edt_out != NULL the EDT is also
+ * copied back in the same [.. ][ld] layout (only the rows x cols rectangle is written).
+ * = the tail of OccupationalGrid (main.c:355-362). */
+int slam_grid_upload_host(slam_engine *e, int slot, const int32_t *occ, const slam_grid_meta *meta, float cap,
+                          float *edt_out);
+/* Adopt an EDT that is already on the device (not copied; caller keeps it alive). */
+int slam_grid_set_dev(slam_engine *e, int slot, const float *d_edt, const slam_grid_meta *meta);
+/* Sensor-frame cartesian beams of the current scan = scan.x / scan.y (main.c:60-69). */
+int slam_scan_upload_host(slam_engine *e, const float *bx, const float *by, int nbeams);
+int slam_scan_set_dev(slam_engine *e, const float *d_bx, const float *d_by, int nbeams);
+
+/* ------------------------------------------------------------------ scan-match score (row A7) */
+
+/* Score every pose against grid `slot` with the current scan:
+ *   score[i] = in-order float sum of EDT[cell(pose_i (+) beam_b)] over in-bounds beams,
+ *   count[i] = number of in-bounds beams                       (main.c:459-518, Appendix A.5).
+ * Heading trig: the `_cs` form takes cos/sin per pose computed by the caller (the reference computes
+ * them with libm on the host, main.c:433-435; this form is bit-exact with the reference for any
+ * pose); the theta form computes them on the device with the engine's specified polynomial
+ * (DESIGN.md "device trig"), bit-exact with the oracle's restatement of the same polynomial. */
+int slam_score_poses_cs_dev(slam_engine *e, int slot, const float *d_x, const float *d_y, const float *d_ct,
+                            const float *d_st, int nposes, float *d_score, int32_t *d_count);
+int slam_score_poses_dev(slam_engine *e, int slot, const float *d_x, const float *d_y, const float *d_theta,
+                         int nposes, float *d_score, int32_t *d_count);
+int slam_score_poses_cs_host(slam_engine *e, int slot, const float *x, const float *y, const float *ct,
+                             const float *st, int nposes, float *score, int32_t *count);
+int slam_score_poses_host(slam_engine *e, int slot, const float *x, const float *y, const float *theta, int nposes,
+                          float *score, int32_t *count);
+/* In-bounds EDT values of ONE pose in beam order (what the reference leaves in
+ * FastMatchParameters.bestHits, main.c:515); hits must hold nbeams floats. */
+int slam_pose_hits_host(slam_engine *e, int slot, float x, float y, float ct, float st, float *hits, int32_t *count);
+
+/* Drop-in for FastMatch (slot 0) / FastMatch2 (slot 1), main.c:381-596 / 598-809, quirks included:
+ * 27-pose lattice laid out once around `pose` with step res[0] in x AND y and res[2] in theta
+ * (res[1] is never read), strict '<' arg-min in theta-major, x, y-minor order, best_hits[] = hits of
+ * the LAST candidate, *best_hits_size = in-bounds count of the BEST one.
+ * best_hits must hold nbeams floats; best_score may be NULL. */
+int slam_fastmatch_host(slam_engine *e, int slot, const float pose[3], const float res[3], float out_pose[3],
+                        float *best_hits, int32_t *best_hits_size, float *best_score);
+
+/* ------------------------------------------------------------------ particle-filter stages
+ * (rows A9-A12: no counterpart in the reference; specified in DESIGN.md and oracle/slam_oracle_pf.c).
+ * Particles are SoA float arrays x[], y[], theta[]; `first_id` is the global index of element 0 of
+ * this shard (0 on a single GPU) so that results do not depend on how particles are sharded. */
+
+/* A9: x,y,theta[i] = src(x,y,theta)[anc ? anc[i] : i] + dp + eps_i, eps ~ N(0, diag(sigma^2)) from
+ * Philox4x32-10 keyed (seed, frame) and countered by the global particle id.  With sigma = 0 this
+ * is the reference's constant-velocity predict (main.c:875-898) applied to every particle.
+ * d_anc (may be NULL) are LOCAL indices into the source arrays (resample gather fused in). */
+int slam_motion_sample_dev(slam_engine *e, const float *d_src_x, const float *d_src_y, const float *d_src_th,
+                           const int32_t *d_anc, float *d_x, float *d_y, float *d_th, int n, int64_t first_id,
+                           const float dp[3], const float sigma[3], uint64_t seed, uint32_t frame);
+
+/* A10: per-particle x per-landmark 2x2 EKF correction (FastSLAM 1.0, known correspondences,
+ * cartesian sensor-frame observations z = H (m - t), H = [[ct,-st],[st,ct]]).
+ * The observation list of the current frame is sensor data like the scan: upload it once per frame
+ * with slam_obs_upload_host (landmark ids must be unique and < nlandmarks; nobs <= SLAM_MAX_OBS).
+ * The map is 5 planes [L][ld_map] (mu_x, mu_y, P_xx, P_xy, P_yy), particle index fastest, plane p
+ * at d_map + p * plane_stride.  For every observed landmark: read the 5 values of
+ * (landmark, src(i)), update, write them to (landmark, i) of the output planes; the observation
+ * log-likelihoods are summed per chunk of 32 observations and then over chunks into loglik[i]
+ * (overwritten).  With d_anc != NULL the resample gather is fused in (src(i) = anc[i], a local
+ * index; requires d_map_in != d_map_out); landmarks without an observation are copied through when
+ * the update is out of place.  P_xx < 0 marks a landmark not seen yet: it is initialised from the
+ * observation and contributes no likelihood. */
+enum { SLAM_MAX_OBS = 8192 };
+int slam_obs_upload_host(slam_engine *e, const int32_t *landmark_id, const float *zx, const float *zy, int nobs,
+                         int nlandmarks);
+int slam_ekf_update_dev(slam_engine *e, const float *d_map_in, float *d_map_out, int64_t plane_stride, int ld_map,
+                        int nlandmarks, const float *d_x, const float *d_y, const float *d_th, const int32_t *d_anc,
+                        int n, float meas_var, float *d_loglik);
+
+/* A11: logw[i] = loglik[i] - score[i] * score_gain  (either input may be NULL = 0) and
+ * *d_max = max_i logw[i] (float, device).  Then, with the GLOBAL maximum m (after an all-reduce MAX
+ * over shards): wq[i] = (uint64) (exp_det(logw[i] - m) * 2^32)  and  *d_sum = sum(wq)  (exact
+ * integer, hence independent of summation order and sharding). */
+int slam_logweight_dev(slam_engine *e, const float *d_score, const float *d_loglik, float score_gain, int n,
+                       float *d_logw, float *d_max);
+int slam_quantise_weights_dev(slam_engine *e, const float *d_logw, const float *d_max, int n, uint64_t *d_wq,
+                              uint64_t *d_sum);
+
+/* A12: systematic resampling on the exact integer CDF.
+ *  step 1 (per shard): d_cdf[i] = inclusive prefix sum of wq within the shard.
+ *  step 2 (per shard): d_first[i] = number of comb teeth below the start of particle i's CDF
+ *          interval = index of the first output slot it fills; needs the shard's base offset
+ *          (sum of wq of all earlier shards), the grand total and the comb offset `u` in [0,total).
+ *  step 3 (per output slot j of any shard): ancestor[j] = last global i with first[i] <= j, by
+ *          binary search in the concatenated `first` array of all shards. */
+int slam_prefix_sum_dev(slam_engine *e, const uint64_t *d_wq, int n, uint64_t *d_cdf);
+int slam_offspring_offsets_dev(slam_engine *e, const uint64_t *d_cdf, int n, uint64_t base, uint64_t total,
+                               uint64_t comb_u, int64_t n_total, int32_t *d_first);
+int slam_ancestors_dev(slam_engine *e, const int32_t *d_first_all, int64_t n_total, int64_t slot0, int nslots,
+                       int32_t *d_anc);
+/* The comb offset of a frame: uniform integer in [0,total) from Philox4x32-10 keyed by seed,
+ * counter (0,0,frame,1).  Pure host function (every rank computes the same value). */
+uint64_t slam_comb_offset(uint64_t seed, uint32_t frame, uint64_t total);
+
+/* Plain gather of particle attributes through an index (used when the gather is not fused into the
+ * next stage, and to pack rows for migration between GPUs). */
+int slam_gather_f32_dev(slam_engine *e, const float *d_src, const int32_t *d_idx, int n, float *d_dst);
+int slam_gather_map_dev(slam_engine *e, const float *d_map_in, float *d_map_out, int64_t in_plane_stride,
+                        int64_t out_plane_stride, int ld_in, int ld_out, int nlandmarks, const int32_t *d_idx, int n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SLAM_HIP_H */

@@ -74,6 +74,24 @@ def lib() -> C.CDLL:
     L.orc_score_poses.argtypes = [P(GridMeta), _f32p, _f32p, _f32p, C.c_int, _f32p, _f32p, _f32p, C.c_int, _f32p, _i32p]
     L.orc_fastmatch.argtypes = [P(GridMeta), _f32p, _f32p, _f32p, C.c_int, _f32p, _f32p, _f32p, _f32p, P(C.c_int),
                                 P(C.c_float)]
+    # ---- particle-filter specification (slam_oracle_pf.c)
+    _i64, _u64, _u32 = C.c_int64, C.c_uint64, C.c_uint32
+    L.orc_det_sincosf_array.argtypes = [_f32p, C.c_int, _f32p, _f32p]
+    L.orc_det_expf_array.argtypes = [_f32p, C.c_int, _f32p]
+    L.orc_det_logf_array.argtypes = [_f32p, C.c_int, _f32p]
+    L.orc_philox4x32_10.argtypes = [_u32p, _u32p, _u32p]
+    L.orc_score_poses_det.argtypes = [P(GridMeta), _f32p, _f32p, _f32p, C.c_int, _f32p, _f32p, _f32p, C.c_int, _f32p, _i32p]
+    L.orc_motion_sample.argtypes = [_f32p, _f32p, _f32p, C.c_void_p, _f32p, _f32p, _f32p, C.c_int, _i64, _f32p, _f32p,
+                                    _u64, _u32]
+    L.orc_ekf_update.argtypes = [_f32p, _f32p, _i64, C.c_int, C.c_int, _f32p, _f32p, _f32p, C.c_void_p, C.c_int, _i32p,
+                                 _f32p, _f32p, C.c_int, C.c_float, _f32p]
+    L.orc_logweight.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_int, _f32p, P(C.c_float)]
+    L.orc_quantise_weights.argtypes = [_f32p, C.c_float, C.c_int, _u64p, P(_u64)]
+    L.orc_prefix_sum.argtypes = [_u64p, C.c_int, _u64p]
+    L.orc_comb_offset.argtypes = [_u64, _u32, _u64]
+    L.orc_comb_offset.restype = _u64
+    L.orc_offspring_offsets.argtypes = [_u64p, C.c_int, _u64, _u64, _u64, _i64, _i32p]
+    L.orc_ancestors.argtypes = [_i32p, _i64, _i64, C.c_int, _i32p]
     _LIB = L
     return L
 
@@ -183,3 +201,124 @@ def run_tool(name: str, *args, **kw) -> subprocess.CompletedProcess:
     if not exe.exists():
         build(ref=False)
     return subprocess.run([str(exe), *map(str, args)], check=True, **kw)
+
+
+# ------------------------------------------------------------------ particle-filter specification
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, np.float32)
+
+
+def _opt_i32(a):
+    if a is None:
+        return None, None
+    a = np.ascontiguousarray(a, np.int32)
+    return a, a.ctypes.data_as(C.c_void_p)
+
+
+def det_sincos(a):
+    a = _f32(np.atleast_1d(a))
+    s = np.empty_like(a)
+    c = np.empty_like(a)
+    lib().orc_det_sincosf_array(a, len(a), s, c)
+    return s, c
+
+
+def det_exp(x):
+    x = _f32(np.atleast_1d(x))
+    y = np.empty_like(x)
+    lib().orc_det_expf_array(x, len(x), y)
+    return y
+
+
+def det_log(x):
+    x = _f32(np.atleast_1d(x))
+    y = np.empty_like(x)
+    lib().orc_det_logf_array(x, len(x), y)
+    return y
+
+
+def philox(ctr, key):
+    out = np.empty(4, np.uint32)
+    lib().orc_philox4x32_10(np.ascontiguousarray(ctr, np.uint32), np.ascontiguousarray(key, np.uint32), out)
+    return out
+
+
+def score_poses_det(m: GridMeta, edt_grid, bx, by, x, y, theta):
+    n = len(x)
+    score = np.empty(n, np.float32)
+    count = np.empty(n, np.int32)
+    lib().orc_score_poses_det(C.byref(m), _f32(edt_grid), _f32(bx), _f32(by), len(bx), _f32(x), _f32(y), _f32(theta), n,
+                              score, count)
+    return score, count
+
+
+def motion_sample(src_x, src_y, src_th, anc, n, first_id, dp, sigma, seed, frame):
+    x, y, th = (np.empty(n, np.float32) for _ in range(3))
+    keep, ancp = _opt_i32(anc)
+    lib().orc_motion_sample(_f32(src_x), _f32(src_y), _f32(src_th), ancp, x, y, th, n, first_id, _f32(dp), _f32(sigma),
+                            seed, frame)
+    return x, y, th
+
+
+def ekf_update(map_in, x, y, th, anc, obs_id, obs_zx, obs_zy, meas_var, n=None):
+    """map_in: float32 [5][L][ld].  Returns (map_out [5][L][ld], loglik[n]); out of place."""
+    map_in = _f32(map_in)
+    _, L_, ld = map_in.shape
+    n = len(x) if n is None else n
+    out = map_in.copy()
+    ll = np.empty(n, np.float32)
+    keep, ancp = _opt_i32(anc)
+    lib().orc_ekf_update(map_in, out, L_ * ld, ld, L_, _f32(x), _f32(y), _f32(th), ancp, n,
+                         np.ascontiguousarray(obs_id, np.int32), _f32(obs_zx), _f32(obs_zy), len(obs_id), meas_var, ll)
+    return out, ll
+
+
+def logweight(score, loglik, gain):
+    n = len(score) if score is not None else len(loglik)
+    logw = np.empty(n, np.float32)
+    m = C.c_float(0)
+    sp = _f32(score).ctypes.data_as(C.c_void_p) if score is not None else None
+    keep_s = _f32(score) if score is not None else None
+    keep_l = _f32(loglik) if loglik is not None else None
+    lib().orc_logweight(keep_s.ctypes.data_as(C.c_void_p) if keep_s is not None else None,
+                        keep_l.ctypes.data_as(C.c_void_p) if keep_l is not None else None, gain, n, logw, C.byref(m))
+    return logw, np.float32(m.value)
+
+
+def quantise_weights(logw, m):
+    wq = np.empty(len(logw), np.uint64)
+    s = C.c_uint64(0)
+    lib().orc_quantise_weights(_f32(logw), m, len(logw), wq, C.byref(s))
+    return wq, int(s.value)
+
+
+def prefix_sum(wq):
+    cdf = np.empty(len(wq), np.uint64)
+    lib().orc_prefix_sum(np.ascontiguousarray(wq, np.uint64), len(wq), cdf)
+    return cdf
+
+
+def comb_offset(seed, frame, total):
+    return int(lib().orc_comb_offset(seed, frame, total))
+
+
+def offspring_offsets(cdf, base, total, comb_u, n_total):
+    first = np.empty(len(cdf), np.int32)
+    lib().orc_offspring_offsets(np.ascontiguousarray(cdf, np.uint64), len(cdf), base, total, comb_u, n_total, first)
+    return first
+
+
+def ancestors(first_all, slot0, nslots):
+    anc = np.empty(nslots, np.int32)
+    lib().orc_ancestors(np.ascontiguousarray(first_all, np.int32), len(first_all), slot0, nslots, anc)
+    return anc
+
+
+def resample(wq, seed, frame):
+    """Whole systematic resample of one unsharded population: -> ancestors[n]."""
+    cdf = prefix_sum(wq)
+    total = int(cdf[-1])
+    first = offspring_offsets(cdf, 0, total, comb_offset(seed, frame, total), len(wq))
+    return ancestors(first, 0, len(wq))
