@@ -73,7 +73,7 @@ SIGNATURES = {
     "slam_logweight_dev": (_i, [_vp, _vp, _vp, _f, _i, _vp, _vp]),
     "slam_quantise_weights_dev": (_i, [_vp, _vp, _vp, _i, _vp, _vp]),
     "slam_prefix_sum_dev": (_i, [_vp, _vp, _i, _vp]),
-    "slam_offspring_offsets_dev": (_i, [_vp, _vp, _i, _u64, _u64, _u64, _i64, _vp]),
+    "slam_offspring_offsets_dev": (_i, [_vp, _vp, _i, _vp, _vp, _u64, _u32, _i64, _vp]),
     "slam_ancestors_dev": (_i, [_vp, _vp, _i64, _i64, _i, _vp]),
     "slam_comb_offset": (_u64, [_u64, _u32, _u64]),
     "slam_gather_f32_dev": (_i, [_vp, _vp, _vp, _i, _vp]),
@@ -254,9 +254,9 @@ class Engine:
     def prefix_sum_dev(self, d_wq, n, d_cdf):
         self._ck(self.lib.slam_prefix_sum_dev(self.h, _ptr(d_wq), n, _ptr(d_cdf)), "prefix_sum_dev")
 
-    def offspring_offsets_dev(self, d_cdf, n, base, total, comb_u, n_total, d_first):
-        self._ck(self.lib.slam_offspring_offsets_dev(self.h, _ptr(d_cdf), n, base, total, comb_u, n_total,
-                                                     _ptr(d_first)), "offspring_offsets_dev")
+    def offspring_offsets_dev(self, d_cdf, n, d_base, d_total, seed, frame, n_total, d_first):
+        self._ck(self.lib.slam_offspring_offsets_dev(self.h, _ptr(d_cdf), n, _ptr(d_base), _ptr(d_total), seed, frame,
+                                                     n_total, _ptr(d_first)), "offspring_offsets_dev")
 
     def ancestors_dev(self, d_first_all, n_total, slot0, nslots, d_anc):
         self._ck(self.lib.slam_ancestors_dev(self.h, _ptr(d_first_all), n_total, slot0, nslots, _ptr(d_anc)),

@@ -610,14 +610,14 @@ int slam_prefix_sum_dev(slam_engine* e, const uint64_t* d_wq, int n, uint64_t* d
     return SLAM_OK;
 }
 
-int slam_offspring_offsets_dev(slam_engine* e, const uint64_t* d_cdf, int n, uint64_t base, uint64_t total,
-                               uint64_t comb_u, int64_t n_total, int32_t* d_first)
+int slam_offspring_offsets_dev(slam_engine* e, const uint64_t* d_cdf, int n, const uint64_t* d_base,
+                               const uint64_t* d_total, uint64_t seed, uint32_t frame, int64_t n_total,
+                               int32_t* d_first)
 {
     ENTER(e);
-    if (n < 0 || n_total < n || n_total > 0x7fffffff || total == 0 || (total >> 63) || comb_u >= total ||
-        (n > 0 && (!d_cdf || !d_first)))
+    if (n < 0 || n_total < n || n_total > 0x7fffffff || !d_total || (n > 0 && (!d_cdf || !d_first)))
         return SLAM_ERR_INVALID_ARG;
-    HIP_TRY(launch_offspring_offsets(e->stream, d_cdf, n, base, total, comb_u, n_total, d_first));
+    HIP_TRY(launch_offspring_offsets(e->stream, d_cdf, n, d_base, d_total, seed, frame, n_total, d_first));
     return SLAM_OK;
 }
 

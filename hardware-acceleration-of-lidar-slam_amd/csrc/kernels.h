@@ -59,8 +59,9 @@ hipError_t launch_quantise_weights(hipStream_t stream, const float* logw, const 
 
 hipError_t launch_prefix_sum(hipStream_t stream, const uint64_t* in, int n, uint64_t* out, uint64_t* block_scratch);
 int prefix_sum_scratch_elems(int n);
-hipError_t launch_offspring_offsets(hipStream_t stream, const uint64_t* cdf, int n, uint64_t base, uint64_t total,
-                                    uint64_t comb_u, int64_t n_total, int32_t* first);
+hipError_t launch_offspring_offsets(hipStream_t stream, const uint64_t* cdf, int n, const uint64_t* d_base,
+                                    const uint64_t* d_total, uint64_t seed, uint32_t frame, int64_t n_total,
+                                    int32_t* first);
 hipError_t launch_ancestors(hipStream_t stream, const int32_t* first_all, int64_t n_total, int64_t slot0, int nslots,
                             int32_t* anc);
 hipError_t launch_gather_f32(hipStream_t stream, const float* src, const int32_t* idx, int n, float* dst);

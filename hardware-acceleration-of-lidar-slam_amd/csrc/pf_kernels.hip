@@ -327,11 +327,22 @@ __device__ __forceinline__ uint64_t div128by64(uint64_t hi, uint64_t lo, uint64_
 }
 
 __global__ __launch_bounds__(kBlock) void offspring_offsets_kernel(const uint64_t* __restrict__ cdf, int n,
-                                                                   uint64_t base, uint64_t total, uint64_t comb_u,
+                                                                   const uint64_t* __restrict__ d_base,
+                                                                   const uint64_t* __restrict__ d_total,
+                                                                   uint32_t key0, uint32_t key1, uint32_t frame,
                                                                    uint64_t n_total, int32_t* __restrict__ first)
 {
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
+    const uint64_t base = d_base ? *d_base : 0ull;
+    const uint64_t total = *d_total;
+    if (total == 0 || (total >> 63)) {   // impossible with finite log-weights (the best particle has wq = 2^32);
+        first[i] = 0;                    // stay memory-safe anyway: no division, every slot gets the last particle
+        return;
+    }
+    // comb offset u in [0,total): Philox counter (0,0,frame,1), high 64 bits of r64*total (wave-uniform)
+    const u32x4 r = philox4x32_10(0u, 0u, frame, 1u /* resample stream */, key0, key1);
+    const uint64_t comb_u = __umul64hi((uint64_t)r.v[0] | ((uint64_t)r.v[1] << 32), total);
     const uint64_t c_excl = base + (i ? cdf[i - 1] : 0ull);
     // X = c_excl * n_total as 128 bits
     uint64_t lo = c_excl * n_total, hi = __umul64hi(c_excl, n_total);
@@ -458,11 +469,13 @@ hipError_t launch_prefix_sum(hipStream_t stream, const uint64_t* in, int n, uint
     return hipGetLastError();
 }
 
-hipError_t launch_offspring_offsets(hipStream_t stream, const uint64_t* cdf, int n, uint64_t base, uint64_t total,
-                                    uint64_t comb_u, int64_t n_total, int32_t* first)
+hipError_t launch_offspring_offsets(hipStream_t stream, const uint64_t* cdf, int n, const uint64_t* d_base,
+                                    const uint64_t* d_total, uint64_t seed, uint32_t frame, int64_t n_total,
+                                    int32_t* first)
 {
     if (n <= 0) return hipSuccess;
-    offspring_offsets_kernel<<<blocks_for(n), kBlock, 0, stream>>>(cdf, n, base, total, comb_u, (uint64_t)n_total,
+    offspring_offsets_kernel<<<blocks_for(n), kBlock, 0, stream>>>(cdf, n, d_base, d_total, (uint32_t)seed,
+                                                                   (uint32_t)(seed >> 32), frame, (uint64_t)n_total,
                                                                    first);
     return hipGetLastError();
 }

@@ -1,0 +1,259 @@
+"""Particle-filter frame loop on the engine: host-side plumbing only.
+
+One process per GPU.  This module owns the device buffers (torch tensors are used purely as HBM
+allocations on the current stream) and the exchange steps between GPUs (``torch.distributed``, i.e.
+RCCL over xGMI with the ``nccl`` backend); every arithmetic stage is a call into the C ABI
+(``include/slam_hip.h``) through ``HipOps``.  There is no CPU compute path here: ``HipOps`` needs a
+gfx950 engine.  (The CPU tests of the sharding logic substitute their own ``ops`` object built on
+the checker in ``oracle/`` — test infrastructure, not shipped.)
+
+Frame t (SURVEY.md §8a rows A9-A12 around the reference's scan-match score, row A7):
+  1. motion sample     pose'[i] = pose[src(i)] + dp + eps_i           (resample gather fused in)
+  2. scan-match score  score[i] = sum_b EDT[cell(pose'[i] (+) beam_b)]  == FastMatch's inner loop,
+                                                                       Subsystem_1/main.c:459-518
+  3. per-landmark EKF  map'[l][i] = update(map[l][src(i)], z_l)       (gather fused in), loglik[i]
+  4. weights           logw = loglik - gain*score ; m = max (all-reduce MAX over GPUs)
+                       wq = fixed-point exp(logw - m) ; shard totals all-gathered (8 B per GPU)
+  5. resample          integer CDF (wavefront prefix sum) -> first slot of every particle
+                       -> all-gather of those indices -> ancestor of every local slot
+  6. migration         particles whose ancestor lives on another GPU are fetched with one
+                       all-to-all of poses (12 B each) and, when maps exist, of map rows (20 B x L)
+Results are bit-identical for any number of GPUs: noise is keyed by global particle id, the CDF is
+exact integer arithmetic, and the comb offset is a pure function of (seed, frame, total).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+class HipOps:
+    """Stage calls -> C ABI.  Tensors must live on the engine's GPU."""
+
+    def __init__(self, engine):
+        self.e = engine
+
+    def bind_stream(self):
+        self.e.set_stream(torch.cuda.current_stream().cuda_stream)
+
+    def motion_sample(self, src, anc, dst, n, first_id, dp, sigma, seed, frame):
+        self.e.motion_sample_dev(src, anc, dst, n, first_id, dp, sigma, seed, frame)
+
+    def score(self, slot, x, y, th, n, score, count):
+        self.e.score_poses_dev(slot, x, y, th, n, score, count)
+
+    def obs_upload(self, ids, zx, zy, nlandmarks):
+        self.e.obs_upload(ids, zx, zy, nlandmarks)
+
+    def ekf(self, map_in, map_out, plane_stride, ld, nlandmarks, x, y, th, anc, n, meas_var, loglik):
+        self.e.ekf_update_dev(map_in, map_out, plane_stride, ld, nlandmarks, x, y, th, anc, n, meas_var, loglik)
+
+    def logweight(self, score, loglik, gain, n, logw, d_max):
+        self.e.logweight_dev(score, loglik, gain, n, logw, d_max)
+
+    def quantise(self, logw, d_max, n, wq, d_sum):
+        self.e.quantise_weights_dev(logw, d_max, n, wq, d_sum)
+
+    def prefix_sum(self, wq, n, cdf):
+        self.e.prefix_sum_dev(wq, n, cdf)
+
+    def offspring_offsets(self, cdf, n, d_base, d_total, seed, frame, n_total, first):
+        self.e.offspring_offsets_dev(cdf, n, d_base, d_total, seed, frame, n_total, first)
+
+    def ancestors(self, first_all, n_total, slot0, nslots, anc):
+        self.e.ancestors_dev(first_all, n_total, slot0, nslots, anc)
+
+    def gather_f32(self, src, idx, n, dst):
+        self.e.gather_f32_dev(src, idx, n, dst)
+
+    def gather_map(self, m_in, m_out, in_stride, out_stride, ld_in, ld_out, nlandmarks, idx, n):
+        self.e.gather_map_dev(m_in, m_out, in_stride, out_stride, ld_in, ld_out, nlandmarks, idx, n)
+
+
+class ParticleFilter:
+    """Sharded FastSLAM-style filter: ``n_local`` particles on this rank, ``world * n_local`` in total."""
+
+    def __init__(self, ops, n_local: int, nlandmarks: int = 0, *, device, rank: int = 0, world: int = 1, group=None,
+                 seed: int = 1, sigma=(0.01, 0.01, 0.002), meas_var: float = 0.01, score_gain: float = 1.0,
+                 grid_slot: int = 0, recv_capacity: int | None = None):
+        self.ops, self.n, self.L = ops, int(n_local), int(nlandmarks)
+        self.rank, self.world, self.group = rank, world, group
+        self.n_total = self.n * world
+        if self.n_total >= 2**31:
+            raise ValueError("total particle count must stay below 2^31 (int32 ancestor indices)")
+        self.device = torch.device(device)
+        self.seed, self.sigma, self.meas_var, self.score_gain = seed, tuple(sigma), meas_var, score_gain
+        self.grid_slot = grid_slot
+        self.recv_cap = 0 if world == 1 else (self.n if recv_capacity is None else int(recv_capacity))
+        self.cap = self.n + self.recv_cap
+        dv = self.device
+        f32, i32, i64 = torch.float32, torch.int32, torch.int64
+        self.pose = torch.zeros((2, 3, self.cap), dtype=f32, device=dv)         # [buffer][x,y,theta][particle]
+        self.map = torch.zeros((2, 5, self.L, self.cap), dtype=f32, device=dv) if self.L else None
+        self.cur = 0
+        self.src_idx = None            # local gather indices left by the previous resample (None = identity)
+        self.score = torch.zeros(self.n, dtype=f32, device=dv)
+        self.count = torch.zeros(self.n, dtype=i32, device=dv)
+        self.loglik = torch.zeros(self.n, dtype=f32, device=dv)
+        self.logw = torch.zeros(self.n, dtype=f32, device=dv)
+        self.wq = torch.zeros(self.n, dtype=i64, device=dv)                       # uint64 bit patterns (< 2^63)
+        self.cdf = torch.zeros(self.n, dtype=i64, device=dv)
+        self.first = torch.zeros(self.n, dtype=i32, device=dv)
+        self.first_all = self.first if world == 1 else torch.zeros(self.n_total, dtype=i32, device=dv)
+        self.anc = torch.zeros((2, self.n), dtype=i32, device=dv)                # double-buffered: the fused gathers
+        self.d_max = torch.zeros(1, dtype=f32, device=dv)                         # of frame t+1 read frame t's indices
+        self.d_sum = torch.zeros(1, dtype=i64, device=dv)
+        self.d_base = torch.zeros(1, dtype=i64, device=dv)
+        self.d_total = torch.zeros(1, dtype=i64, device=dv)
+        self.totals = torch.zeros(world, dtype=i64, device=dv)
+        self.frame = 0
+        self.migrated_last = 0
+        if hasattr(ops, "bind_stream"):
+            ops.bind_stream()
+
+    # ------------------------------------------------------------------ state access
+    def set_poses(self, x, y, th):
+        for k, a in enumerate((x, y, th)):
+            self.pose[self.cur, k, : self.n] = torch.as_tensor(a, dtype=torch.float32).to(self.device)
+        self.src_idx = None
+
+    def set_map(self, planes):
+        """planes: float32 [5][L][n_local]"""
+        self.map[self.cur, :, :, : self.n] = torch.as_tensor(planes, dtype=torch.float32).to(self.device)
+        self.src_idx = None
+
+    def poses(self):
+        """Current particle poses [3][n_local] with any pending resample gather applied."""
+        p = self.pose[self.cur]
+        return p[:, : self.n] if self.src_idx is None else p[:, self.src_idx.long()]
+
+    def maps(self):
+        m = self.map[self.cur]
+        return m[:, :, : self.n] if self.src_idx is None else m[:, :, self.src_idx.long()]
+
+    # ------------------------------------------------------------------ one frame
+    def step(self, dp, obs=None):
+        """dp: odometry increment (3 floats).  obs: (landmark ids, zx, zy) host arrays or None."""
+        o, n, cur, nxt = self.ops, self.n, self.cur, 1 - self.cur
+        src, dst = self.pose[cur], self.pose[nxt]
+        # 1. motion (+ fused gather of the previous resample)
+        o.motion_sample((src[0], src[1], src[2]), self.src_idx, (dst[0], dst[1], dst[2]), n, self.rank * n, dp,
+                        self.sigma, self.seed, self.frame)
+        # 2. scan-match score
+        o.score(self.grid_slot, dst[0], dst[1], dst[2], n, self.score, self.count)
+        # 3. per-landmark EKF (+ fused gather)
+        use_ll = self.L > 0 and obs is not None
+        if use_ll:
+            o.obs_upload(obs[0], obs[1], obs[2], self.L)
+            o.ekf(self.map[cur], self.map[nxt], self.L * self.cap, self.cap, self.L, dst[0], dst[1], dst[2],
+                  self.src_idx, n, self.meas_var, self.loglik)
+        elif self.L > 0:   # no observation this frame: the maps still have to follow their particles
+            idx = self.src_idx if self.src_idx is not None else torch.arange(n, dtype=torch.int32, device=self.device)
+            o.gather_map(self.map[cur], self.map[nxt], self.L * self.cap, self.L * self.cap, self.cap, self.cap,
+                         self.L, idx, n)
+        # 4. weights
+        o.logweight(self.score, self.loglik if use_ll else None, self.score_gain, n, self.logw, self.d_max)
+        if self.world > 1:
+            dist.all_reduce(self.d_max, op=dist.ReduceOp.MAX, group=self.group)
+        o.quantise(self.logw, self.d_max, n, self.wq, self.d_sum)
+        # 5. resample on the integer CDF
+        o.prefix_sum(self.wq, n, self.cdf)
+        if self.world > 1:
+            dist.all_gather_into_tensor(self.totals, self.d_sum, group=self.group)
+            self.d_base.copy_(self.totals[: self.rank].sum().reshape(1))
+            self.d_total.copy_(self.totals.sum().reshape(1))
+            d_base, d_total = self.d_base, self.d_total
+        else:
+            d_base, d_total = None, self.d_sum
+        o.offspring_offsets(self.cdf, n, d_base, d_total, self.seed, self.frame, self.n_total, self.first)
+        if self.world > 1:
+            dist.all_gather_into_tensor(self.first_all, self.first, group=self.group)
+        anc = self.anc[nxt]
+        o.ancestors(self.first_all, self.n_total, self.rank * n, n, anc)
+        # 6. particles whose ancestor lives on another GPU
+        self.cur = nxt
+        if self.world == 1:
+            self.src_idx = anc
+            self.migrated_last = 0
+        else:
+            self.src_idx = self._migrate(anc)
+        self.frame += 1
+
+    # ------------------------------------------------------------------ multi-GPU exchange
+    def _plan(self):
+        """Slot ranges [A_s, B_s) filled by the particles of rank s: A_s = first_all[s*n]."""
+        n, G = self.n, self.world
+        sel = torch.arange(G, device=self.device) * n
+        bounds = self.first_all[sel].cpu().tolist() + [self.n_total]   # one small device->host sync per frame
+        r = self.rank
+        send = [(max(bounds[r], d * n), min(bounds[r + 1], (d + 1) * n)) for d in range(G)]
+        recv = [(max(bounds[s], r * n), min(bounds[s + 1], (r + 1) * n)) for s in range(G)]
+        send = [(lo, hi) if hi > lo and d != r else (0, 0) for d, (lo, hi) in enumerate(send)]
+        recv = [(lo, hi) if hi > lo and s != r else (0, 0) for s, (lo, hi) in enumerate(recv)]
+        return send, recv
+
+    def _migrate(self, anc):
+        o, n, r, G, dv = self.ops, self.n, self.rank, self.world, self.device
+        send, recv = self._plan()
+        scnt = [hi - lo for lo, hi in send]
+        rcnt = [hi - lo for lo, hi in recv]
+        stot, rtot = sum(scnt), sum(rcnt)
+        if rtot > self.recv_cap:
+            raise RuntimeError(f"rank {r}: {rtot} particles to receive exceed recv_capacity {self.recv_cap}")
+        self.migrated_last = rtot
+        pose, L = self.pose[self.cur], self.L
+        # pack: per destination a block [x | y | theta] (and [5][L][cnt] map rows)
+        sbuf = torch.empty(3 * stot, dtype=torch.float32, device=dv)
+        rbuf = torch.empty(3 * rtot, dtype=torch.float32, device=dv)
+        smap = torch.empty(5 * L * stot, dtype=torch.float32, device=dv) if L else None
+        rmap = torch.empty(5 * L * rtot, dtype=torch.float32, device=dv) if L else None
+        idx = torch.empty(stot, dtype=torch.int32, device=dv)
+        off = 0
+        for d, (lo, hi) in enumerate(send):
+            c = hi - lo
+            if c == 0:
+                continue
+            seg = idx[off: off + c]
+            o.ancestors(self.first_all, self.n_total, lo, c, seg)   # global ids, all inside my particle range
+            seg -= r * n
+            for k in range(3):
+                o.gather_f32(pose[k], seg, c, sbuf[3 * off + k * c: 3 * off + (k + 1) * c])
+            if L:
+                o.gather_map(self.map[self.cur], smap[5 * L * off:], L * self.cap, L * c, self.cap, c, L, seg, c)
+            off += c
+        dist.all_to_all_single(rbuf, sbuf, [3 * c for c in rcnt], [3 * c for c in scnt], group=self.group)
+        if L:
+            dist.all_to_all_single(rmap, smap, [5 * L * c for c in rcnt], [5 * L * c for c in scnt], group=self.group)
+        # unpack into the staging region behind the local particles, build the local gather index
+        lo_t = torch.zeros(G, dtype=torch.int64, device=dv)
+        off_t = torch.zeros(G, dtype=torch.int64, device=dv)
+        off = 0
+        for s, (lo, hi) in enumerate(recv):
+            c = hi - lo
+            if c == 0:
+                continue
+            blk = rbuf[3 * off: 3 * (off + c)].view(3, c)
+            pose[:, n + off: n + off + c] = blk
+            if L:
+                self.map[self.cur][:, :, n + off: n + off + c] = rmap[5 * L * off: 5 * L * (off + c)].view(5, L, c)
+            lo_t[s], off_t[s] = lo, off
+            off += c
+        a64 = anc.long()
+        owner = torch.div(a64, n, rounding_mode="floor")
+        slot = torch.arange(r * n, (r + 1) * n, dtype=torch.int64, device=dv)
+        remote = n + off_t[owner] + (slot - lo_t[owner])
+        src = torch.where(owner == r, a64 - r * n, remote).to(torch.int32)
+        return src
+
+    # ------------------------------------------------------------------ estimate
+    def best_particle(self):
+        """(log-weight, global id, pose) of the heaviest particle of the last frame (lowest id on ties)."""
+        lw, i = torch.max(self.logw, dim=0)
+        cand = torch.stack([lw.double(), (self.rank * self.n + i).double()])
+        if self.world > 1:
+            allc = torch.empty((self.world, 2), dtype=torch.float64, device=self.device)
+            dist.all_gather_into_tensor(allc, cand.reshape(1, 2), group=self.group)
+            k = int(torch.argmax(allc[:, 0]))   # first max = lowest rank = lowest id
+            cand = allc[k]
+        return float(cand[0]), int(cand[1])

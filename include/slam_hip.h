@@ -174,12 +174,15 @@ int slam_quantise_weights_dev(slam_engine *e, const float *d_logw, const float *
  *  step 1 (per shard): d_cdf[i] = inclusive prefix sum of wq within the shard.
  *  step 2 (per shard): d_first[i] = number of comb teeth below the start of particle i's CDF
  *          interval = index of the first output slot it fills; needs the shard's base offset
- *          (sum of wq of all earlier shards), the grand total and the comb offset `u` in [0,total).
+ *          (sum of wq of all earlier shards; NULL = 0) and the grand total, both read from DEVICE
+ *          memory so that the frame loop never synchronises with the host; the comb offset
+ *          u = slam_comb_offset(seed, frame, total) is computed inside the kernel.
  *  step 3 (per output slot j of any shard): ancestor[j] = last global i with first[i] <= j, by
  *          binary search in the concatenated `first` array of all shards. */
 int slam_prefix_sum_dev(slam_engine *e, const uint64_t *d_wq, int n, uint64_t *d_cdf);
-int slam_offspring_offsets_dev(slam_engine *e, const uint64_t *d_cdf, int n, uint64_t base, uint64_t total,
-                               uint64_t comb_u, int64_t n_total, int32_t *d_first);
+int slam_offspring_offsets_dev(slam_engine *e, const uint64_t *d_cdf, int n, const uint64_t *d_base,
+                               const uint64_t *d_total, uint64_t seed, uint32_t frame, int64_t n_total,
+                               int32_t *d_first);
 int slam_ancestors_dev(slam_engine *e, const int32_t *d_first_all, int64_t n_total, int64_t slot0, int nslots,
                        int32_t *d_anc);
 /* The comb offset of a frame: uniform integer in [0,total) from Philox4x32-10 keyed by seed,

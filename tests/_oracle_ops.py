@@ -1,0 +1,69 @@
+"""`ops` object for pf.ParticleFilter built on the CPU checker (oracle/): TEST INFRASTRUCTURE.
+
+Lets the sharding / exchange logic of the frame loop run on CPU tensors with the gloo backend
+(world_size 2) so that it can be compared with an unsharded run — without a GPU.  Never shipped,
+never used by the product path."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+import oracle
+
+
+def _np(t):
+    return None if t is None else t.numpy()
+
+
+class OracleOps:
+    def __init__(self, grid_meta, edt, bx, by):
+        self.meta, self.edt, self.bx, self.by = grid_meta, np.ascontiguousarray(edt, np.float32), bx, by
+        self.obs = None
+
+    def motion_sample(self, src, anc, dst, n, first_id, dp, sigma, seed, frame):
+        x, y, th = oracle.motion_sample(_np(src[0]), _np(src[1]), _np(src[2]), _np(anc), n, first_id, dp, sigma, seed, frame)
+        dst[0][:n] = torch.from_numpy(x); dst[1][:n] = torch.from_numpy(y); dst[2][:n] = torch.from_numpy(th)
+
+    def score(self, slot, x, y, th, n, score, count):
+        s, c = oracle.score_poses_det(self.meta, self.edt, self.bx, self.by, _np(x)[:n], _np(y)[:n], _np(th)[:n])
+        score[:n] = torch.from_numpy(s); count[:n] = torch.from_numpy(c)
+
+    def obs_upload(self, ids, zx, zy, nlandmarks):
+        self.obs = (np.asarray(ids, np.int32), np.asarray(zx, np.float32), np.asarray(zy, np.float32))
+
+    def ekf(self, map_in, map_out, plane_stride, ld, nlandmarks, x, y, th, anc, n, meas_var, loglik):
+        L = oracle.lib()
+        ll = np.empty(n, np.float32)
+        a = _np(anc)
+        L.orc_ekf_update(_np(map_in).reshape(5, nlandmarks, ld), _np(map_out).reshape(5, nlandmarks, ld), plane_stride, ld,
+                         nlandmarks, _np(x), _np(y), _np(th), a.ctypes.data_as(C.c_void_p) if a is not None else None, n,
+                         self.obs[0], self.obs[1], self.obs[2], len(self.obs[0]), meas_var, ll)
+        loglik[:n] = torch.from_numpy(ll)
+
+    def logweight(self, score, loglik, gain, n, logw, d_max):
+        lw, m = oracle.logweight(_np(score), _np(loglik), gain)
+        logw[:n] = torch.from_numpy(lw); d_max[0] = float(m)
+
+    def quantise(self, logw, d_max, n, wq, d_sum):
+        q, s = oracle.quantise_weights(_np(logw), float(d_max[0]))
+        wq[:n] = torch.from_numpy(q.view(np.int64)); d_sum[0] = s
+
+    def prefix_sum(self, wq, n, cdf):
+        cdf[:n] = torch.from_numpy(oracle.prefix_sum(_np(wq).view(np.uint64)).view(np.int64))
+
+    def offspring_offsets(self, cdf, n, d_base, d_total, seed, frame, n_total, first):
+        base = int(d_base[0]) if d_base is not None else 0
+        total = int(d_total[0])
+        u = oracle.comb_offset(seed, frame, total)
+        first[:n] = torch.from_numpy(oracle.offspring_offsets(_np(cdf).view(np.uint64), base, total, u, n_total))
+
+    def ancestors(self, first_all, n_total, slot0, nslots, anc):
+        anc[:nslots] = torch.from_numpy(oracle.ancestors(_np(first_all)[:n_total], slot0, nslots))
+
+    def gather_f32(self, src, idx, n, dst):
+        dst[:n] = src[idx[:n].long()]
+
+    def gather_map(self, m_in, m_out, in_stride, out_stride, ld_in, ld_out, nlandmarks, idx, n):
+        src = torch.as_strided(m_in, (5, nlandmarks, ld_in), (in_stride, ld_in, 1), m_in.storage_offset())
+        out = torch.as_strided(m_out, (5, nlandmarks, ld_out), (out_stride, ld_out, 1), m_out.storage_offset())
+        out[:, :, :n] = src[:, :, idx[:n].long()]
