@@ -1,0 +1,314 @@
+#!/usr/bin/env python3
+"""bench.py — particle-updates/s of the particle-filter frame loop on synthetic 360-beam scans.
+
+    python bench.py [--gpus N --steps K --warmup W]                 (N = 1)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W    (N > 1, one rank per GPU, RCCL)
+
+A "step" is one whole frame of the hot path over one batch of synthetic input: motion sample ->
+scan-match score (the reference's FastMatch inner loop, Subsystem_1/main.c:459-518, for every
+particle) -> per-particle x per-landmark 2x2 EKF over ALL landmarks -> weight normalisation ->
+systematic resample (gathers fused into the next frame's motion/EKF kernels) -> migration between
+GPUs.  Workload = BASELINE.json configs[1] per GPU: 65536 particles, 360 beams, 500 landmarks,
+1024 x 1024 EDT grid; weak scaling (per-GPU work fixed).  Particles, maps, EDT and scan are resident
+in HBM when the timed region starts; per frame only the sensor data (360 beams + 500 observations,
+8.9 KB) crosses PCIe.  value = N_total_particles * K / max-over-ranks wall time.
+
+Other workloads (never the default; used to fill BASELINE.md):
+    --mode score   scan-match-only microbench (configs[2]: --particles 1048576 --grid 2048)
+    --mode ekf     EKF sweep only (north-star roofline case: --particles 1048576 --landmarks 1000)
+
+One JSON line on stdout (rank 0), including
+  roofline     — dominant kernel, algorithmic bytes / average launch duration from HIP events recorded
+                 on the kernel's own stream inside the timed region (slam_profile_* in the C ABI)
+  cpu_baseline — the CPU port of the same frame loop (oracle/, single thread) timed on this host
+                 on a bounded sample (rank 0, N = 1 only)
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+# synthetic world: 15 x 11 m room with two boxes, in the reference's pose convention
+ROOM = (-3.0, -5.5, 12.0, 5.5)
+BOXES = [(5.0, 2.0, 7.0, 3.5), (2.0, -4.0, 3.0, -3.0)]
+
+
+def raycast(px, py, ang):
+    """Range of rays from (px,py) at world angles `ang` against the room (from inside) and the boxes."""
+    dx, dy = np.cos(ang), np.sin(ang)
+    best = np.full(ang.shape, 1e30)
+    for (x0, y0, x1, y1) in [ROOM] + BOXES:
+        for ex in (x0, x1):
+            with np.errstate(divide="ignore", invalid="ignore"):
+                t = (ex - px) / dx
+            yy = py + t * dy
+            ok = (t > 1e-9) & (yy >= y0) & (yy <= y1) & (t < best)
+            best = np.where(ok, t, best)
+        for ey in (y0, y1):
+            with np.errstate(divide="ignore", invalid="ignore"):
+                t = (ey - py) / dy
+            xx = px + t * dx
+            ok = (t > 1e-9) & (xx >= x0) & (xx <= x1) & (t < best)
+            best = np.where(ok, t, best)
+    return best
+
+
+def occupancy(grid, pixel, min_x, min_y):
+    """Walls of the room and boxes rasterised 3 cells thick -> ~1 % occupied."""
+    occ = np.zeros((grid, grid), np.int32)
+
+    def cells(v, lo):
+        return int(round((v - lo) / pixel))
+
+    for (x0, y0, x1, y1) in [ROOM] + BOXES:
+        c0, c1, r0, r1 = cells(x0, min_x), cells(x1, min_x), cells(y0, min_y), cells(y1, min_y)
+        for r in (r0, r1):
+            occ[max(r - 1, 0): r + 2, max(c0, 0): c1 + 1] = 1
+        for c in (c0, c1):
+            occ[max(r0, 0): r1 + 1, max(c - 1, 0): c + 2] = 1
+    return occ
+
+
+def true_pose(f):
+    """Robot truth at frame f: 4 mm and 0.6 mrad per frame on an arc (theta in the reference's sign)."""
+    th = -0.0006 * f
+    R = 0.004 / 0.0006
+    return np.array([R * np.sin(0.0006 * f), R * (1 - np.cos(0.0006 * f)), th])
+
+
+def sensor_frame(points, pose):
+    """H (m - t), H = [[ct,-st],[st,ct]]: inverse of the reference's world = R^T p + t (main.c:115-116)."""
+    ct, st = np.cos(pose[2]), np.sin(pose[2])
+    d = points - pose[:2]
+    return np.stack([ct * d[:, 0] - st * d[:, 1], st * d[:, 0] + ct * d[:, 1]], 1)
+
+
+def make_frames(nframes, nbeams, landmarks, rng):
+    frames = []
+    ang = -np.pi + 2 * np.pi * np.arange(nbeams) / nbeams
+    prev = true_pose(0)
+    for f in range(1, nframes + 1):
+        pose = true_pose(f)
+        r = raycast(pose[0], pose[1], ang - pose[2]) + rng.uniform(-0.005, 0.005, nbeams)
+        bx, by = (r * np.cos(ang)).astype(np.float32), (r * np.sin(ang)).astype(np.float32)
+        z = sensor_frame(landmarks, pose) + rng.normal(0, 0.02, landmarks.shape)
+        ids = rng.permutation(len(landmarks)).astype(np.int32)
+        frames.append(dict(bx=bx, by=by, dp=(pose - prev).astype(np.float32), ids=ids,
+                           zx=z[ids, 0].astype(np.float32), zy=z[ids, 1].astype(np.float32)))
+        prev = pose
+    return frames
+
+
+def cpu_baseline(args, occ, meta_t, frames, landmarks, budget_s=12.0):
+    """The CPU port (oracle/, TEST INFRASTRUCTURE used here only as the reported baseline): the same
+    frame loop, single thread, on a bounded sample of the workload."""
+    import oracle
+
+    rows = cols = args.grid
+    edt = oracle.edt(occ, rows, cols, 10.0, "window")
+    m = oracle.meta(rows, cols, cols, *meta_t)
+    n = 1024
+    rng = np.random.default_rng(99)
+    p0 = true_pose(0)
+    x = (p0[0] + rng.normal(0, 0.05, n)).astype(np.float32)
+    y = (p0[1] + rng.normal(0, 0.05, n)).astype(np.float32)
+    th = (p0[2] + rng.normal(0, 0.01, n)).astype(np.float32)
+    L = len(landmarks)
+    mp = np.zeros((5, max(L, 1), n), np.float32)
+    if L:
+        mp[0] = landmarks[:, 0:1] + rng.normal(0, 0.1, (L, n))
+        mp[1] = landmarks[:, 1:2] + rng.normal(0, 0.1, (L, n))
+        mp[2] = 0.05
+        mp[4] = 0.05
+    anc = None
+    done = 0
+    t0 = time.perf_counter()
+    while True:
+        fr = frames[done % len(frames)]
+        x, y, th = oracle.motion_sample(x, y, th, anc, n, 0, fr["dp"], args.sigma, 1234, done)
+        score, _ = oracle.score_poses_det(m, edt, fr["bx"], fr["by"], x, y, th)
+        ll = None
+        if L and args.mode != "score":
+            mp, ll = oracle.ekf_update(mp, x, y, th, anc, fr["ids"], fr["zx"], fr["zy"], args.meas_var)
+        logw, mx = oracle.logweight(score, ll, args.score_gain)
+        wq, _ = oracle.quantise_weights(logw, mx)
+        anc = oracle.resample(wq, 1234, done)
+        done += 1
+        el = time.perf_counter() - t0
+        if el > budget_s and done >= 3:
+            break
+    return {"value": n * done / el, "unit": "particle-updates/s", "cores": 1, "kind": "port",
+            "sample": f"{n} particles x {done} frames of the same workload ({args.beams} beams, {L} landmarks, "
+                      f"{args.grid}^2 EDT), oracle/ C port, 1 thread, {el:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--mode", choices=["pf", "score", "ekf"], default="pf")
+    ap.add_argument("--particles", type=int, default=65536, help="per GPU")
+    ap.add_argument("--beams", type=int, default=360)
+    ap.add_argument("--landmarks", type=int, default=500)
+    ap.add_argument("--grid", type=int, default=1024)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+    args.sigma = (0.01, 0.01, 0.002)
+    args.meas_var = 0.02 ** 2 * 4
+    args.score_gain = 0.02
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch N>1 with torch.distributed.run")
+
+    import torch
+    import torch.distributed as dist
+
+    from __graft_entry__ import load_package
+
+    pkg = load_package()
+    from hardware_acceleration_of_lidar_slam_amd.pf import HipOps, ParticleFilter
+
+    if not torch.cuda.is_available():
+        sys.exit("bench.py: no GPU visible; the engine has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    eng = pkg.Engine(local_rank)
+    ops = HipOps(eng)
+    ops.bind_stream()
+
+    # ---- synthetic inputs (identical on every rank)
+    rng = np.random.default_rng(4321)
+    L = 0 if args.mode == "score" else args.landmarks
+    landmarks = np.stack([rng.uniform(ROOM[0] + 0.5, ROOM[2] - 0.5, L), rng.uniform(ROOM[1] + 0.5, ROOM[3] - 0.5, L)], 1)
+    pixel = np.float32(20.48 / args.grid)
+    min_x, min_y = np.float32(-4.24), np.float32(-10.24)
+    occ = occupancy(args.grid, float(pixel), float(min_x), float(min_y))
+    nframes = args.steps + args.warmup
+    frames = make_frames(min(nframes, 256), args.beams, landmarks, rng)
+
+    d_occ = torch.from_numpy(occ).to(dev)
+    d_edt = torch.empty((args.grid, args.grid), dtype=torch.float32, device=dev)
+    eng.edt_dev(d_occ, args.grid, args.grid, args.grid, 10.0, d_edt)
+    meta = pkg.grid_meta(args.grid, args.grid, args.grid, pixel, min_x, min_y)
+    eng.grid_set_dev(0, d_edt, meta)
+
+    n = args.particles
+    pf = ParticleFilter(ops, n, L, device=dev, rank=rank, world=world, seed=1234, sigma=args.sigma,
+                        meas_var=args.meas_var, score_gain=args.score_gain, grid_slot=0)
+    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    p0 = true_pose(0)
+    pf.set_poses(p0[0] + 0.05 * torch.randn(n, generator=g), p0[1] + 0.05 * torch.randn(n, generator=g),
+                 p0[2] + 0.01 * torch.randn(n, generator=g))
+    if L:
+        lm = torch.from_numpy(landmarks.astype(np.float32)).to(dev)
+        m0 = pf.map[pf.cur]
+        m0[0, :, :n] = lm[:, 0:1] + 0.1 * torch.randn((L, n), device=dev)
+        m0[1, :, :n] = lm[:, 1:2] + 0.1 * torch.randn((L, n), device=dev)
+        m0[2, :, :n] = 0.05
+        m0[3, :, :n] = 0.0
+        m0[4, :, :n] = 0.05
+
+    def one_step(k):
+        fr = frames[k % len(frames)]
+        eng.scan_upload(fr["bx"], fr["by"])
+        if args.mode == "pf":
+            pf.step(fr["dp"], (fr["ids"], fr["zx"], fr["zy"]) if L else None)
+        elif args.mode == "score":
+            p = pf.pose[0]
+            eng.score_poses_dev(0, p[0], p[1], p[2], n, pf.score, pf.count)
+        else:   # ekf sweep: out of place, ping-pong between the two map buffers
+            p = pf.pose[0]
+            eng.obs_upload(fr["ids"], fr["zx"], fr["zy"], L)
+            eng.ekf_update_dev(pf.map[k & 1], pf.map[1 - (k & 1)], L * pf.cap, pf.cap, L, p[0], p[1], p[2], None, n,
+                               args.meas_var, pf.loglik)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for k in range(args.warmup):
+        one_step(k)
+    barrier()
+    eng.profile_enable(True)
+    for kk in (eng.PROF_SCORE, eng.PROF_EKF):
+        eng.profile_read(kk)
+    t0 = time.perf_counter()
+    for k in range(args.warmup, args.warmup + args.steps):
+        one_step(k)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    eng.profile_enable(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t[0])
+
+    score_ms, score_n = eng.profile_read(eng.PROF_SCORE)
+    ekf_ms, ekf_n = eng.profile_read(eng.PROF_EKF)
+    n_total = n * world
+    value = n_total * args.steps / elapsed
+
+    # dominant kernel + its algorithmic bytes per launch (DESIGN.md "Measurement")
+    score_bytes = (12 + 4 * args.beams + 4) * n              # pose read + one EDT gather per beam + score write
+    ekf_bytes = 40 * n * L                                   # 20 B read + 20 B written per (particle, landmark)
+    if ekf_n and (ekf_ms >= score_ms or args.mode == "ekf"):
+        kern, dur_ms, alg = "ekf_update_kernel", ekf_ms / ekf_n, ekf_bytes
+    else:
+        kern, dur_ms, alg = "score_poses_kernel", score_ms / max(score_n, 1), score_bytes
+    achieved = alg / (dur_ms * 1e-3) / 1e9 if dur_ms > 0 else 0.0
+    traffic = None
+    tfile = ROOT / "profiles" / "traffic.json"   # HBM bytes per launch from rocprofv3 --pmc runs of this command
+    if tfile.exists():
+        rec = json.loads(tfile.read_text()).get(f"{args.mode}:{n}:{args.beams}:{L}:{args.grid}", {})
+        traffic = rec.get(kern)
+    out = {
+        "metric": "particle-updates/sec (N_particles x scans/s) on 360-beam lidar",
+        "value": value, "unit": "particle-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": {"pf": "BASELINE configs[1]: full particle-filter frame (motion, scan-match score, "
+                                      "EKF over all landmarks, weights, resample)",
+                                "score": "scan-match score only", "ekf": "EKF sweep only"}[args.mode],
+                   "mode": args.mode, "particles_per_gpu": n, "particles_total": n_total, "beams": args.beams,
+                   "landmarks": L, "edt_grid": f"{args.grid}x{args.grid}", "parallelism": f"particle-shard x{world}"},
+        "roofline": {"bound": "hbm", "kernel": kern, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": alg,
+                     "avg_launch_ms": dur_ms, "launches": int(ekf_n if kern.startswith("ekf") else score_n),
+                     "other_kernel_avg_ms": {"score_poses_kernel": score_ms / max(score_n, 1),
+                                             "ekf_update_kernel": ekf_ms / max(ekf_n, 1)}},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args, occ, (float(pixel), float(min_x), float(min_y)), frames, landmarks)
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -55,6 +55,8 @@ SIGNATURES = {
     "slam_engine_destroy": (_i, [_vp]),
     "slam_engine_set_stream": (_i, [_vp, _vp]),
     "slam_engine_sync": (_i, [_vp]),
+    "slam_profile_enable": (_i, [_vp, _i]),
+    "slam_profile_read": (_i, [_vp, _i, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "slam_edt_dev": (_i, [_vp, _vp, _i, _i, _i, _f, _vp]),
     "slam_edt_host": (_i, [_vp, _vp, _i, _i, _i, _f, _vp]),
     "slam_grid_upload_host": (_i, [_vp, _i, _vp, C.POINTER(GridMeta), _f, _vp]),
@@ -152,6 +154,17 @@ class Engine:
 
     def sync(self):
         self._ck(self.lib.slam_engine_sync(self.h), "sync")
+
+    PROF_SCORE, PROF_EDT, PROF_EKF = 0, 1, 2
+
+    def profile_enable(self, on: bool = True):
+        self._ck(self.lib.slam_profile_enable(self.h, 1 if on else 0), "profile_enable")
+
+    def profile_read(self, kernel: int):
+        """-> (total milliseconds, launches) of that kernel since the last read (HIP events on the engine stream)."""
+        ms, n = C.c_double(0), C.c_int64(0)
+        self._ck(self.lib.slam_profile_read(self.h, kernel, C.byref(ms), C.byref(n)), "profile_read")
+        return ms.value, n.value
 
     # ---------------------------------------------------------------- host-buffer level (drop-in)
     def edt_host(self, occ: np.ndarray, rows: int, cols: int, cap: float = 10.0, out: np.ndarray | None = None):

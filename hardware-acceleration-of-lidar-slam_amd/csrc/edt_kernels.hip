@@ -92,7 +92,8 @@ __global__ __launch_bounds__(kEdtBlock) void edt_kernel(const int32_t* __restric
 
 }  // namespace
 
-hipError_t launch_edt(hipStream_t stream, const int32_t* occ, int ld, int rows, int cols, float cap, float* out)
+hipError_t launch_edt(hipStream_t stream, const int32_t* occ, int ld, int rows, int cols, float cap, float* out,
+                      const EventPair* ev)
 {
     if (rows <= 0 || cols <= 0) return hipSuccess;
     int rad = (int)ceilf(cap);
@@ -100,7 +101,9 @@ hipError_t launch_edt(hipStream_t stream, const int32_t* occ, int ld, int rows, 
     if (rad > EDT_MAX_RADIUS) return hipErrorInvalidValue;
     const dim3 grid((cols + kTileW - 1) / kTileW, (rows + kTileH - 1) / kTileH);
     const size_t lds = (size_t)(kTileH + 2 * rad) * (kTileW + 2 * rad) + (size_t)(kTileH + 2 * rad) * kTileW;
+    if (ev) (void)hipEventRecord(ev->start, stream);
     edt_kernel<<<grid, kEdtBlock, lds, stream>>>(occ, ld, rows, cols, cap, cap * cap, rad, out);
+    if (ev) (void)hipEventRecord(ev->stop, stream);
     return hipGetLastError();
 }
 

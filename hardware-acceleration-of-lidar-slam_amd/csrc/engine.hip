@@ -82,6 +82,24 @@ struct slam_engine {
     float* h_fm = nullptr;     // pinned mirror
     DevBuf scratch;            // per-call temporaries of the *_dev stages
     DevBuf host_io[6];         // temporaries of the *_host convenience calls
+
+    // per-kernel HIP-event timing (slam_profile_*)
+    bool prof_on = false;
+    std::vector<EventPair> prof_pool[SLAM_PROF_COUNT];   // grown on demand, reused after each read
+    size_t prof_used[SLAM_PROF_COUNT] = { 0, 0, 0 };
+    EventPair prof_cur{};
+
+    const EventPair* prof_next(int k)
+    {
+        if (!prof_on) return nullptr;
+        auto& pool = prof_pool[k];
+        if (prof_used[k] == pool.size()) {
+            EventPair p;
+            if (hipEventCreate(&p.start) != hipSuccess || hipEventCreate(&p.stop) != hipSuccess) return nullptr;
+            pool.push_back(p);
+        }
+        return &pool[prof_used[k]++];
+    }
 };
 
 namespace {
@@ -211,9 +229,38 @@ int slam_engine_destroy(slam_engine* e)
     e->fm_buf.release();
     e->scratch.release();
     for (auto& b : e->host_io) b.release();
+    for (auto& pool : e->prof_pool)
+        for (auto& p : pool) {
+            (void)hipEventDestroy(p.start);
+            (void)hipEventDestroy(p.stop);
+        }
     if (e->h_fm) (void)hipHostFree(e->h_fm);
     if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
     delete e;
+    return SLAM_OK;
+}
+
+int slam_profile_enable(slam_engine* e, int enable)
+{
+    ENTER(e);
+    e->prof_on = enable != 0;
+    return SLAM_OK;
+}
+
+int slam_profile_read(slam_engine* e, int kernel, double* total_ms, int64_t* launches)
+{
+    ENTER(e);
+    if (kernel < 0 || kernel >= SLAM_PROF_COUNT || !total_ms || !launches) return SLAM_ERR_INVALID_ARG;
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    double sum = 0.0;
+    for (size_t i = 0; i < e->prof_used[kernel]; ++i) {
+        float ms = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&ms, e->prof_pool[kernel][i].start, e->prof_pool[kernel][i].stop));
+        sum += (double)ms;
+    }
+    *total_ms = sum;
+    *launches = (int64_t)e->prof_used[kernel];
+    e->prof_used[kernel] = 0;
     return SLAM_OK;
 }
 
@@ -238,7 +285,7 @@ int slam_edt_dev(slam_engine* e, const int32_t* d_occ, int ld, int rows, int col
     ENTER(e);
     if (!d_occ || !d_out || rows < 0 || cols < 0 || ld < cols || !(cap >= 0.0f)) return SLAM_ERR_INVALID_ARG;
     if (ceilf(cap) > (float)EDT_MAX_RADIUS) return SLAM_ERR_CAPACITY;
-    HIP_TRY(launch_edt(e->stream, d_occ, ld, rows, cols, cap, d_out));
+    HIP_TRY(launch_edt(e->stream, d_occ, ld, rows, cols, cap, d_out, e->prof_next(SLAM_PROF_EDT)));
     return SLAM_OK;
 }
 
@@ -338,7 +385,7 @@ int slam_score_poses_cs_dev(slam_engine* e, int slot, const float* d_x, const fl
         return SLAM_ERR_INVALID_ARG;
     if (int rc = check_score_inputs(e, slot)) return rc;
     HIP_TRY(launch_score_poses(e->stream, score_grid(e->grid[slot]), e->d_bx, e->d_by, e->nbeams, d_x, d_y, d_ct, d_st,
-                               nposes, d_score, d_count));
+                               nposes, d_score, d_count, e->prof_next(SLAM_PROF_SCORE)));
     return SLAM_OK;
 }
 
@@ -349,7 +396,7 @@ int slam_score_poses_dev(slam_engine* e, int slot, const float* d_x, const float
     if (nposes < 0 || (nposes > 0 && (!d_x || !d_y || !d_theta || !d_score || !d_count))) return SLAM_ERR_INVALID_ARG;
     if (int rc = check_score_inputs(e, slot)) return rc;
     HIP_TRY(launch_score_poses(e->stream, score_grid(e->grid[slot]), e->d_bx, e->d_by, e->nbeams, d_x, d_y, d_theta,
-                               nullptr, nposes, d_score, d_count));
+                               nullptr, nposes, d_score, d_count, e->prof_next(SLAM_PROF_SCORE)));
     return SLAM_OK;
 }
 
@@ -577,7 +624,7 @@ int slam_ekf_update_dev(slam_engine* e, const float* d_map_in, float* d_map_out,
         HIP_TRY(e->scratch.ensure(sizeof(float) * (size_t)nchunks * (size_t)n));
         a.ll_part = e->scratch.as<float>();
     }
-    HIP_TRY(launch_ekf_update(e->stream, a));
+    HIP_TRY(launch_ekf_update(e->stream, a, e->prof_next(SLAM_PROF_EKF)));
     return SLAM_OK;
 }
 

@@ -9,6 +9,12 @@
 
 namespace slam {
 
+// Optional timing of ONE kernel: when non-null, `start` is recorded immediately before and `stop`
+// immediately after that kernel's launch on the same stream.
+struct EventPair {
+    hipEvent_t start = nullptr, stop = nullptr;
+};
+
 // ---- score_kernels.hip (reference: Subsystem_1/main.c:381-596)
 struct ScoreGrid {
     const float* edt;   // [rows][ld]
@@ -18,13 +24,14 @@ struct ScoreGrid {
 };
 hipError_t launch_score_poses(hipStream_t stream, const ScoreGrid& g, const float* bx, const float* by, int nbeams,
                               const float* x, const float* y, const float* th_or_ct, const float* st_or_null,
-                              int nposes, float* score, int32_t* count);
+                              int nposes, float* score, int32_t* count, const EventPair* ev = nullptr);
 hipError_t launch_pose_hits(hipStream_t stream, const ScoreGrid& g, const float* bx, const float* by, int nbeams,
                             const float* pose_xycs /*4 floats on device*/, float* hits, int32_t* count);
 
 // ---- edt_kernels.hip (row A6; reference: main.c:223-269, main_accelerated.c:215-283)
 enum { EDT_MAX_RADIUS = 32 };
-hipError_t launch_edt(hipStream_t stream, const int32_t* occ, int ld, int rows, int cols, float cap, float* out);
+hipError_t launch_edt(hipStream_t stream, const int32_t* occ, int ld, int rows, int cols, float cap, float* out,
+                      const EventPair* ev = nullptr);
 
 // ---- pf_kernels.hip (rows A9-A12; no reference counterpart)
 hipError_t launch_motion_sample(hipStream_t stream, const float* sx, const float* sy, const float* sth,
@@ -49,7 +56,7 @@ struct EkfArgs {
     float* ll_part;   // scratch [nchunks][n] (only read when nchunks > 1)
 };
 enum { EKF_OBS_CHUNK = 32 };
-hipError_t launch_ekf_update(hipStream_t stream, const EkfArgs& a);
+hipError_t launch_ekf_update(hipStream_t stream, const EkfArgs& a, const EventPair* ev = nullptr);
 
 hipError_t launch_logweight(hipStream_t stream, const float* score, const float* loglik, float gain, int n,
                             float* logw, float* block_max_scratch, float* d_max);

@@ -413,7 +413,7 @@ hipError_t launch_motion_sample(hipStream_t stream, const float* sx, const float
     return hipGetLastError();
 }
 
-hipError_t launch_ekf_update(hipStream_t stream, const EkfArgs& a)
+hipError_t launch_ekf_update(hipStream_t stream, const EkfArgs& a, const EventPair* ev)
 {
     if (a.n <= 0) return hipSuccess;
     const int nchunks = (a.nobs + EKF_OBS_CHUNK - 1) / EKF_OBS_CHUNK;
@@ -425,7 +425,9 @@ hipError_t launch_ekf_update(hipStream_t stream, const EkfArgs& a)
         hipError_t err = hipMemsetAsync(a.loglik, 0, sizeof(float) * (size_t)a.n, stream);
         return err != hipSuccess ? err : hipGetLastError();
     }
+    if (ev) (void)hipEventRecord(ev->start, stream);
     ekf_update_kernel<<<dim3(blocks_for(a.n), nchunks), kBlock, 0, stream>>>(a);
+    if (ev) (void)hipEventRecord(ev->stop, stream);
     if (nchunks > 1)
         ekf_loglik_finalize_kernel<<<blocks_for(a.n), kBlock, 0, stream>>>(a.ll_part, nchunks, a.n, a.loglik);
     return hipGetLastError();

@@ -119,17 +119,19 @@ __global__ __launch_bounds__(64) void pose_hits_kernel(ScoreGrid g, const float*
 
 hipError_t launch_score_poses(hipStream_t stream, const ScoreGrid& g, const float* bx, const float* by, int nbeams,
                               const float* x, const float* y, const float* th_or_ct, const float* st_or_null,
-                              int nposes, float* score, int32_t* count)
+                              int nposes, float* score, int32_t* count, const EventPair* ev)
 {
     if (nposes <= 0) return hipSuccess;
     const int blocks = (nposes + kScoreBlock - 1) / kScoreBlock;
     const size_t lds = sizeof(float2) * (size_t)(nbeams > 0 ? nbeams : 1);
+    if (ev) (void)hipEventRecord(ev->start, stream);
     if (st_or_null)
         score_poses_kernel<true><<<blocks, kScoreBlock, lds, stream>>>(g, bx, by, nbeams, x, y, th_or_ct, st_or_null,
                                                                         nposes, score, count);
     else
         score_poses_kernel<false><<<blocks, kScoreBlock, lds, stream>>>(g, bx, by, nbeams, x, y, th_or_ct, nullptr,
                                                                          nposes, score, count);
+    if (ev) (void)hipEventRecord(ev->stop, stream);
     return hipGetLastError();
 }
 

@@ -74,6 +74,15 @@ int slam_engine_destroy(slam_engine *e);
 int slam_engine_set_stream(slam_engine *e, void *hip_stream);
 int slam_engine_sync(slam_engine *e);
 
+/* Per-kernel timing with HIP events recorded on the engine's stream around the named kernel's
+ * launches only (not around host work or neighbouring kernels).  Off by default.  slam_profile_read
+ * synchronises the stream, returns the summed duration and the launch count since the last reset
+ * and resets the counters.  (The reference's only timer is clock() around the whole run,
+ * main.c:826-827, 971-973.) */
+typedef enum { SLAM_PROF_SCORE = 0, SLAM_PROF_EDT = 1, SLAM_PROF_EKF = 2, SLAM_PROF_COUNT = 3 } slam_prof_kernel;
+int slam_profile_enable(slam_engine *e, int enable);
+int slam_profile_read(slam_engine *e, int kernel, double *total_ms, int64_t *launches);
+
 /* ------------------------------------------------------------------ EDT */
 
 /* Capped exact Euclidean distance transform of occ[0..rows)[0..cols) (row-major, leading dimension
