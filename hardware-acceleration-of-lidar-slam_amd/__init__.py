@@ -61,6 +61,7 @@ SIGNATURES = {
     "slam_edt_host": (_i, [_vp, _vp, _i, _i, _i, _f, _vp]),
     "slam_grid_upload_host": (_i, [_vp, _i, _vp, C.POINTER(GridMeta), _f, _vp]),
     "slam_grid_set_dev": (_i, [_vp, _i, _vp, C.POINTER(GridMeta)]),
+    "slam_grid_set_meta": (_i, [_vp, _i, C.POINTER(GridMeta)]),
     "slam_scan_upload_host": (_i, [_vp, _vp, _vp, _i]),
     "slam_scan_set_dev": (_i, [_vp, _vp, _vp, _i]),
     "slam_score_poses_cs_dev": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
@@ -185,6 +186,9 @@ class Engine:
     def grid_set_dev(self, slot: int, d_edt, meta: GridMeta):
         self._ck(self.lib.slam_grid_set_dev(self.h, slot, _ptr(d_edt), C.byref(meta)), "grid_set_dev")
 
+    def grid_set_meta(self, slot: int, meta: GridMeta):
+        self._ck(self.lib.slam_grid_set_meta(self.h, slot, C.byref(meta)), "grid_set_meta")
+
     def scan_upload(self, bx, by):
         bx, by = _np(bx, np.float32), _np(by, np.float32)
         assert bx.shape == by.shape and bx.ndim == 1
@@ -217,10 +221,12 @@ class Engine:
         self._ck(self.lib.slam_pose_hits_host(self.h, slot, x, y, ct, st, _ptr(hits), C.byref(n)), "pose_hits")
         return hits[: n.value].copy(), n.value
 
-    def fastmatch(self, slot, pose, res):
-        """-> (pose[3], hit buffer (nbeams long; live prefix = last candidate's hits), best_hits_size, best_score)"""
+    def fastmatch(self, slot, pose, res, hits: np.ndarray | None = None):
+        """-> (pose[3], hit buffer, best_hits_size, best_score).  `hits` (float32, >= nbeams) plays the role of
+        the reference's persistent FastMatchParameters.bestHits; a zeroed one is made when omitted."""
         out = (C.c_float * 3)()
-        hits = np.zeros(max(self.nbeams, 1), np.float32)
+        if hits is None:
+            hits = np.zeros(max(self.nbeams, 1), np.float32)
         n = C.c_int32(-1)
         sc = C.c_float(0)
         self._ck(self.lib.slam_fastmatch_host(self.h, slot, _f3(pose), _f3(res), out, _ptr(hits), C.byref(n),

@@ -79,6 +79,7 @@ struct slam_engine {
     const float *d_obs_zx = nullptr, *d_obs_zy = nullptr;
 
     DevBuf fm_buf;             // kFmIn + kFmOut floats
+    DevBuf fm_work;            // 27 x SLAM_MAX_BEAMS floats: per-candidate hit rows of the lattice kernel
     float* h_fm = nullptr;     // pinned mirror
     DevBuf scratch;            // per-call temporaries of the *_dev stages
     DevBuf host_io[6];         // temporaries of the *_host convenience calls
@@ -204,6 +205,7 @@ int slam_engine_create(int device, slam_engine** out)
     e->device = device;
     if (hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking) != hipSuccess ||
         e->fm_buf.ensure(sizeof(float) * (kFmIn + kFmOut)) != hipSuccess ||
+        e->fm_work.ensure(sizeof(float) * kLattice * SLAM_MAX_BEAMS) != hipSuccess ||
         hipHostMalloc((void**)&e->h_fm, sizeof(float) * (kFmIn + kFmOut), hipHostMallocDefault) != hipSuccess ||
         e->scan_buf.ensure(sizeof(float) * 2 * SLAM_MAX_BEAMS) != hipSuccess) {
         (void)hipGetLastError();
@@ -227,6 +229,7 @@ int slam_engine_destroy(slam_engine* e)
     e->scan_buf.release();
     e->obs_buf.release();
     e->fm_buf.release();
+    e->fm_work.release();
     e->scratch.release();
     for (auto& b : e->host_io) b.release();
     for (auto& pool : e->prof_pool)
@@ -345,6 +348,17 @@ int slam_grid_set_dev(slam_engine* e, int slot, const float* d_edt, const slam_g
     g.meta = *meta;
     g.d_edt = d_edt;
     g.ready = true;
+    return SLAM_OK;
+}
+
+int slam_grid_set_meta(slam_engine* e, int slot, const slam_grid_meta* meta)
+{
+    ENTER(e);
+    if (!slot_ok(slot) || !meta_ok(meta)) return SLAM_ERR_INVALID_ARG;
+    GridSlot& g = e->grid[slot];
+    if (!g.ready) return SLAM_ERR_NOT_READY;
+    if (meta->rows != g.meta.rows || meta->cols != g.meta.cols || meta->ld != g.meta.ld) return SLAM_ERR_INVALID_ARG;
+    g.meta = *meta;
     return SLAM_OK;
 }
 
@@ -488,17 +502,11 @@ int slam_fastmatch_host(slam_engine* e, int slot, const float pose[3], const flo
                 h_in[3 * kLattice + k] = s;
             }
     }
-    // the hit buffer ends up holding the LAST candidate's hits
-    for (int c = 0; c < 4; ++c) h_in[4 * kLattice + c] = h_in[c * kLattice + (kLattice - 1)];
-
     float* d_in = e->fm_buf.as<float>();
     float* d_out = d_in + kFmIn;
     const ScoreGrid g = score_grid(e->grid[slot]);
-    HIP_TRY(hipMemcpyAsync(d_in, h_in, sizeof(float) * kFmIn, hipMemcpyHostToDevice, e->stream));
-    HIP_TRY(launch_score_poses(e->stream, g, e->d_bx, e->d_by, e->nbeams, d_in, d_in + kLattice, d_in + 2 * kLattice,
-                               d_in + 3 * kLattice, kLattice, d_out, reinterpret_cast<int32_t*>(d_out + kLattice)));
-    HIP_TRY(launch_pose_hits(e->stream, g, e->d_bx, e->d_by, e->nbeams, d_in + 4 * kLattice, d_out + 2 * kLattice + 1,
-                             reinterpret_cast<int32_t*>(d_out + 2 * kLattice)));
+    HIP_TRY(hipMemcpyAsync(d_in, h_in, sizeof(float) * 4 * kLattice, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(launch_lattice(e->stream, g, e->d_bx, e->d_by, e->nbeams, d_in, e->fm_work.as<float>(), d_out));
     HIP_TRY(hipMemcpyAsync(h_out, d_out, sizeof(float) * (2 * kLattice + 1 + (size_t)e->nbeams), hipMemcpyDeviceToHost,
                            e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
@@ -521,9 +529,11 @@ int slam_fastmatch_host(slam_engine* e, int slot, const float pose[3], const flo
         out_pose[1] = pose[1];
         out_pose[2] = pose[2];
     }
-    int32_t nlast;
-    memcpy(&nlast, h_out + 2 * kLattice, sizeof nlast);
-    if (nlast > 0) memcpy(best_hits, h_out + 2 * kLattice + 1, sizeof(float) * (size_t)nlast);
+    // the caller's hit buffer ends up exactly as the reference's shared scratch does: the
+    // prefix every candidate overwrote, last writer wins; entries beyond the longest candidate untouched
+    int32_t maxc;
+    memcpy(&maxc, h_out + 2 * kLattice, sizeof maxc);
+    if (maxc > 0) memcpy(best_hits, h_out + 2 * kLattice + 1, sizeof(float) * (size_t)maxc);
     if (best_score) *best_score = best;
     return SLAM_OK;
 }

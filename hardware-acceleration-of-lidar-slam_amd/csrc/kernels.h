@@ -28,6 +28,14 @@ hipError_t launch_score_poses(hipStream_t stream, const ScoreGrid& g, const floa
 hipError_t launch_pose_hits(hipStream_t stream, const ScoreGrid& g, const float* bx, const float* by, int nbeams,
                             const float* pose_xycs /*4 floats on device*/, float* hits, int32_t* count);
 
+// The reference's 27-candidate lattice in one launch (FastMatch, main.c:440-573): candidate c gets one
+// wavefront; score[c], count[c] and, in merged_hits, exactly what the reference leaves in its shared
+// bestHits[] scratch after the sweep — entry j holds the hit of the LAST candidate (in evaluation
+// order) that had more than j in-bounds beams (main.c:515 overwrites the prefix for every candidate).
+// work: device scratch of 27*nbeams floats.  out layout: score[27] | count[27] (int) | maxcount (int) | merged[nbeams]
+hipError_t launch_lattice(hipStream_t stream, const ScoreGrid& g, const float* bx, const float* by, int nbeams,
+                          const float* cand_xycs /* X[27] Y[27] CT[27] ST[27] */, float* work, float* out);
+
 // ---- edt_kernels.hip (row A6; reference: main.c:223-269, main_accelerated.c:215-283)
 enum { EDT_MAX_RADIUS = 32 };
 hipError_t launch_edt(hipStream_t stream, const int32_t* occ, int ld, int rows, int cols, float cap, float* out,

@@ -115,7 +115,85 @@ __global__ __launch_bounds__(64) void pose_hits_kernel(ScoreGrid g, const float*
     if (lane == 0) *count = base;
 }
 
+constexpr int kLatticeN = 27;
+
+// One wavefront per lattice candidate.  Beams are taken 64 at a time: every lane classifies one beam,
+// ballot + lane prefix give the beam's in-order slot among the in-bounds ones, the hit goes to LDS
+// (for the ordered sum) and to this candidate's row of `work` (for the merge below).  The score is
+// then accumulated by lane 0 in slot order — the reference's sequential float sum (main.c:516).
+__global__ __launch_bounds__(64) void lattice_kernel(ScoreGrid g, const float* __restrict__ bx,
+                                                     const float* __restrict__ by, int nbeams,
+                                                     const float* __restrict__ cand, float* __restrict__ work,
+                                                     float* __restrict__ out)
+{
+    extern __shared__ float s_hit[];
+    const int c = blockIdx.x, lane = threadIdx.x;
+    const float x = cand[c], y = cand[kLatticeN + c], ct = cand[2 * kLatticeN + c], st = cand[3 * kLatticeN + c];
+    const float nst = -st;
+    const float off_x = (x - g.min_x) * g.ipix;
+    const float off_y = (y - g.min_y) * g.ipix;
+    const float lim_x = (float)(g.cols - 1);
+    const float lim_y = (float)(g.rows - 1);
+    float* __restrict__ row = work + (size_t)c * nbeams;
+    int base = 0;
+    for (int b0 = 0; b0 < nbeams; b0 += 64) {
+        const int b = b0 + lane;
+        bool in = false;
+        float h = 0.0f;
+        if (b < nbeams) {
+            const float qx = bx[b] * g.ipix, qy = by[b] * g.ipix;
+            const float rx = (qx * ct) + (qy * st);
+            const float ry = (qx * nst) + (qy * ct);
+            const float fx = round_half_away(rx + off_x);
+            const float fy = round_half_away(ry + off_y);
+            in = (fx > 0.0f) & (fy > 0.0f) & (fx < lim_x) & (fy < lim_y);
+            if (in) h = g.edt[(int)fy * g.ld + (int)fx];
+        }
+        const unsigned long long mask = __ballot(in);
+        const int slot = base + __popcll(mask & ((1ull << lane) - 1ull));
+        if (in) {
+            s_hit[slot] = h;
+            row[slot] = h;
+        }
+        base += __popcll(mask);
+    }
+    __syncthreads();
+    if (lane == 0) {
+        float total = 0.0f;
+        for (int j = 0; j < base; ++j) total = total + s_hit[j];
+        out[c] = total;
+        reinterpret_cast<int32_t*>(out)[kLatticeN + c] = base;
+    }
+}
+
+__global__ __launch_bounds__(256) void lattice_merge_kernel(const float* __restrict__ work, int nbeams,
+                                                            float* __restrict__ out)
+{
+    __shared__ int s_cnt[kLatticeN];
+    const int32_t* cnt = reinterpret_cast<const int32_t*>(out) + kLatticeN;
+    if (threadIdx.x < kLatticeN) s_cnt[threadIdx.x] = cnt[threadIdx.x];
+    __syncthreads();
+    int maxc = 0;
+    for (int c = 0; c < kLatticeN; ++c) maxc = s_cnt[c] > maxc ? s_cnt[c] : maxc;
+    if (threadIdx.x == 0) reinterpret_cast<int32_t*>(out)[2 * kLatticeN] = maxc;
+    float* merged = out + 2 * kLatticeN + 1;
+    for (int j = threadIdx.x; j < maxc; j += 256) {
+        int c = kLatticeN - 1;
+        while (s_cnt[c] <= j) --c;   // terminates: some candidate has count == maxc > j
+        merged[j] = work[(size_t)c * nbeams + j];
+    }
+}
+
 }  // namespace
+
+hipError_t launch_lattice(hipStream_t stream, const ScoreGrid& g, const float* bx, const float* by, int nbeams,
+                          const float* cand_xycs, float* work, float* out)
+{
+    const size_t lds = sizeof(float) * (size_t)(nbeams > 0 ? nbeams : 1);
+    lattice_kernel<<<kLatticeN, 64, lds, stream>>>(g, bx, by, nbeams, cand_xycs, work, out);
+    lattice_merge_kernel<<<1, 256, 0, stream>>>(work, nbeams, out);
+    return hipGetLastError();
+}
 
 hipError_t launch_score_poses(hipStream_t stream, const ScoreGrid& g, const float* bx, const float* by, int nbeams,
                               const float* x, const float* y, const float* th_or_ct, const float* st_or_null,

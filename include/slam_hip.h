@@ -103,6 +103,10 @@ enum { SLAM_MAX_GRID_SLOTS = 4, SLAM_MAX_BEAMS = 4096 };
  * = the tail of OccupationalGrid (main.c:355-362). */
 int slam_grid_upload_host(slam_engine *e, int slot, const int32_t *occ, const slam_grid_meta *meta, float cap,
                           float *edt_out);
+/* Replace pixel / min_x / min_y of a grid already in `slot` (rows, cols, ld must be unchanged).  The
+ * reference runs its EDTs before it records pixel_size and top_left_corner (main.c:355-362); an
+ * adapter with the reference's EDT signature therefore learns them one step later. */
+int slam_grid_set_meta(slam_engine *e, int slot, const slam_grid_meta *meta);
 /* Adopt an EDT that is already on the device (not copied; caller keeps it alive). */
 int slam_grid_set_dev(slam_engine *e, int slot, const float *d_edt, const slam_grid_meta *meta);
 /* Sensor-frame cartesian beams of the current scan = scan.x / scan.y (main.c:60-69). */
@@ -132,9 +136,12 @@ int slam_pose_hits_host(slam_engine *e, int slot, float x, float y, float ct, fl
 
 /* Drop-in for FastMatch (slot 0) / FastMatch2 (slot 1), main.c:381-596 / 598-809, quirks included:
  * 27-pose lattice laid out once around `pose` with step res[0] in x AND y and res[2] in theta
- * (res[1] is never read), strict '<' arg-min in theta-major, x, y-minor order, best_hits[] = hits of
- * the LAST candidate, *best_hits_size = in-bounds count of the BEST one.
- * best_hits must hold nbeams floats; best_score may be NULL. */
+ * (res[1] is never read), strict '<' arg-min in theta-major, x, y-minor order; *best_hits_size =
+ * in-bounds count of the BEST candidate while best_hits[] is left as the reference leaves its shared
+ * scratch: every candidate overwrote the prefix [0, its count), last writer wins, entries beyond the
+ * longest candidate keep the caller's previous content.  best_hits must hold
+ * nbeams floats and should persist between calls like FastMatchParameters.bestHits; best_score may
+ * be NULL. */
 int slam_fastmatch_host(slam_engine *e, int slot, const float pose[3], const float res[3], float out_pose[3],
                         float *best_hits, int32_t *best_hits_size, float *best_score);
 

@@ -126,6 +126,36 @@ def test_fastmatch_golden_calls(eng, golden):
         assert np.array_equal(bits(hits[:nlast]), bits(golden["fm_hits"][k][:nlast]))   # Q2
 
 
+def test_fastmatch_hit_scratch_is_reference_exact(eng, orc, golden):
+    """Q2 in full: after a call the scratch holds, per entry, the hit of the LAST candidate that had that
+    many in-bounds beams.  A pose near the grid border gives candidates with different counts."""
+    meta = _load_state_grid(eng, golden, 1)
+    bx, by = golden["scan_x_41"], golden["scan_y_41"]
+    eng.scan_upload(bx, by)
+    rows, cols, ld = (int(v) for v in golden["state_meta_1"])
+    pix, minx, miny = golden["state_metaf_1"]
+    m = orc.meta(rows, cols, ld, pix, minx, miny)
+    edt = np.zeros((ld, ld), np.float32)
+    edt[:rows, :cols] = golden["state_edt_1"]
+    persist = np.full(len(bx), -5.0, np.float32)
+    persist_ref = persist.copy()
+    partial = []
+    for guess, res in [([40.0, 40.0, 0.0], [0.05, 0.05, 0.01]), ([5.0, -1.4, 0.47], [0.6, 0.6, 0.05]),
+                       ([-3.0, 2.0, 1.0], [0.5, 0.5, 0.2]), ([0.16, 0.0, -0.02], [0.025, 0.025, 0.004363]),
+                       ([4.0, -3.5, 0.5], [0.9, 0.9, 0.1]), ([-5.0, 4.0, -0.7], [0.7, 0.7, 0.3])]:
+        pose, hits, nbest, best = eng.fastmatch(1, guess, res, hits=persist)
+        import ctypes as C
+        out = np.empty(3, np.float32); n = C.c_int(-1); sc = C.c_float(0)
+        orc.lib().orc_fastmatch(C.byref(m), edt, bx, by, len(bx), np.asarray(guess, np.float32), np.asarray(res, np.float32),
+                                out, persist_ref, C.byref(n), C.byref(sc))
+        assert np.array_equal(bits(pose), bits(out)) and (nbest == n.value or n.value == -1)
+        assert np.array_equal(bits(persist), bits(persist_ref))      # the whole buffer, stale tail included
+        if guess[0] == 40.0:   # nothing in bounds: no candidate writes, the caller's buffer is untouched
+            assert (persist == -5.0).all() and nbest == 0
+        partial.append(0 < nbest < len(bx))
+    assert any(partial) and not all(partial)   # the list mixes border poses with fully-inside ones
+
+
 def test_score_particle_mode_vs_oracle_state_grid(eng, orc, golden):
     """N arbitrary poses on the reference-built grid, device trig: must equal the oracle bit for bit,
     and agree with libm trig except where a 1-ulp heading difference flips a cell."""
@@ -216,3 +246,23 @@ def test_slam_main_matches_reference_logs(orc, tmp_path, name, frames):
     assert "\n".join(poses) + "\n" == (GOLDEN / f"{name}_pose.txt").read_text()
     assert (tmp_path / "map.csv").read_bytes() == (GOLDEN / f"{name}_map.csv").read_bytes()
     print(r.stderr.strip())
+
+
+def test_unmodified_reference_program_on_the_engine(orc, tmp_path):
+    """oracle/_ref/main_accel_dropin = the reference's own main_accelerated.c object (built in the build
+    container, hot symbols weakened) linked with host/ref_compat.c + libslam_hip.so: the reference's
+    unmodified frame loop calling the engine through the reference-named adapter.  Its stdout and map
+    file must equal what the all-CPU reference program produced (golden loop_*)."""
+    import os
+    exe = orc.REF / "main_accel_dropin"
+    if not exe.exists():
+        pytest.skip("oracle/_ref/main_accel_dropin was not shipped (it is built only where /root/reference exists)")
+    info = json.loads((GOLDEN / "datasets.json").read_text())["loop"]
+    csv = tmp_path / "loop.csv"
+    orc.run_tool("gen_dataset", csv, *info["gen_args"])
+    env = dict(os.environ, ORACLE_DATASET=str(csv), ORACLE_MAP_OUT=str(tmp_path / "map.csv"))
+    r = subprocess.run([str(exe)], env=env, check=True, capture_output=True, text=True)
+    poses = [ln for ln in r.stdout.splitlines() if ln.startswith("pose =")]
+    assert "\n".join(poses) + "\n" == (GOLDEN / "loop_pose.txt").read_text()
+    assert (tmp_path / "map.csv").read_bytes() == (GOLDEN / "loop_map.csv").read_bytes()
+    print([ln for ln in r.stdout.splitlines() if ln.startswith("time taken")])
