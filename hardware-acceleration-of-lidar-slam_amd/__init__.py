@@ -71,10 +71,15 @@ SIGNATURES = {
     "slam_pose_hits_host": (_i, [_vp, _i, _f, _f, _f, _f, _vp, C.POINTER(C.c_int32)]),
     "slam_fastmatch_host": (_i, [_vp, _i, _fp, _fp, _fp, _vp, C.POINTER(C.c_int32), _fp]),
     "slam_motion_sample_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _fp, _fp, _u64, _u32]),
+    "slam_motion_score_dev": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _fp, _fp, _u64, _u32, _vp, _vp]),
     "slam_obs_upload_host": (_i, [_vp, _vp, _vp, _vp, _i, _i]),
+    "slam_obs_set_dev": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _i, _i]),
+    "slam_logweight_ekf_dev": (_i, [_vp, _vp, _f, _i, _vp, _vp]),
     "slam_ekf_update_dev": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _i, _f, _vp]),
     "slam_logweight_dev": (_i, [_vp, _vp, _vp, _f, _i, _vp, _vp]),
     "slam_quantise_weights_dev": (_i, [_vp, _vp, _vp, _i, _vp, _vp]),
+    "slam_quantise_scan_dev": (_i, [_vp, _vp, _vp, _i, _vp]),
+    "slam_offspring_from_scan_dev": (_i, [_vp, _i, _vp, _vp, _u64, _u32, _i64, _vp]),
     "slam_prefix_sum_dev": (_i, [_vp, _vp, _i, _vp]),
     "slam_offspring_offsets_dev": (_i, [_vp, _vp, _i, _vp, _vp, _u64, _u32, _i64, _vp]),
     "slam_ancestors_dev": (_i, [_vp, _vp, _i64, _i64, _i, _vp]),
@@ -150,16 +155,22 @@ class Engine:
         if rc != SLAM_OK:
             raise SlamError(rc, where, self.lib.slam_last_error(self.h).decode())
 
-    def set_stream(self, stream_ptr):
-        self._ck(self.lib.slam_engine_set_stream(self.h, C.c_void_p(stream_ptr) if stream_ptr else None), "set_stream")
+    def set_stream(self, stream_ptr: int | None):
+        """stream_ptr: a hipStream_t as an integer (0 = HIP's default stream); None = the engine's own stream."""
+        p = C.c_void_p(-1 & (2 ** (8 * C.sizeof(C.c_void_p)) - 1)) if stream_ptr is None else C.c_void_p(stream_ptr)
+        self._ck(self.lib.slam_engine_set_stream(self.h, p), "set_stream")
 
     def sync(self):
         self._ck(self.lib.slam_engine_sync(self.h), "sync")
 
     PROF_SCORE, PROF_EDT, PROF_EKF = 0, 1, 2
 
-    def profile_enable(self, on: bool = True):
-        self._ck(self.lib.slam_profile_enable(self.h, 1 if on else 0), "profile_enable")
+    def profile_enable(self, *kernels):
+        """profile_enable(PROF_EKF, ...) times those kernels; profile_enable() switches timing off."""
+        mask = 0
+        for k in kernels:
+            mask |= 1 << k
+        self._ck(self.lib.slam_profile_enable(self.h, mask), "profile_enable")
 
     def profile_read(self, kernel: int):
         """-> (total milliseconds, launches) of that kernel since the last read (HIP events on the engine stream)."""
@@ -251,6 +262,19 @@ class Engine:
                                                  _ptr(dst[0]), _ptr(dst[1]), _ptr(dst[2]), n, first_id, _f3(dp),
                                                  _f3(sigma), seed, frame), "motion_sample_dev")
 
+    def motion_score_dev(self, slot, src, anc, dst, n, first_id, dp, sigma, seed, frame, d_score, d_count):
+        self._ck(self.lib.slam_motion_score_dev(self.h, slot, _ptr(src[0]), _ptr(src[1]), _ptr(src[2]), _ptr(anc),
+                                                _ptr(dst[0]), _ptr(dst[1]), _ptr(dst[2]), n, first_id, _f3(dp),
+                                                _f3(sigma), seed, frame, _ptr(d_score), _ptr(d_count)), "motion_score_dev")
+
+    def obs_set_dev(self, d_ids, d_zx, d_zy, nobs, d_unobs, nunobs, nlandmarks):
+        self._ck(self.lib.slam_obs_set_dev(self.h, _ptr(d_ids), _ptr(d_zx), _ptr(d_zy), nobs, _ptr(d_unobs), nunobs,
+                                           nlandmarks), "obs_set_dev")
+
+    def logweight_ekf_dev(self, d_score, gain, n, d_logw, d_max):
+        self._ck(self.lib.slam_logweight_ekf_dev(self.h, _ptr(d_score), gain, n, _ptr(d_logw), _ptr(d_max)),
+                 "logweight_ekf_dev")
+
     def obs_upload(self, landmark_id, zx, zy, nlandmarks):
         ids, zx, zy = _np(landmark_id, np.int32), _np(zx, np.float32), _np(zy, np.float32)
         self._ck(self.lib.slam_obs_upload_host(self.h, _ptr(ids), _ptr(zx), _ptr(zy), len(ids), nlandmarks),
@@ -269,6 +293,13 @@ class Engine:
     def quantise_weights_dev(self, d_logw, d_max, n, d_wq, d_sum):
         self._ck(self.lib.slam_quantise_weights_dev(self.h, _ptr(d_logw), _ptr(d_max), n, _ptr(d_wq), _ptr(d_sum)),
                  "quantise_weights_dev")
+
+    def quantise_scan_dev(self, d_logw, d_max, n, d_sum):
+        self._ck(self.lib.slam_quantise_scan_dev(self.h, _ptr(d_logw), _ptr(d_max), n, _ptr(d_sum)), "quantise_scan_dev")
+
+    def offspring_from_scan_dev(self, n, d_base, d_total, seed, frame, n_total, d_first):
+        self._ck(self.lib.slam_offspring_from_scan_dev(self.h, n, _ptr(d_base), _ptr(d_total), seed, frame, n_total,
+                                                       _ptr(d_first)), "offspring_from_scan_dev")
 
     def prefix_sum_dev(self, d_wq, n, d_cdf):
         self._ck(self.lib.slam_prefix_sum_dev(self.h, _ptr(d_wq), n, _ptr(d_cdf)), "prefix_sum_dev")

@@ -135,4 +135,48 @@ __device__ __forceinline__ u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_
     return u32x4{ { c0, c1, c2, c3 } };
 }
 
+// Motion sample of one particle (row A9; specification: oracle/slam_oracle_pf.c orc_motion_sample).
+struct MotionParams {
+    float dp[3];
+    float sigma[3];
+    uint32_t key0, key1, frame;
+    uint64_t first_id;
+};
+
+inline MotionParams make_motion_params(int64_t first_id, const float dp[3], const float sigma[3], uint64_t seed,
+                                       uint32_t frame)
+{
+    MotionParams mp;
+    for (int k = 0; k < 3; ++k) {
+        mp.dp[k] = dp[k];
+        mp.sigma[k] = sigma[k];
+    }
+    mp.key0 = (uint32_t)seed;
+    mp.key1 = (uint32_t)(seed >> 32);
+    mp.frame = frame;
+    mp.first_id = (uint64_t)first_id;
+    return mp;
+}
+
+__device__ __forceinline__ void motion_sample_one(const MotionParams& mp, uint64_t local_index, float sx, float sy,
+                                                  float sth, float& x, float& y, float& th)
+{
+    const uint64_t gid = mp.first_id + local_index;
+    const u32x4 r = philox4x32_10((uint32_t)gid, (uint32_t)(gid >> 32), mp.frame, 0u /* motion stream */, mp.key0,
+                                  mp.key1);
+    const float u1 = (float)((r.v[0] >> 8) + 1u) * 5.9604644775390625e-8f;
+    const float u2 = (float)(r.v[1] >> 8) * 5.9604644775390625e-8f;
+    const float u3 = (float)((r.v[2] >> 8) + 1u) * 5.9604644775390625e-8f;
+    const float u4 = (float)(r.v[3] >> 8) * 5.9604644775390625e-8f;
+    float s1, c1, s2, c2;
+    const float rad1 = sqrtf(-2.0f * det_logf(u1));   // sqrtf: correctly rounded (NOT __fsqrt_rn)
+    det_sincosf(6.2831853072f * u2, s1, c1);
+    const float rad2 = sqrtf(-2.0f * det_logf(u3));
+    det_sincosf(6.2831853072f * u4, s2, c2);
+    const float z0 = rad1 * c1, z1 = rad1 * s1, z2 = rad2 * c2;
+    x = (sx + mp.dp[0]) + mp.sigma[0] * z0;
+    y = (sy + mp.dp[1]) + mp.sigma[1] * z1;
+    th = (sth + mp.dp[2]) + mp.sigma[2] * z2;
+}
+
 }  // namespace slam

@@ -57,6 +57,8 @@ constexpr int kLattice = 27;
 //   out: SCORE[27] COUNT[27] NLAST[1] HITS[SLAM_MAX_BEAMS]
 constexpr int kFmIn = 4 * kLattice + 4;
 constexpr int kFmOut = 2 * kLattice + 1 + SLAM_MAX_BEAMS;
+constexpr unsigned kStageSlots = 8;
+constexpr size_t kStageFloats = 3 * SLAM_MAX_OBS > 2 * SLAM_MAX_BEAMS ? 3 * SLAM_MAX_OBS : 2 * SLAM_MAX_BEAMS;
 
 }  // namespace
 
@@ -82,17 +84,44 @@ struct slam_engine {
     DevBuf fm_work;            // 27 x SLAM_MAX_BEAMS floats: per-candidate hit rows of the lattice kernel
     float* h_fm = nullptr;     // pinned mirror
     DevBuf scratch;            // per-call temporaries of the *_dev stages
+    DevBuf bmax_buf;           // block maxima left by slam_logweight_dev (read by slam_quantise_scan_dev)
+    int bmax_count = 0, bmax_n = -1;
+    DevBuf scan_state;         // tile-local CDF u64[n] + tile totals, left by slam_quantise_scan_dev
+    int scan_n = -1;
+    DevBuf ll_buf;             // per-chunk log-likelihood partials [nchunks][n] of the last EKF call
+    int ll_n = -1, ll_chunks = 0;
+    // pinned staging ring for the per-frame sensor uploads: one host-to-device copy per upload, and the
+    // host only waits if kStageSlots uploads are still in flight
+    float* h_stage = nullptr;
+    hipEvent_t stage_ev[8] = {};
+    unsigned stage_next = 0;
+
+    float* stage_acquire()
+    {
+        const unsigned k = stage_next++ % kStageSlots;
+        if (stage_ev[k]) (void)hipEventSynchronize(stage_ev[k]);
+        return h_stage + (size_t)k * kStageFloats;
+    }
+    hipError_t stage_release(const float* slot)
+    {
+        const unsigned k = (unsigned)((slot - h_stage) / kStageFloats);
+        if (!stage_ev[k]) {
+            hipError_t err = hipEventCreateWithFlags(&stage_ev[k], hipEventDisableTiming);
+            if (err != hipSuccess) return err;
+        }
+        return hipEventRecord(stage_ev[k], stream);
+    }
     DevBuf host_io[6];         // temporaries of the *_host convenience calls
 
     // per-kernel HIP-event timing (slam_profile_*)
-    bool prof_on = false;
+    int prof_mask = 0;
     std::vector<EventPair> prof_pool[SLAM_PROF_COUNT];   // grown on demand, reused after each read
     size_t prof_used[SLAM_PROF_COUNT] = { 0, 0, 0 };
     EventPair prof_cur{};
 
     const EventPair* prof_next(int k)
     {
-        if (!prof_on) return nullptr;
+        if (!(prof_mask & (1 << k))) return nullptr;
         auto& pool = prof_pool[k];
         if (prof_used[k] == pool.size()) {
             EventPair p;
@@ -207,7 +236,9 @@ int slam_engine_create(int device, slam_engine** out)
         e->fm_buf.ensure(sizeof(float) * (kFmIn + kFmOut)) != hipSuccess ||
         e->fm_work.ensure(sizeof(float) * kLattice * SLAM_MAX_BEAMS) != hipSuccess ||
         hipHostMalloc((void**)&e->h_fm, sizeof(float) * (kFmIn + kFmOut), hipHostMallocDefault) != hipSuccess ||
-        e->scan_buf.ensure(sizeof(float) * 2 * SLAM_MAX_BEAMS) != hipSuccess) {
+        e->scan_buf.ensure(sizeof(float) * 2 * SLAM_MAX_BEAMS) != hipSuccess ||
+        hipHostMalloc((void**)&e->h_stage, sizeof(float) * kStageSlots * kStageFloats, hipHostMallocDefault) !=
+            hipSuccess) {
         (void)hipGetLastError();
         slam_engine_destroy(e);
         return SLAM_ERR_NO_DEVICE;
@@ -221,7 +252,7 @@ int slam_engine_destroy(slam_engine* e)
 {
     if (!e) return SLAM_OK;
     (void)hipSetDevice(e->device);
-    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    (void)hipStreamSynchronize(e->stream);
     for (auto& g : e->grid) {
         g.occ_buf.release();
         g.edt_buf.release();
@@ -231,6 +262,12 @@ int slam_engine_destroy(slam_engine* e)
     e->fm_buf.release();
     e->fm_work.release();
     e->scratch.release();
+    e->bmax_buf.release();
+    e->scan_state.release();
+    e->ll_buf.release();
+    if (e->h_stage) (void)hipHostFree(e->h_stage);
+    for (auto& ev : e->stage_ev)
+        if (ev) (void)hipEventDestroy(ev);
     for (auto& b : e->host_io) b.release();
     for (auto& pool : e->prof_pool)
         for (auto& p : pool) {
@@ -243,10 +280,10 @@ int slam_engine_destroy(slam_engine* e)
     return SLAM_OK;
 }
 
-int slam_profile_enable(slam_engine* e, int enable)
+int slam_profile_enable(slam_engine* e, int mask)
 {
     ENTER(e);
-    e->prof_on = enable != 0;
+    e->prof_mask = mask;
     return SLAM_OK;
 }
 
@@ -270,7 +307,7 @@ int slam_profile_read(slam_engine* e, int kernel, double* total_ms, int64_t* lau
 int slam_engine_set_stream(slam_engine* e, void* hip_stream)
 {
     ENTER(e);
-    e->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : e->own_stream;
+    e->stream = hip_stream == SLAM_OWN_STREAM ? e->own_stream : static_cast<hipStream_t>(hip_stream);
     return SLAM_OK;
 }
 
@@ -369,11 +406,15 @@ int slam_scan_upload_host(slam_engine* e, const float* bx, const float* by, int 
     if (nbeams > SLAM_MAX_BEAMS) return SLAM_ERR_CAPACITY;
     float* d = e->scan_buf.as<float>();
     if (nbeams > 0) {
-        HIP_TRY(hipMemcpyAsync(d, bx, sizeof(float) * nbeams, hipMemcpyHostToDevice, e->stream));
-        HIP_TRY(hipMemcpyAsync(d + SLAM_MAX_BEAMS, by, sizeof(float) * nbeams, hipMemcpyHostToDevice, e->stream));
+        // pinned staging -> ONE host-to-device copy per frame (bx | by back to back)
+        float* h = e->stage_acquire();
+        memcpy(h, bx, sizeof(float) * nbeams);
+        memcpy(h + nbeams, by, sizeof(float) * nbeams);
+        HIP_TRY(hipMemcpyAsync(d, h, sizeof(float) * 2 * nbeams, hipMemcpyHostToDevice, e->stream));
+        HIP_TRY(e->stage_release(h));
     }
     e->d_bx = d;
-    e->d_by = d + SLAM_MAX_BEAMS;
+    e->d_by = d + nbeams;
     e->nbeams = nbeams;
     return SLAM_OK;
 }
@@ -554,6 +595,23 @@ int slam_motion_sample_dev(slam_engine* e, const float* d_src_x, const float* d_
     return SLAM_OK;
 }
 
+int slam_motion_score_dev(slam_engine* e, int slot, const float* d_src_x, const float* d_src_y, const float* d_src_th,
+                          const int32_t* d_anc, float* d_x, float* d_y, float* d_th, int n, int64_t first_id,
+                          const float dp[3], const float sigma[3], uint64_t seed, uint32_t frame, float* d_score,
+                          int32_t* d_count)
+{
+    ENTER(e);
+    if (n < 0 || first_id < 0 || !dp || !sigma ||
+        (n > 0 && (!d_src_x || !d_src_y || !d_src_th || !d_x || !d_y || !d_th || !d_score || !d_count)))
+        return SLAM_ERR_INVALID_ARG;
+    if (d_src_x == d_x || d_src_y == d_y || d_src_th == d_th) return SLAM_ERR_INVALID_ARG;   // several lanes re-read src
+    if (int rc = check_score_inputs(e, slot)) return rc;
+    MotionIO io{ d_src_x, d_src_y, d_src_th, d_anc, d_x, d_y, d_th };
+    HIP_TRY(launch_motion_score(e->stream, score_grid(e->grid[slot]), e->d_bx, e->d_by, e->nbeams, io, n, first_id, dp,
+                                sigma, seed, frame, d_score, d_count, e->prof_next(SLAM_PROF_SCORE)));
+    return SLAM_OK;
+}
+
 int slam_obs_upload_host(slam_engine* e, const int32_t* landmark_id, const float* zx, const float* zy, int nobs,
                          int nlandmarks)
 {
@@ -576,13 +634,16 @@ int slam_obs_upload_host(slam_engine* e, const int32_t* landmark_id, const float
         HIP_TRY(e->obs_buf.ensure(words * 4));
     }
     int32_t* d_id = e->obs_buf.as<int32_t>();
-    float* d_zx = e->obs_buf.as<float>() + SLAM_MAX_OBS;
-    float* d_zy = e->obs_buf.as<float>() + 2 * SLAM_MAX_OBS;
+    float* d_zx = e->obs_buf.as<float>() + nobs;
+    float* d_zy = e->obs_buf.as<float>() + 2 * nobs;
     int32_t* d_un = e->obs_buf.as<int32_t>() + 3 * SLAM_MAX_OBS;
-    if (nobs > 0) {
-        HIP_TRY(hipMemcpyAsync(d_id, landmark_id, sizeof(int32_t) * nobs, hipMemcpyHostToDevice, e->stream));
-        HIP_TRY(hipMemcpyAsync(d_zx, zx, sizeof(float) * nobs, hipMemcpyHostToDevice, e->stream));
-        HIP_TRY(hipMemcpyAsync(d_zy, zy, sizeof(float) * nobs, hipMemcpyHostToDevice, e->stream));
+    if (nobs > 0) {   // ids | zx | zy packed into one pinned block -> one copy
+        float* h = e->stage_acquire();
+        memcpy(h, landmark_id, sizeof(int32_t) * nobs);
+        memcpy(h + nobs, zx, sizeof(float) * nobs);
+        memcpy(h + 2 * nobs, zy, sizeof(float) * nobs);
+        HIP_TRY(hipMemcpyAsync(d_id, h, sizeof(float) * 3 * nobs, hipMemcpyHostToDevice, e->stream));
+        HIP_TRY(e->stage_release(h));
     }
     if (!unobs.empty()) {
         HIP_TRY(hipMemcpyAsync(d_un, unobs.data(), sizeof(int32_t) * unobs.size(), hipMemcpyHostToDevice, e->stream));
@@ -598,13 +659,31 @@ int slam_obs_upload_host(slam_engine* e, const int32_t* landmark_id, const float
     return SLAM_OK;
 }
 
+int slam_obs_set_dev(slam_engine* e, const int32_t* d_landmark_id, const float* d_zx, const float* d_zy, int nobs,
+                     const int32_t* d_unobserved_id, int nunobserved, int nlandmarks)
+{
+    ENTER(e);
+    if (nobs < 0 || nunobserved < 0 || nlandmarks < 0 || nobs + nunobserved != nlandmarks ||
+        (nobs > 0 && (!d_landmark_id || !d_zx || !d_zy)) || (nunobserved > 0 && !d_unobserved_id))
+        return SLAM_ERR_INVALID_ARG;
+    if (nobs > SLAM_MAX_OBS) return SLAM_ERR_CAPACITY;
+    e->d_obs_id = d_landmark_id;
+    e->d_obs_zx = d_zx;
+    e->d_obs_zy = d_zy;
+    e->d_unobs_id = d_unobserved_id;
+    e->nobs = nobs;
+    e->nunobs = nunobserved;
+    e->obs_nlandmarks = nlandmarks;
+    return SLAM_OK;
+}
+
 int slam_ekf_update_dev(slam_engine* e, const float* d_map_in, float* d_map_out, int64_t plane_stride, int ld_map,
                         int nlandmarks, const float* d_x, const float* d_y, const float* d_th, const int32_t* d_anc,
                         int n, float meas_var, float* d_loglik)
 {
     ENTER(e);
     if (n < 0 || nlandmarks < 0 || ld_map < n || plane_stride < (int64_t)nlandmarks * ld_map || !(meas_var > 0.0f) ||
-        (n > 0 && (!d_map_in || !d_map_out || !d_x || !d_y || !d_th || !d_loglik)))
+        (n > 0 && (!d_map_in || !d_map_out || !d_x || !d_y || !d_th)))
         return SLAM_ERR_INVALID_ARG;
     if (d_anc && d_map_in == d_map_out) return SLAM_ERR_INVALID_ARG;
     if (e->nobs < 0 || e->obs_nlandmarks != nlandmarks) return SLAM_ERR_NOT_READY;
@@ -630,11 +709,25 @@ int slam_ekf_update_dev(slam_engine* e, const float* d_map_in, float* d_map_out,
     a.meas_var = meas_var;
     a.loglik = d_loglik;
     a.ll_part = nullptr;
-    if (nchunks > 1) {
-        HIP_TRY(e->scratch.ensure(sizeof(float) * (size_t)nchunks * (size_t)n));
-        a.ll_part = e->scratch.as<float>();
+    if (nchunks > 1 || !d_loglik) {
+        HIP_TRY(e->ll_buf.ensure(sizeof(float) * (size_t)(nchunks > 0 ? nchunks : 1) * (size_t)n));
+        a.ll_part = e->ll_buf.as<float>();
     }
     HIP_TRY(launch_ekf_update(e->stream, a, e->prof_next(SLAM_PROF_EKF)));
+    e->ll_n = n;   // what slam_logweight_ekf_dev will consume
+    e->ll_chunks = nchunks;
+    return SLAM_OK;
+}
+
+static int logweight_common(slam_engine* e, const float* d_score, const float* d_loglik, const float* ll_part,
+                            int nchunks, float score_gain, int n, float* d_logw, float* d_max)
+{
+    if (n <= 0 || !d_logw) return SLAM_ERR_INVALID_ARG;
+    HIP_TRY(e->bmax_buf.ensure(sizeof(float) * (size_t)logweight_scratch_elems(n)));
+    HIP_TRY(launch_logweight(e->stream, d_score, d_loglik, ll_part, nchunks, score_gain, n, d_logw,
+                             e->bmax_buf.as<float>(), d_max));
+    e->bmax_count = logweight_scratch_elems(n);
+    e->bmax_n = n;
     return SLAM_OK;
 }
 
@@ -642,9 +735,38 @@ int slam_logweight_dev(slam_engine* e, const float* d_score, const float* d_logl
                        float* d_logw, float* d_max)
 {
     ENTER(e);
-    if (n <= 0 || !d_logw || !d_max) return SLAM_ERR_INVALID_ARG;
-    HIP_TRY(e->scratch.ensure(sizeof(float) * (size_t)logweight_scratch_elems(n)));
-    HIP_TRY(launch_logweight(e->stream, d_score, d_loglik, score_gain, n, d_logw, e->scratch.as<float>(), d_max));
+    return logweight_common(e, d_score, d_loglik, nullptr, 0, score_gain, n, d_logw, d_max);
+}
+
+int slam_logweight_ekf_dev(slam_engine* e, const float* d_score, float score_gain, int n, float* d_logw, float* d_max)
+{
+    ENTER(e);
+    if (e->ll_n != n) return SLAM_ERR_NOT_READY;   // needs slam_ekf_update_dev(…, n, …) on this engine first
+    if (e->ll_chunks == 0) return logweight_common(e, d_score, nullptr, nullptr, 0, score_gain, n, d_logw, d_max);
+    return logweight_common(e, d_score, nullptr, e->ll_buf.as<float>(), e->ll_chunks, score_gain, n, d_logw, d_max);
+}
+
+int slam_quantise_scan_dev(slam_engine* e, const float* d_logw, const float* d_max, int n, uint64_t* d_sum)
+{
+    ENTER(e);
+    if (n <= 0 || !d_logw) return SLAM_ERR_INVALID_ARG;
+    if (!d_max && e->bmax_n != n) return SLAM_ERR_NOT_READY;   // needs the maxima of slam_logweight_dev(n)
+    const size_t ntiles = (size_t)prefix_sum_scratch_elems(n);
+    HIP_TRY(e->scan_state.ensure(sizeof(uint64_t) * ((size_t)n + ntiles)));
+    uint64_t* cdf = e->scan_state.as<uint64_t>();
+    HIP_TRY(launch_quantise_scan(e->stream, d_logw, d_max, e->bmax_buf.as<float>(), e->bmax_count, n, cdf, cdf + n, d_sum));
+    e->scan_n = n;
+    return SLAM_OK;
+}
+
+int slam_offspring_from_scan_dev(slam_engine* e, int n, const uint64_t* d_base, const uint64_t* d_total, uint64_t seed,
+                                 uint32_t frame, int64_t n_total, int32_t* d_first)
+{
+    ENTER(e);
+    if (n <= 0 || n_total < n || n_total > 0x7fffffff || !d_first) return SLAM_ERR_INVALID_ARG;
+    if (e->scan_n != n) return SLAM_ERR_NOT_READY;
+    const uint64_t* cdf = e->scan_state.as<uint64_t>();
+    HIP_TRY(launch_offspring_from_scan(e->stream, cdf, cdf + n, n, d_base, d_total, seed, frame, n_total, d_first));
     return SLAM_OK;
 }
 

@@ -25,6 +25,16 @@ struct ScoreGrid {
 hipError_t launch_score_poses(hipStream_t stream, const ScoreGrid& g, const float* bx, const float* by, int nbeams,
                               const float* x, const float* y, const float* th_or_ct, const float* st_or_null,
                               int nposes, float* score, int32_t* count, const EventPair* ev = nullptr);
+// motion sample fused in front of the score: pose' = motion(src[anc]), written to dst and scored
+struct MotionIO {
+    const float *sx, *sy, *sth;
+    const int32_t* anc;
+    float *x, *y, *th;
+};
+hipError_t launch_motion_score(hipStream_t stream, const ScoreGrid& g, const float* bx, const float* by, int nbeams,
+                               const MotionIO& io, int nposes, int64_t first_id, const float dp[3], const float sigma[3],
+                               uint64_t seed, uint32_t frame, float* score, int32_t* count,
+                               const EventPair* ev = nullptr);
 hipError_t launch_pose_hits(hipStream_t stream, const ScoreGrid& g, const float* bx, const float* by, int nbeams,
                             const float* pose_xycs /*4 floats on device*/, float* hits, int32_t* count);
 
@@ -66,12 +76,18 @@ struct EkfArgs {
 enum { EKF_OBS_CHUNK = 32 };
 hipError_t launch_ekf_update(hipStream_t stream, const EkfArgs& a, const EventPair* ev = nullptr);
 
-hipError_t launch_logweight(hipStream_t stream, const float* score, const float* loglik, float gain, int n,
-                            float* logw, float* block_max_scratch, float* d_max);
+hipError_t launch_logweight(hipStream_t stream, const float* score, const float* loglik, const float* ll_part,
+                            int nchunks, float gain, int n, float* logw, float* block_max_scratch, float* d_max);
 int logweight_scratch_elems(int n);
 hipError_t launch_quantise_weights(hipStream_t stream, const float* logw, const float* d_max, int n, uint64_t* wq,
                                    uint64_t* d_sum);
 
+// fused frame-loop form (quantise + tile scan; offsets straight from the tile-local scan)
+hipError_t launch_quantise_scan(hipStream_t stream, const float* logw, const float* d_max, const float* block_max,
+                                int nblock_max, int n, uint64_t* cdf_local, uint64_t* tile_total, uint64_t* d_sum);
+hipError_t launch_offspring_from_scan(hipStream_t stream, const uint64_t* cdf_local, const uint64_t* tile_total, int n,
+                                      const uint64_t* d_base, const uint64_t* d_total, uint64_t seed, uint32_t frame,
+                                      int64_t n_total, int32_t* first);
 hipError_t launch_prefix_sum(hipStream_t stream, const uint64_t* in, int n, uint64_t* out, uint64_t* block_scratch);
 int prefix_sum_scratch_elems(int n);
 hipError_t launch_offspring_offsets(hipStream_t stream, const uint64_t* cdf, int n, const uint64_t* d_base,

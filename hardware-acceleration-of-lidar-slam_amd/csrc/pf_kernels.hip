@@ -21,37 +21,21 @@ namespace {
 constexpr int kBlock = 256;
 
 // ------------------------------------------------------------------ A9: motion sample
-struct MotionConst {
-    float dp[3];
-    float sigma[3];
-};
-
 __global__ __launch_bounds__(kBlock) void motion_sample_kernel(const float* __restrict__ sx,
                                                                const float* __restrict__ sy,
                                                                const float* __restrict__ sth,
                                                                const int32_t* __restrict__ anc, float* __restrict__ x,
                                                                float* __restrict__ y, float* __restrict__ th, int n,
-                                                               uint64_t first_id, MotionConst mc, uint32_t key0,
-                                                               uint32_t key1, uint32_t frame)
+                                                               MotionParams mp)
 {
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
-    const uint64_t gid = first_id + (uint64_t)i;
-    const u32x4 r = philox4x32_10((uint32_t)gid, (uint32_t)(gid >> 32), frame, 0u /* motion stream */, key0, key1);
-    const float u1 = (float)((r.v[0] >> 8) + 1u) * 5.9604644775390625e-8f;
-    const float u2 = (float)(r.v[1] >> 8) * 5.9604644775390625e-8f;
-    const float u3 = (float)((r.v[2] >> 8) + 1u) * 5.9604644775390625e-8f;
-    const float u4 = (float)(r.v[3] >> 8) * 5.9604644775390625e-8f;
-    float s1, c1, s2, c2;
-    const float rad1 = sqrtf(-2.0f * det_logf(u1));
-    det_sincosf(6.2831853072f * u2, s1, c1);
-    const float rad2 = sqrtf(-2.0f * det_logf(u3));
-    det_sincosf(6.2831853072f * u4, s2, c2);
-    const float z0 = rad1 * c1, z1 = rad1 * s1, z2 = rad2 * c2;
     const int j = anc ? anc[i] : i;
-    x[i] = (sx[j] + mc.dp[0]) + mc.sigma[0] * z0;
-    y[i] = (sy[j] + mc.dp[1]) + mc.sigma[1] * z1;
-    th[i] = (sth[j] + mc.dp[2]) + mc.sigma[2] * z2;
+    float ox, oy, ot;
+    motion_sample_one(mp, (uint64_t)i, sx[j], sy[j], sth[j], ox, oy, ot);
+    x[i] = ox;
+    y[i] = oy;
+    th[i] = ot;
 }
 
 // ------------------------------------------------------------------ A10: 2x2 EKF per (particle, landmark)
@@ -119,7 +103,7 @@ __global__ __launch_bounds__(kBlock) void ekf_update_kernel(EkfArgs a)
         out[3 * ps + wi] = oxy;
         out[4 * ps + wi] = oyy;
     }
-    if (gridDim.y == 1)
+    if (gridDim.y == 1 && a.loglik)
         a.loglik[i] = 0.0f + part;
     else
         a.ll_part[(int64_t)chunk * a.n + i] = part;
@@ -157,14 +141,22 @@ __device__ __forceinline__ float wave_max(float v)
     return v;
 }
 
+// ll_part/nchunks: when the EKF left its per-chunk partial sums (nchunks > 1) they are added up here in
+// chunk order — the specified summation order — instead of in a separate finalize pass.
 __global__ __launch_bounds__(kBlock) void logweight_kernel(const float* __restrict__ score,
-                                                           const float* __restrict__ loglik, float gain, int n,
-                                                           float* __restrict__ logw, float* __restrict__ block_max)
+                                                           const float* __restrict__ loglik,
+                                                           const float* __restrict__ ll_part, int nchunks, float gain,
+                                                           int n, float* __restrict__ logw,
+                                                           float* __restrict__ block_max)
 {
     __shared__ float s_max[kBlock / 64];
     float m = -INFINITY;
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
-        const float ll = loglik ? loglik[i] : 0.0f;
+        float ll = loglik ? loglik[i] : 0.0f;
+        if (ll_part) {
+            ll = 0.0f;
+            for (int c = 0; c < nchunks; ++c) ll = ll + ll_part[(int64_t)c * n + i];
+        }
         const float sc = score ? score[i] * gain : 0.0f;
         const float lw = ll - sc;
         logw[i] = lw;
@@ -311,6 +303,75 @@ __global__ __launch_bounds__(kBlock) void add_tile_offsets_kernel(uint64_t* __re
     }
 }
 
+// ---- fused frame-loop form: weights are quantised and scanned in one pass, never stored
+// max over an array of block maxima, by the whole workgroup (every workgroup repeats it: <= 2048 floats)
+__device__ __forceinline__ float block_max_of(const float* __restrict__ v, int count, float* s_red /*[kBlock/64]*/)
+{
+    float m = -INFINITY;
+    for (int i = threadIdx.x; i < count; i += kBlock) m = fmaxf(m, v[i]);
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    float r = s_red[0];
+#pragma unroll
+    for (int w = 1; w < kBlock / 64; ++w) r = fmaxf(r, s_red[w]);
+    __syncthreads();
+    return r;
+}
+
+__global__ __launch_bounds__(kBlock) void quantise_scan_kernel(const float* __restrict__ logw,
+                                                               const float* __restrict__ d_max,
+                                                               const float* __restrict__ block_max, int nblock_max,
+                                                               int n, uint64_t* __restrict__ cdf_local,
+                                                               uint64_t* __restrict__ tile_total)
+{
+    __shared__ uint64_t s_wave[kBlock / 64];
+    __shared__ float s_red[kBlock / 64];
+    const float m = d_max ? *d_max : block_max_of(block_max, nblock_max, s_red);
+    const int base = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
+    uint64_t v[kScanItems];
+    uint64_t run = 0;
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+        const int i = base + k;
+        uint64_t q = 0;
+        if (i < n) q = (uint64_t)(det_expf(logw[i] - m) * 4294967296.0f);
+        run += q;
+        v[k] = run;
+    }
+    uint64_t total;
+    const uint64_t incl = block_inclusive_scan(run, s_wave, total);
+    const uint64_t excl = incl - run;
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+        const int i = base + k;
+        if (i < n) cdf_local[i] = v[k] + excl;   // inclusive, local to this 2048-element tile
+    }
+    if (threadIdx.x == 0) tile_total[blockIdx.x] = total;
+}
+
+__device__ __forceinline__ uint64_t block_sum_u64(uint64_t v, uint64_t* s_red /*[kBlock/64]*/)
+{
+    v = wave_sum_u64(v);
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    uint64_t r = 0;
+#pragma unroll
+    for (int w = 0; w < kBlock / 64; ++w) r += s_red[w];
+    __syncthreads();
+    return r;
+}
+
+__global__ __launch_bounds__(kBlock) void sum_tiles_kernel(const uint64_t* __restrict__ tile_total, int ntiles,
+                                                           uint64_t* __restrict__ d_sum)
+{
+    __shared__ uint64_t s_red[kBlock / 64];
+    uint64_t acc = 0;
+    for (int t = threadIdx.x; t < ntiles; t += kBlock) acc += tile_total[t];
+    acc = block_sum_u64(acc, s_red);
+    if (threadIdx.x == 0) *d_sum = acc;
+}
+
 // floor((hi:lo) / d) for hi < d < 2^63 (so the quotient fits 64 bits): restoring long division
 __device__ __forceinline__ uint64_t div128by64(uint64_t hi, uint64_t lo, uint64_t d)
 {
@@ -355,6 +416,48 @@ __global__ __launch_bounds__(kBlock) void offspring_offsets_kernel(const uint64_
         f = (int32_t)(div128by64(hi, lo, total) + 1ull);
     }
     first[i] = f;
+}
+
+// comb_first(): shared by the staged and the fused offsets kernels
+__device__ __forceinline__ int32_t comb_first(uint64_t c_excl, uint64_t total, uint64_t n_total, uint32_t key0,
+                                              uint32_t key1, uint32_t frame)
+{
+    if (total == 0 || (total >> 63)) return 0;   // see offspring_offsets_kernel
+    const u32x4 r = philox4x32_10(0u, 0u, frame, 1u /* resample stream */, key0, key1);
+    const uint64_t comb_u = __umul64hi((uint64_t)r.v[0] | ((uint64_t)r.v[1] << 32), total);
+    uint64_t lo = c_excl * n_total, hi = __umul64hi(c_excl, n_total);
+    if (hi == 0 && lo <= comb_u) return 0;
+    const uint64_t sub = comb_u + 1ull;
+    hi -= lo < sub ? 1ull : 0ull;
+    lo -= sub;
+    return (int32_t)(div128by64(hi, lo, total) + 1ull);
+}
+
+// fused form: CDF = base + (sum of earlier tiles) + tile-local scan; every workgroup re-derives its tile's
+// offset (and, on a single GPU, the grand total) from the <= n/2048 tile totals instead of a separate pass
+__global__ __launch_bounds__(kBlock) void offspring_from_scan_kernel(const uint64_t* __restrict__ cdf_local,
+                                                                     const uint64_t* __restrict__ tile_total,
+                                                                     int ntiles, int n,
+                                                                     const uint64_t* __restrict__ d_base,
+                                                                     const uint64_t* __restrict__ d_total,
+                                                                     uint32_t key0, uint32_t key1, uint32_t frame,
+                                                                     uint64_t n_total, int32_t* __restrict__ first)
+{
+    __shared__ uint64_t s_red[kBlock / 64];
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    const int tile = (blockIdx.x * kBlock) / kScanTile;   // kScanTile is a multiple of kBlock
+    uint64_t before = 0, all = 0;
+    for (int t = threadIdx.x; t < ntiles; t += kBlock) {
+        const uint64_t v = tile_total[t];
+        all += v;
+        before += t < tile ? v : 0ull;
+    }
+    before = block_sum_u64(before, s_red);
+    const uint64_t total = d_total ? *d_total : block_sum_u64(all, s_red);
+    if (i >= n) return;
+    const uint64_t base = (d_base ? *d_base : 0ull) + before;
+    const uint64_t c_excl = base + ((i % kScanTile) ? cdf_local[i - 1] : 0ull);
+    first[i] = comb_first(c_excl, total, n_total, key0, key1, frame);
 }
 
 __global__ __launch_bounds__(kBlock) void ancestors_kernel(const int32_t* __restrict__ first_all, int64_t n_total,
@@ -403,13 +506,8 @@ hipError_t launch_motion_sample(hipStream_t stream, const float* sx, const float
                                 const float dp[3], const float sigma[3], uint64_t seed, uint32_t frame)
 {
     if (n <= 0) return hipSuccess;
-    MotionConst mc;
-    for (int k = 0; k < 3; ++k) {
-        mc.dp[k] = dp[k];
-        mc.sigma[k] = sigma[k];
-    }
-    motion_sample_kernel<<<blocks_for(n), kBlock, 0, stream>>>(sx, sy, sth, anc, x, y, th, n, (uint64_t)first_id, mc,
-                                                               (uint32_t)seed, (uint32_t)(seed >> 32), frame);
+    const MotionParams mp = make_motion_params(first_id, dp, sigma, seed, frame);
+    motion_sample_kernel<<<blocks_for(n), kBlock, 0, stream>>>(sx, sy, sth, anc, x, y, th, n, mp);
     return hipGetLastError();
 }
 
@@ -422,13 +520,14 @@ hipError_t launch_ekf_update(hipStream_t stream, const EkfArgs& a, const EventPa
         map_copy_through_kernel<<<dim3(blocks_for(a.n), gy), kBlock, 0, stream>>>(a);
     }
     if (nchunks == 0) {
+        if (!a.loglik) return hipGetLastError();
         hipError_t err = hipMemsetAsync(a.loglik, 0, sizeof(float) * (size_t)a.n, stream);
         return err != hipSuccess ? err : hipGetLastError();
     }
     if (ev) (void)hipEventRecord(ev->start, stream);
     ekf_update_kernel<<<dim3(blocks_for(a.n), nchunks), kBlock, 0, stream>>>(a);
     if (ev) (void)hipEventRecord(ev->stop, stream);
-    if (nchunks > 1)
+    if (nchunks > 1 && a.loglik)   // loglik == nullptr: the partials are consumed by launch_logweight instead
         ekf_loglik_finalize_kernel<<<blocks_for(a.n), kBlock, 0, stream>>>(a.ll_part, nchunks, a.n, a.loglik);
     return hipGetLastError();
 }
@@ -436,13 +535,13 @@ hipError_t launch_ekf_update(hipStream_t stream, const EkfArgs& a, const EventPa
 static int capped_blocks(int n) { const int b = blocks_for(n); return b < 2048 ? b : 2048; }
 int logweight_scratch_elems(int n) { return capped_blocks(n > 0 ? n : 1); }
 
-hipError_t launch_logweight(hipStream_t stream, const float* score, const float* loglik, float gain, int n,
-                            float* logw, float* block_max_scratch, float* d_max)
+hipError_t launch_logweight(hipStream_t stream, const float* score, const float* loglik, const float* ll_part,
+                            int nchunks, float gain, int n, float* logw, float* block_max_scratch, float* d_max)
 {
     if (n <= 0) return hipSuccess;
     const int nb = capped_blocks(n);
-    logweight_kernel<<<nb, kBlock, 0, stream>>>(score, loglik, gain, n, logw, block_max_scratch);
-    max_finalize_kernel<<<1, kBlock, 0, stream>>>(block_max_scratch, nb, d_max);
+    logweight_kernel<<<nb, kBlock, 0, stream>>>(score, loglik, ll_part, nchunks, gain, n, logw, block_max_scratch);
+    if (d_max) max_finalize_kernel<<<1, kBlock, 0, stream>>>(block_max_scratch, nb, d_max);
     return hipGetLastError();
 }
 
@@ -468,6 +567,28 @@ hipError_t launch_prefix_sum(hipStream_t stream, const uint64_t* in, int n, uint
         scan_totals_kernel<<<1, kBlock, 0, stream>>>(block_scratch, ntiles);
         add_tile_offsets_kernel<<<ntiles, kBlock, 0, stream>>>(out, n, block_scratch);
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_quantise_scan(hipStream_t stream, const float* logw, const float* d_max, const float* block_max,
+                                int nblock_max, int n, uint64_t* cdf_local, uint64_t* tile_total, uint64_t* d_sum)
+{
+    if (n <= 0) return hipSuccess;
+    const int ntiles = (n + kScanTile - 1) / kScanTile;
+    quantise_scan_kernel<<<ntiles, kBlock, 0, stream>>>(logw, d_max, block_max, nblock_max, n, cdf_local, tile_total);
+    if (d_sum) sum_tiles_kernel<<<1, kBlock, 0, stream>>>(tile_total, ntiles, d_sum);
+    return hipGetLastError();
+}
+
+hipError_t launch_offspring_from_scan(hipStream_t stream, const uint64_t* cdf_local, const uint64_t* tile_total, int n,
+                                      const uint64_t* d_base, const uint64_t* d_total, uint64_t seed, uint32_t frame,
+                                      int64_t n_total, int32_t* first)
+{
+    if (n <= 0) return hipSuccess;
+    const int ntiles = (n + kScanTile - 1) / kScanTile;
+    offspring_from_scan_kernel<<<blocks_for(n), kBlock, 0, stream>>>(cdf_local, tile_total, ntiles, n, d_base, d_total,
+                                                                     (uint32_t)seed, (uint32_t)(seed >> 32), frame,
+                                                                     (uint64_t)n_total, first);
     return hipGetLastError();
 }
 

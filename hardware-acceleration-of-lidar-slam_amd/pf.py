@@ -43,6 +43,15 @@ class HipOps:
     def score(self, slot, x, y, th, n, score, count):
         self.e.score_poses_dev(slot, x, y, th, n, score, count)
 
+    def motion_score(self, slot, src, anc, dst, n, first_id, dp, sigma, seed, frame, score, count):
+        self.e.motion_score_dev(slot, src, anc, dst, n, first_id, dp, sigma, seed, frame, score, count)
+
+    def obs_set_dev(self, d_ids, d_zx, d_zy, nobs, d_unobs, nunobs, nlandmarks):
+        self.e.obs_set_dev(d_ids, d_zx, d_zy, nobs, d_unobs, nunobs, nlandmarks)
+
+    def logweight_ekf(self, score, gain, n, logw, d_max):
+        self.e.logweight_ekf_dev(score, gain, n, logw, d_max)
+
     def obs_upload(self, ids, zx, zy, nlandmarks):
         self.e.obs_upload(ids, zx, zy, nlandmarks)
 
@@ -57,6 +66,12 @@ class HipOps:
 
     def prefix_sum(self, wq, n, cdf):
         self.e.prefix_sum_dev(wq, n, cdf)
+
+    def quantise_scan(self, logw, d_max, n, d_sum):
+        self.e.quantise_scan_dev(logw, d_max, n, d_sum)
+
+    def offspring_from_scan(self, n, d_base, d_total, seed, frame, n_total, first):
+        self.e.offspring_from_scan_dev(n, d_base, d_total, seed, frame, n_total, first)
 
     def offspring_offsets(self, cdf, n, d_base, d_total, seed, frame, n_total, first):
         self.e.offspring_offsets_dev(cdf, n, d_base, d_total, seed, frame, n_total, first)
@@ -97,8 +112,6 @@ class ParticleFilter:
         self.count = torch.zeros(self.n, dtype=i32, device=dv)
         self.loglik = torch.zeros(self.n, dtype=f32, device=dv)
         self.logw = torch.zeros(self.n, dtype=f32, device=dv)
-        self.wq = torch.zeros(self.n, dtype=i64, device=dv)                       # uint64 bit patterns (< 2^63)
-        self.cdf = torch.zeros(self.n, dtype=i64, device=dv)
         self.first = torch.zeros(self.n, dtype=i32, device=dv)
         self.first_all = self.first if world == 1 else torch.zeros(self.n_total, dtype=i32, device=dv)
         self.anc = torch.zeros((2, self.n), dtype=i32, device=dv)                # double-buffered: the fused gathers
@@ -133,40 +146,46 @@ class ParticleFilter:
         return m[:, :, : self.n] if self.src_idx is None else m[:, :, self.src_idx.long()]
 
     # ------------------------------------------------------------------ one frame
-    def step(self, dp, obs=None):
-        """dp: odometry increment (3 floats).  obs: (landmark ids, zx, zy) host arrays or None."""
+    def step(self, dp, obs=None, obs_dev=None):
+        """dp: odometry increment (3 floats).  Observations of this frame, either
+        obs = (landmark ids, zx, zy) host arrays (uploaded here), or
+        obs_dev = (d_ids, d_zx, d_zy, nobs, d_unobserved_ids, nunobserved) already resident on the device."""
         o, n, cur, nxt = self.ops, self.n, self.cur, 1 - self.cur
         src, dst = self.pose[cur], self.pose[nxt]
-        # 1. motion (+ fused gather of the previous resample)
-        o.motion_sample((src[0], src[1], src[2]), self.src_idx, (dst[0], dst[1], dst[2]), n, self.rank * n, dp,
-                        self.sigma, self.seed, self.frame)
-        # 2. scan-match score
-        o.score(self.grid_slot, dst[0], dst[1], dst[2], n, self.score, self.count)
-        # 3. per-landmark EKF (+ fused gather)
-        use_ll = self.L > 0 and obs is not None
+        # 1+2. motion (+ fused gather of the previous resample) and scan-match score, one launch
+        o.motion_score(self.grid_slot, (src[0], src[1], src[2]), self.src_idx, (dst[0], dst[1], dst[2]), n,
+                       self.rank * n, dp, self.sigma, self.seed, self.frame, self.score, self.count)
+        # 3. per-landmark EKF (+ fused gather); the log-likelihood stays inside the engine for step 4
+        use_ll = self.L > 0 and (obs is not None or obs_dev is not None)
         if use_ll:
-            o.obs_upload(obs[0], obs[1], obs[2], self.L)
+            if obs_dev is not None:
+                o.obs_set_dev(*obs_dev, self.L)
+            else:
+                o.obs_upload(obs[0], obs[1], obs[2], self.L)
             o.ekf(self.map[cur], self.map[nxt], self.L * self.cap, self.cap, self.L, dst[0], dst[1], dst[2],
-                  self.src_idx, n, self.meas_var, self.loglik)
+                  self.src_idx, n, self.meas_var, None)
         elif self.L > 0:   # no observation this frame: the maps still have to follow their particles
             idx = self.src_idx if self.src_idx is not None else torch.arange(n, dtype=torch.int32, device=self.device)
             o.gather_map(self.map[cur], self.map[nxt], self.L * self.cap, self.L * self.cap, self.cap, self.cap,
                          self.L, idx, n)
-        # 4. weights
-        o.logweight(self.score, self.loglik if use_ll else None, self.score_gain, n, self.logw, self.d_max)
-        if self.world > 1:
+        # 4. weights (fused form: the fixed-point weights are scanned as they are produced, never stored)
+        multi = self.world > 1
+        if use_ll:
+            o.logweight_ekf(self.score, self.score_gain, n, self.logw, self.d_max if multi else None)
+        else:
+            o.logweight(self.score, None, self.score_gain, n, self.logw, self.d_max if multi else None)
+        if multi:
             dist.all_reduce(self.d_max, op=dist.ReduceOp.MAX, group=self.group)
-        o.quantise(self.logw, self.d_max, n, self.wq, self.d_sum)
+        o.quantise_scan(self.logw, self.d_max if multi else None, n, self.d_sum if multi else None)
         # 5. resample on the integer CDF
-        o.prefix_sum(self.wq, n, self.cdf)
-        if self.world > 1:
+        if multi:
             dist.all_gather_into_tensor(self.totals, self.d_sum, group=self.group)
             self.d_base.copy_(self.totals[: self.rank].sum().reshape(1))
             self.d_total.copy_(self.totals.sum().reshape(1))
             d_base, d_total = self.d_base, self.d_total
         else:
-            d_base, d_total = None, self.d_sum
-        o.offspring_offsets(self.cdf, n, d_base, d_total, self.seed, self.frame, self.n_total, self.first)
+            d_base, d_total = None, None
+        o.offspring_from_scan(n, d_base, d_total, self.seed, self.frame, self.n_total, self.first)
         if self.world > 1:
             dist.all_gather_into_tensor(self.first_all, self.first, group=self.group)
         anc = self.anc[nxt]

@@ -70,17 +70,21 @@ const char *slam_last_error(const slam_engine *e);
 int slam_engine_create(int device, slam_engine **out);
 int slam_engine_destroy(slam_engine *e);
 /* Run the engine on a caller-provided hipStream_t (e.g. the framework's current stream) instead of
- * its own; NULL restores the engine's own stream. */
+ * its own.  NULL means what it means to HIP: the default (null) stream.  SLAM_OWN_STREAM restores the
+ * engine's own non-blocking stream (the initial state). */
+#define SLAM_OWN_STREAM ((void *)(intptr_t)-1)
 int slam_engine_set_stream(slam_engine *e, void *hip_stream);
 int slam_engine_sync(slam_engine *e);
 
 /* Per-kernel timing with HIP events recorded on the engine's stream around the named kernel's
- * launches only (not around host work or neighbouring kernels).  Off by default.  slam_profile_read
+ * launches only (not around host work or neighbouring kernels).  Off by default.  `mask` selects the
+ * kernels: bit k = slam_prof_kernel k (an event pair costs a few microseconds of stream time per launch,
+ * so time only what you need); 0 switches timing off.  slam_profile_read
  * synchronises the stream, returns the summed duration and the launch count since the last reset
  * and resets the counters.  (The reference's only timer is clock() around the whole run,
  * main.c:826-827, 971-973.) */
 typedef enum { SLAM_PROF_SCORE = 0, SLAM_PROF_EDT = 1, SLAM_PROF_EKF = 2, SLAM_PROF_COUNT = 3 } slam_prof_kernel;
-int slam_profile_enable(slam_engine *e, int enable);
+int slam_profile_enable(slam_engine *e, int mask);
 int slam_profile_read(slam_engine *e, int kernel, double *total_ms, int64_t *launches);
 
 /* ------------------------------------------------------------------ EDT */
@@ -158,6 +162,14 @@ int slam_motion_sample_dev(slam_engine *e, const float *d_src_x, const float *d_
                            const int32_t *d_anc, float *d_x, float *d_y, float *d_th, int n, int64_t first_id,
                            const float dp[3], const float sigma[3], uint64_t seed, uint32_t frame);
 
+/* A9 + A7 in one launch: the motion sample above followed by the scan-match score of the new poses
+ * (same results as slam_motion_sample_dev then slam_score_poses_dev; source and destination arrays
+ * must differ). */
+int slam_motion_score_dev(slam_engine *e, int slot, const float *d_src_x, const float *d_src_y,
+                          const float *d_src_th, const int32_t *d_anc, float *d_x, float *d_y, float *d_th, int n,
+                          int64_t first_id, const float dp[3], const float sigma[3], uint64_t seed, uint32_t frame,
+                          float *d_score, int32_t *d_count);
+
 /* A10: per-particle x per-landmark 2x2 EKF correction (FastSLAM 1.0, known correspondences,
  * cartesian sensor-frame observations z = H (m - t), H = [[ct,-st],[st,ct]]).
  * The observation list of the current frame is sensor data like the scan: upload it once per frame
@@ -173,6 +185,12 @@ int slam_motion_sample_dev(slam_engine *e, const float *d_src_x, const float *d_
 enum { SLAM_MAX_OBS = 8192 };
 int slam_obs_upload_host(slam_engine *e, const int32_t *landmark_id, const float *zx, const float *zy, int nobs,
                          int nlandmarks);
+/* Same, for an observation list that is already on the device (nothing is copied or checked: ids must be
+ * unique, d_unobserved_id must list the nlandmarks - nobs landmarks without an observation). */
+int slam_obs_set_dev(slam_engine *e, const int32_t *d_landmark_id, const float *d_zx, const float *d_zy, int nobs,
+                     const int32_t *d_unobserved_id, int nunobserved, int nlandmarks);
+/* d_loglik may be NULL: the per-chunk partial sums then stay inside the engine and are added up, in the
+ * specified order, by slam_logweight_ekf_dev (one launch less per frame). */
 int slam_ekf_update_dev(slam_engine *e, const float *d_map_in, float *d_map_out, int64_t plane_stride, int ld_map,
                         int nlandmarks, const float *d_x, const float *d_y, const float *d_th, const int32_t *d_anc,
                         int n, float meas_var, float *d_loglik);
@@ -185,6 +203,22 @@ int slam_logweight_dev(slam_engine *e, const float *d_score, const float *d_logl
                        float *d_logw, float *d_max);
 int slam_quantise_weights_dev(slam_engine *e, const float *d_logw, const float *d_max, int n, uint64_t *d_wq,
                               uint64_t *d_sum);
+/* slam_logweight_dev with loglik = the log-likelihood of the last slam_ekf_update_dev(…, n, …) call on this
+ * engine, taken from wherever that call left it (see there). */
+int slam_logweight_ekf_dev(slam_engine *e, const float *d_score, float score_gain, int n, float *d_logw,
+                           float *d_max);
+
+/* Fused form of the two stages above + the prefix sum below, for the frame loop: weights are quantised and
+ * scanned in one pass and never stored; the engine keeps the scan for slam_offspring_from_scan_dev.
+ *   d_max  NULL on a single GPU = use the maxima the preceding slam_logweight_dev(…, n, …, d_max = NULL or
+ *          not) left inside the engine; on several GPUs pass the all-reduced maximum.
+ *   d_sum  shard total written to the device for the all-gather between GPUs; may be NULL on one GPU.
+ * slam_logweight_dev accepts d_max == NULL (the global maximum is then not materialised). */
+int slam_quantise_scan_dev(slam_engine *e, const float *d_logw, const float *d_max, int n, uint64_t *d_sum);
+/* = slam_offspring_offsets_dev on the scan kept by slam_quantise_scan_dev; d_total may be NULL on a
+ * single GPU (the grand total is then the shard total, derived inside the kernel). */
+int slam_offspring_from_scan_dev(slam_engine *e, int n, const uint64_t *d_base, const uint64_t *d_total,
+                                 uint64_t seed, uint32_t frame, int64_t n_total, int32_t *d_first);
 
 /* A12: systematic resampling on the exact integer CDF.
  *  step 1 (per shard): d_cdf[i] = inclusive prefix sum of wq within the shard.

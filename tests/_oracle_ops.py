@@ -28,6 +28,16 @@ class OracleOps:
         s, c = oracle.score_poses_det(self.meta, self.edt, self.bx, self.by, _np(x)[:n], _np(y)[:n], _np(th)[:n])
         score[:n] = torch.from_numpy(s); count[:n] = torch.from_numpy(c)
 
+    def motion_score(self, slot, src, anc, dst, n, first_id, dp, sigma, seed, frame, score, count):
+        self.motion_sample(src, anc, dst, n, first_id, dp, sigma, seed, frame)
+        self.score(slot, dst[0], dst[1], dst[2], n, score, count)
+
+    def obs_set_dev(self, d_ids, d_zx, d_zy, nobs, d_unobs, nunobs, nlandmarks):
+        self.obs = (_np(d_ids)[:nobs].copy(), _np(d_zx)[:nobs].copy(), _np(d_zy)[:nobs].copy())
+
+    def logweight_ekf(self, score, gain, n, logw, d_max):
+        self.logweight(score, torch.from_numpy(self._ll), gain, n, logw, d_max)
+
     def obs_upload(self, ids, zx, zy, nlandmarks):
         self.obs = (np.asarray(ids, np.int32), np.asarray(zx, np.float32), np.asarray(zy, np.float32))
 
@@ -38,11 +48,15 @@ class OracleOps:
         L.orc_ekf_update(_np(map_in).reshape(5, nlandmarks, ld), _np(map_out).reshape(5, nlandmarks, ld), plane_stride, ld,
                          nlandmarks, _np(x), _np(y), _np(th), a.ctypes.data_as(C.c_void_p) if a is not None else None, n,
                          self.obs[0], self.obs[1], self.obs[2], len(self.obs[0]), meas_var, ll)
-        loglik[:n] = torch.from_numpy(ll)
+        self._ll = ll
+        if loglik is not None:
+            loglik[:n] = torch.from_numpy(ll)
 
     def logweight(self, score, loglik, gain, n, logw, d_max):
         lw, m = oracle.logweight(_np(score), _np(loglik), gain)
-        logw[:n] = torch.from_numpy(lw); d_max[0] = float(m)
+        logw[:n] = torch.from_numpy(lw)
+        if d_max is not None:
+            d_max[0] = float(m)
 
     def quantise(self, logw, d_max, n, wq, d_sum):
         q, s = oracle.quantise_weights(_np(logw), float(d_max[0]))
@@ -50,6 +64,20 @@ class OracleOps:
 
     def prefix_sum(self, wq, n, cdf):
         cdf[:n] = torch.from_numpy(oracle.prefix_sum(_np(wq).view(np.uint64)).view(np.int64))
+
+    def quantise_scan(self, logw, d_max, n, d_sum):
+        lw = _np(logw)[:n]
+        m = float(d_max[0]) if d_max is not None else float(lw.max())
+        q, s = oracle.quantise_weights(lw, m)
+        self._cdf = oracle.prefix_sum(q)
+        if d_sum is not None:
+            d_sum[0] = s
+
+    def offspring_from_scan(self, n, d_base, d_total, seed, frame, n_total, first):
+        base = int(d_base[0]) if d_base is not None else 0
+        total = int(d_total[0]) if d_total is not None else int(self._cdf[-1])
+        u = oracle.comb_offset(seed, frame, total)
+        first[:n] = torch.from_numpy(oracle.offspring_offsets(self._cdf, base, total, u, n_total))
 
     def offspring_offsets(self, cdf, n, d_base, d_total, seed, frame, n_total, first):
         base = int(d_base[0]) if d_base is not None else 0

@@ -155,6 +155,35 @@ def test_weights_and_prefix_sum(eng, orc, n):
     assert np.array_equal(bits(host(logw)), bits(ll))
 
 
+@pytest.mark.parametrize("n,single_gpu", [(1, True), (2047, True), (2048, False), (2049, True), (65536, True), (1_000_003, False)])
+def test_fused_quantise_scan_offsets(eng, orc, n, single_gpu):
+    """Frame-loop form (weights never stored): first[] must equal the staged specification."""
+    rng = np.random.default_rng(n + 5)
+    score = rng.uniform(0, 300, n).astype(np.float32)
+    ll = rng.normal(-40, 15, n).astype(np.float32)
+    seed, frame = 0xFEEDFACE12345, 11
+    wl, wm = orc.logweight(score, ll, 0.21)
+    q, ssum = orc.quantise_weights(wl, wm)
+    cdf = orc.prefix_sum(q)
+    logw = torch.empty(n, device=DEV)
+    first = torch.empty(n, dtype=torch.int32, device=DEV)
+    if single_gpu:   # no maximum, no totals on the device: everything derived inside the kernels
+        eng.logweight_dev(dev(score), dev(ll), 0.21, n, logw, None)
+        eng.quantise_scan_dev(logw, None, n, None)
+        eng.offspring_from_scan_dev(n, None, None, seed, frame, n, first)
+        want = orc.offspring_offsets(cdf, 0, ssum, orc.comb_offset(seed, frame, ssum), n)
+    else:            # this shard is the middle one of three: base and grand total come from "other GPUs"
+        d_max, d_sum = torch.empty(1, device=DEV), torch.empty(1, dtype=torch.int64, device=DEV)
+        eng.logweight_dev(dev(score), dev(ll), 0.21, n, logw, d_max)
+        eng.quantise_scan_dev(logw, d_max, n, d_sum)
+        assert int(host(d_sum)[0]) == ssum and host(d_max)[0] == wm
+        base, total, n_total = 7 * ssum // 5, 4 * ssum, 3 * n
+        eng.offspring_from_scan_dev(n, dev(np.array([base], np.int64)), dev(np.array([total], np.int64)), seed, frame, n_total, first)
+        want = orc.offspring_offsets(cdf, base, total, orc.comb_offset(seed, frame, total), n_total)
+    assert np.array_equal(bits(host(logw)), bits(wl))
+    assert np.array_equal(host(first), want)
+
+
 def test_prefix_sum_full_width_values(eng):
     """64-bit carries across lanes, waves and tiles."""
     n = 300_001
@@ -207,6 +236,63 @@ def test_resample_8m_equal_weights_128bit_path(eng):
     eng.offspring_offsets_dev(cdf, n, base, total, 99, 7, n_total, first)
     f = host(first)
     assert np.array_equal(f[1:], np.arange(3 * n + 1, 4 * n, dtype=np.int32)) and f[0] == 3 * n
+
+
+def test_fused_entries_equal_staged_ones(eng, orc):
+    """slam_motion_score_dev == motion then score; EKF with the log-likelihood kept in the engine +
+    slam_logweight_ekf_dev == EKF with an explicit loglik + slam_logweight_dev; device-resident
+    observation lists == uploaded ones."""
+    import _shard_worker as W
+    pkg = load_package()
+    L = 70
+    meta, edt, bx, by, lm = W.make_world(L=L)
+    keep = dev(edt)
+    eng.grid_set_dev(2, keep, pkg.grid_meta(meta.rows, meta.cols, meta.ld, meta.pixel, meta.min_x, meta.min_y))
+    eng.scan_upload(bx, by)
+    for n in (1000, 200_000):   # both scorer mappings (4 lanes per pose / 1 lane per pose)
+        rng = np.random.default_rng(n)
+        m = n + 50
+        src = [dev(rng.normal(0, 0.3, m).astype(np.float32)) for _ in range(3)]
+        anc = dev(np.sort(rng.integers(0, m, n)).astype(np.int32))
+        dp, sig = [0.01, -0.02, 0.003], [0.02, 0.02, 0.004]
+        a = [torch.empty(n, device=DEV) for _ in range(3)]
+        b = [torch.empty(n, device=DEV) for _ in range(3)]
+        sa, ca = torch.empty(n, device=DEV), torch.empty(n, dtype=torch.int32, device=DEV)
+        sb, cb = torch.empty(n, device=DEV), torch.empty(n, dtype=torch.int32, device=DEV)
+        eng.motion_sample_dev(src, anc, a, n, 7, dp, sig, 99, 4)
+        eng.score_poses_dev(2, a[0], a[1], a[2], n, sa, ca)
+        eng.motion_score_dev(2, src, anc, b, n, 7, dp, sig, 99, 4, sb, cb)
+        for u, v in zip(a + [sa, ca], b + [sb, cb]):
+            assert torch.equal(u, v)
+        # EKF: 70 observations = 3 chunks
+        mp = _rand_map(rng, L, m, n)
+        ids = rng.permutation(L).astype(np.int32)
+        zx, zy = rng.normal(0, 2, L).astype(np.float32), rng.normal(0, 2, L).astype(np.float32)
+        d_in = dev(mp)
+        o1, o2 = torch.zeros((5, L, m), device=DEV), torch.zeros((5, L, m), device=DEV)
+        ll = torch.empty(n, device=DEV)
+        lw1, lw2 = torch.empty(n, device=DEV), torch.empty(n, device=DEV)
+        m1, m2 = torch.empty(1, device=DEV), torch.empty(1, device=DEV)
+        eng.obs_upload(ids, zx, zy, L)
+        eng.ekf_update_dev(d_in, o1, L * m, m, L, a[0], a[1], a[2], anc, n, 0.02, ll)
+        eng.logweight_dev(sa, ll, 0.3, n, lw1, m1)
+        eng.obs_set_dev(dev(ids), dev(zx), dev(zy), L, None, 0, L)
+        eng.ekf_update_dev(d_in, o2, L * m, m, L, a[0], a[1], a[2], anc, n, 0.02, None)
+        eng.logweight_ekf_dev(sa, 0.3, n, lw2, m2)
+        assert torch.equal(o1, o2) and torch.equal(lw1, lw2) and torch.equal(m1, m2)
+        # a single chunk, and a partial observation list given on the device with its complement
+        few = ids[:9].copy()
+        unobs = np.setdiff1d(np.arange(L, dtype=np.int32), few).astype(np.int32)
+        eng.obs_upload(few, zx[:9], zy[:9], L)
+        eng.ekf_update_dev(d_in, o1, L * m, m, L, a[0], a[1], a[2], anc, n, 0.02, ll)
+        eng.logweight_dev(sa, ll, 0.3, n, lw1, m1)
+        eng.obs_set_dev(dev(few), dev(zx[:9]), dev(zy[:9]), 9, dev(unobs), len(unobs), L)
+        eng.ekf_update_dev(d_in, o2, L * m, m, L, a[0], a[1], a[2], anc, n, 0.02, None)
+        eng.logweight_ekf_dev(sa, 0.3, n, lw2, m2)
+        assert torch.equal(o1, o2) and torch.equal(lw1, lw2) and torch.equal(m1, m2)
+    with pytest.raises(pkg.SlamError) as ei:
+        eng.logweight_ekf_dev(sa, 0.3, 17, lw2, m2)   # no EKF call for 17 particles on this engine
+    assert ei.value.status == -4
 
 
 def test_gathers(eng):
