@@ -166,6 +166,8 @@ def main():
     ap.add_argument("--landmarks", type=int, default=500)
     ap.add_argument("--grid", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, production) | gloo (functional rehearsal)")
+    ap.add_argument("--device-index", type=int, default=None, help="force every rank onto this GPU (rehearsal only)")
     ap.add_argument("--host-sensor", action="store_true", help="upload scan + observations from the host every frame")
     ap.add_argument("--events", choices=["dominant", "all", "none"], default="dominant",
                     help="kernels bracketed by HIP events inside the timed region (a pair costs a few us of stream time)")
@@ -190,13 +192,17 @@ def main():
 
     if not torch.cuda.is_available():
         sys.exit("bench.py: no GPU visible; the engine has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank if args.device_index is None else args.device_index
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
 
-    eng = pkg.Engine(local_rank)
+    eng = pkg.Engine(dev_index)
     ops = HipOps(eng)
     ops.bind_stream()
 
@@ -282,7 +288,7 @@ def main():
     elapsed = time.perf_counter() - t0
     eng.profile_enable()
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t[0])
 

@@ -122,8 +122,36 @@ class ParticleFilter:
         self.totals = torch.zeros(world, dtype=i64, device=dv)
         self.frame = 0
         self.migrated_last = 0
+        # gloo cannot move GPU tensors for every collective used here: stage them through the host then
+        # (functional rehearsal of the multi-rank path on one card; the production backend is nccl = RCCL)
+        self._host_staged = world > 1 and self.device.type == "cuda" and dist.get_backend(group) == "gloo"
         if hasattr(ops, "bind_stream"):
             ops.bind_stream()
+
+    # ------------------------------------------------------------------ collectives (plumbing only)
+    def _all_reduce_max(self, t):
+        if self._host_staged:
+            h = t.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.MAX, group=self.group)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+
+    def _all_gather(self, out, t):
+        if self._host_staged:
+            h = torch.empty(out.shape, dtype=out.dtype)
+            dist.all_gather_into_tensor(h, t.cpu(), group=self.group)
+            out.copy_(h)
+        else:
+            dist.all_gather_into_tensor(out, t, group=self.group)
+
+    def _all_to_all(self, out, inp, out_splits, in_splits):
+        if self._host_staged:
+            h = torch.empty(out.shape, dtype=out.dtype)
+            dist.all_to_all_single(h, inp.cpu(), out_splits, in_splits, group=self.group)
+            out.copy_(h)
+        else:
+            dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group)
 
     # ------------------------------------------------------------------ state access
     def set_poses(self, x, y, th):
@@ -175,11 +203,11 @@ class ParticleFilter:
         else:
             o.logweight(self.score, None, self.score_gain, n, self.logw, self.d_max if multi else None)
         if multi:
-            dist.all_reduce(self.d_max, op=dist.ReduceOp.MAX, group=self.group)
+            self._all_reduce_max(self.d_max)
         o.quantise_scan(self.logw, self.d_max if multi else None, n, self.d_sum if multi else None)
         # 5. resample on the integer CDF
         if multi:
-            dist.all_gather_into_tensor(self.totals, self.d_sum, group=self.group)
+            self._all_gather(self.totals, self.d_sum)
             self.d_base.copy_(self.totals[: self.rank].sum().reshape(1))
             self.d_total.copy_(self.totals.sum().reshape(1))
             d_base, d_total = self.d_base, self.d_total
@@ -187,7 +215,7 @@ class ParticleFilter:
             d_base, d_total = None, None
         o.offspring_from_scan(n, d_base, d_total, self.seed, self.frame, self.n_total, self.first)
         if self.world > 1:
-            dist.all_gather_into_tensor(self.first_all, self.first, group=self.group)
+            self._all_gather(self.first_all, self.first)
         anc = self.anc[nxt]
         o.ancestors(self.first_all, self.n_total, self.rank * n, n, anc)
         # 6. particles whose ancestor lives on another GPU
@@ -241,9 +269,9 @@ class ParticleFilter:
             if L:
                 o.gather_map(self.map[self.cur], smap[5 * L * off:], L * self.cap, L * c, self.cap, c, L, seg, c)
             off += c
-        dist.all_to_all_single(rbuf, sbuf, [3 * c for c in rcnt], [3 * c for c in scnt], group=self.group)
+        self._all_to_all(rbuf, sbuf, [3 * c for c in rcnt], [3 * c for c in scnt])
         if L:
-            dist.all_to_all_single(rmap, smap, [5 * L * c for c in rcnt], [5 * L * c for c in scnt], group=self.group)
+            self._all_to_all(rmap, smap, [5 * L * c for c in rcnt], [5 * L * c for c in scnt])
         # unpack into the staging region behind the local particles, build the local gather index
         lo_t = torch.zeros(G, dtype=torch.int64, device=dv)
         off_t = torch.zeros(G, dtype=torch.int64, device=dv)
@@ -272,7 +300,7 @@ class ParticleFilter:
         cand = torch.stack([lw.double(), (self.rank * self.n + i).double()])
         if self.world > 1:
             allc = torch.empty((self.world, 2), dtype=torch.float64, device=self.device)
-            dist.all_gather_into_tensor(allc, cand.reshape(1, 2), group=self.group)
+            self._all_gather(allc, cand.reshape(1, 2))
             k = int(torch.argmax(allc[:, 0]))   # first max = lowest rank = lowest id
             cand = allc[k]
         return float(cand[0]), int(cand[1])

@@ -93,3 +93,46 @@ def worker(rank, world, port, n_total, L, frames, outdir):
                  best=np.array(out["best"]), **({"map": out["map"]} if L else {}))
     finally:
         dist.destroy_process_group()
+
+
+def worker_gpu(rank, world, port, n_total, L, frames, outdir):
+    """Two ranks sharing ONE MI355X (cuda:0), gloo for the exchange (staged through the host by pf.py):
+    the real HIP stages + the real sharding/migration logic, without needing a second card."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from __graft_entry__ import load_package
+
+        pkg = load_package()
+        from hardware_acceleration_of_lidar_slam_amd.pf import HipOps, ParticleFilter
+
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(dev)
+        meta, edt, bx, by, lm = make_world(L=L)
+        eng = pkg.Engine(0)
+        d_edt = torch.from_numpy(edt).to(dev)
+        eng.set_stream(torch.cuda.current_stream().cuda_stream)
+        eng.grid_set_dev(0, d_edt, pkg.grid_meta(meta.rows, meta.cols, meta.ld, meta.pixel, meta.min_x, meta.min_y))
+        eng.scan_upload(bx, by)
+        n = n_total // world
+        pf = ParticleFilter(HipOps(eng), n, L, device=dev, rank=rank, world=world, seed=77, sigma=(0.02, 0.02, 0.004),
+                            meas_var=0.02, score_gain=0.05 if L else 1.0, grid_slot=0)
+        x, y, th, mp = init_state(n_total, L, lm)
+        sl = slice(rank * n, (rank + 1) * n)
+        pf.set_poses(x[sl], y[sl], th[sl])
+        if L:
+            pf.set_map(mp[:, :, sl])
+        migrated = []
+        for f in range(frames):
+            pf.step([0.01, -0.005, 0.002], observations(lm, f) if L else None)
+            migrated.append(pf.migrated_last)
+        torch.cuda.synchronize()
+        out = {"pose": pf.poses().cpu().numpy(), "logw": pf.logw.cpu().numpy(), "migrated": np.array(migrated),
+               "best": np.array(pf.best_particle())}
+        if L:
+            out["map"] = pf.maps().cpu().numpy()
+        np.savez(Path(outdir) / f"rank{rank}.npz", **out)
+        eng.close()
+    finally:
+        dist.destroy_process_group()
