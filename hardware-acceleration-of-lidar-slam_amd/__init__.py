@@ -84,8 +84,18 @@ SIGNATURES = {
     "slam_offspring_offsets_dev": (_i, [_vp, _vp, _i, _vp, _vp, _u64, _u32, _i64, _vp]),
     "slam_ancestors_dev": (_i, [_vp, _vp, _i64, _i64, _i, _vp]),
     "slam_comb_offset": (_u64, [_u64, _u32, _u64]),
+    "slam_argmax_dev": (_i, [_vp, _vp, _i, _vp, _vp]),
     "slam_gather_f32_dev": (_i, [_vp, _vp, _vp, _i, _vp]),
     "slam_gather_map_dev": (_i, [_vp, _vp, _vp, _i64, _i64, _i, _i, _i, _vp, _i]),
+    "slam_pf_create": (_i, [_vp, _vp, C.POINTER(_vp)]),
+    "slam_pf_destroy": (_i, [_vp]),
+    "slam_pf_reset": (_i, [_vp, _fp]),
+    "slam_pf_set_poses_host": (_i, [_vp, _vp, _vp, _vp]),
+    "slam_pf_set_map_host": (_i, [_vp, _vp]),
+    "slam_pf_step": (_i, [_vp, _i, _fp, _i]),
+    "slam_pf_best": (_i, [_vp, _fp, _fp, C.POINTER(C.c_int32)]),
+    "slam_pf_get_poses_host": (_i, [_vp, _vp, _vp, _vp]),
+    "slam_pf_get_map_host": (_i, [_vp, _vp]),
 }
 
 _LIB = None
@@ -318,6 +328,61 @@ class Engine:
     def gather_map_dev(self, d_in, d_out, in_stride, out_stride, ld_in, ld_out, nlandmarks, d_idx, n):
         self._ck(self.lib.slam_gather_map_dev(self.h, _ptr(d_in), _ptr(d_out), in_stride, out_stride, ld_in, ld_out,
                                               nlandmarks, _ptr(d_idx), n), "gather_map_dev")
+
+
+class PfConfig(C.Structure):
+    """``slam_pf_config``"""
+
+    _fields_ = [("n_particles", C.c_int32), ("n_landmarks", C.c_int32), ("sigma", C.c_float * 3),
+                ("meas_var", C.c_float), ("score_gain", C.c_float), ("seed", C.c_uint64)]
+
+
+class PfSession:
+    """``slam_pf`` — the C-level particle-filter session (what a plain C host uses)."""
+
+    def __init__(self, engine: Engine, n_particles, n_landmarks=0, sigma=(0.01, 0.01, 0.002), meas_var=0.01,
+                 score_gain=1.0, seed=1):
+        self.e, self.n, self.L = engine, n_particles, n_landmarks
+        cfg = PfConfig(n_particles, n_landmarks, (C.c_float * 3)(*sigma), meas_var, score_gain, seed)
+        h = C.c_void_p()
+        engine._ck(engine.lib.slam_pf_create(engine.h, C.byref(cfg), C.byref(h)), "pf_create")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.e.lib.slam_pf_destroy(self.h)
+            self.h = None
+
+    def reset(self, pose):
+        self.e._ck(self.e.lib.slam_pf_reset(self.h, _f3(pose)), "pf_reset")
+
+    def set_poses(self, x, y, th):
+        x, y, th = (_np(a, np.float32) for a in (x, y, th))
+        self.e._ck(self.e.lib.slam_pf_set_poses_host(self.h, _ptr(x), _ptr(y), _ptr(th)), "pf_set_poses")
+
+    def set_map(self, planes):
+        planes = _np(planes, np.float32)
+        assert planes.shape == (5, self.L, self.n)
+        self.e._ck(self.e.lib.slam_pf_set_map_host(self.h, _ptr(planes)), "pf_set_map")
+
+    def step(self, slot, dp, use_observations=False):
+        self.e._ck(self.e.lib.slam_pf_step(self.h, slot, _f3(dp), 1 if use_observations else 0), "pf_step")
+
+    def best(self):
+        pose = (C.c_float * 3)()
+        lw, idx = C.c_float(0), C.c_int32(0)
+        self.e._ck(self.e.lib.slam_pf_best(self.h, pose, C.byref(lw), C.byref(idx)), "pf_best")
+        return np.array(list(pose), np.float32), np.float32(lw.value), idx.value
+
+    def poses(self):
+        x, y, th = (np.empty(self.n, np.float32) for _ in range(3))
+        self.e._ck(self.e.lib.slam_pf_get_poses_host(self.h, _ptr(x), _ptr(y), _ptr(th)), "pf_get_poses")
+        return np.stack([x, y, th])
+
+    def maps(self):
+        m = np.empty((5, self.L, self.n), np.float32)
+        self.e._ck(self.e.lib.slam_pf_get_map_host(self.h, _ptr(m)), "pf_get_map")
+        return m
 
 
 def comb_offset(seed: int, frame: int, total: int) -> int:

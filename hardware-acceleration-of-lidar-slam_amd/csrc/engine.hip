@@ -818,6 +818,14 @@ uint64_t slam_comb_offset(uint64_t seed, uint32_t frame, uint64_t total)
     return (uint64_t)(((unsigned __int128)r64 * total) >> 64);
 }
 
+int slam_argmax_dev(slam_engine* e, const float* d_values, int n, int32_t* d_index, float* d_value)
+{
+    ENTER(e);
+    if (n <= 0 || !d_values || !d_index || !d_value) return SLAM_ERR_INVALID_ARG;
+    HIP_TRY(launch_argmax(e->stream, d_values, n, d_index, d_value));
+    return SLAM_OK;
+}
+
 int slam_gather_f32_dev(slam_engine* e, const float* d_src, const int32_t* d_idx, int n, float* d_dst)
 {
     ENTER(e);

@@ -95,6 +95,7 @@ hipError_t launch_offspring_offsets(hipStream_t stream, const uint64_t* cdf, int
                                     int32_t* first);
 hipError_t launch_ancestors(hipStream_t stream, const int32_t* first_all, int64_t n_total, int64_t slot0, int nslots,
                             int32_t* anc);
+hipError_t launch_argmax(hipStream_t stream, const float* v, int n, int32_t* idx_out, float* val_out);
 hipError_t launch_gather_f32(hipStream_t stream, const float* src, const int32_t* idx, int n, float* dst);
 hipError_t launch_gather_map(hipStream_t stream, const float* in, float* out, int64_t in_stride, int64_t out_stride,
                              int ld_in, int ld_out, int nlandmarks, const int32_t* idx, int n);

@@ -497,6 +497,34 @@ __global__ __launch_bounds__(kBlock) void gather_map_kernel(const float* __restr
     }
 }
 
+// index of the largest value, lowest index on ties (the heaviest particle); one workgroup
+__global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ v, int n, int32_t* __restrict__ idx_out,
+                                                      float* __restrict__ val_out)
+{
+    __shared__ float s_v[16];
+    __shared__ int s_i[16];
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        const float x = v[i];
+        if (x > bv || (x == bv && i < bi)) { bv = x; bi = i; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(bv, o);
+        const int oi = __shfl_xor(bi, o);
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if ((threadIdx.x & 63) == 0) { s_v[threadIdx.x >> 6] = bv; s_i[threadIdx.x >> 6] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 16; ++w)
+            if (s_v[w] > bv || (s_v[w] == bv && s_i[w] < bi)) { bv = s_v[w]; bi = s_i[w]; }
+        *idx_out = bi == 0x7fffffff ? 0 : bi;
+        *val_out = bv;
+    }
+}
+
 inline int blocks_for(int n) { return (n + kBlock - 1) / kBlock; }
 
 }  // namespace
@@ -608,6 +636,13 @@ hipError_t launch_ancestors(hipStream_t stream, const int32_t* first_all, int64_
 {
     if (nslots <= 0) return hipSuccess;
     ancestors_kernel<<<blocks_for(nslots), kBlock, 0, stream>>>(first_all, n_total, slot0, nslots, anc);
+    return hipGetLastError();
+}
+
+hipError_t launch_argmax(hipStream_t stream, const float* v, int n, int32_t* idx_out, float* val_out)
+{
+    if (n <= 0) return hipSuccess;
+    argmax_kernel<<<1, 1024, 0, stream>>>(v, n, idx_out, val_out);
     return hipGetLastError();
 }
 

@@ -239,11 +239,46 @@ int slam_ancestors_dev(slam_engine *e, const int32_t *d_first_all, int64_t n_tot
  * counter (0,0,frame,1).  Pure host function (every rank computes the same value). */
 uint64_t slam_comb_offset(uint64_t seed, uint32_t frame, uint64_t total);
 
+/* Index (lowest on ties) and value of the largest element: the heaviest particle. */
+int slam_argmax_dev(slam_engine *e, const float *d_values, int n, int32_t *d_index, float *d_value);
+
 /* Plain gather of particle attributes through an index (used when the gather is not fused into the
  * next stage, and to pack rows for migration between GPUs). */
 int slam_gather_f32_dev(slam_engine *e, const float *d_src, const int32_t *d_idx, int n, float *d_dst);
 int slam_gather_map_dev(slam_engine *e, const float *d_map_in, float *d_map_out, int64_t in_plane_stride,
                         int64_t out_plane_stride, int ld_in, int ld_out, int nlandmarks, const int32_t *d_idx, int n);
+
+/* ------------------------------------------------------------------ particle-filter session
+ * Convenience object for hosts that do not manage device memory themselves (a plain C program): it owns
+ * the particle arrays, the landmark maps and the resample indices on the device and runs one whole frame
+ * per call by chaining the stage entry points above on the engine's stream — motion+score, EKF (when the
+ * filter has landmarks and `use_observations` is set), weights, integer-CDF resample; the resample gather
+ * is fused into the next frame.  Single GPU; several GPUs are driven through the stage entry points
+ * (pf.py).  The current scan (slam_scan_*), grid (slam_grid_*) and observation list (slam_obs_*) of the
+ * engine are the frame's inputs. */
+typedef struct slam_pf slam_pf;
+typedef struct {
+    int32_t n_particles;
+    int32_t n_landmarks;   /* 0 = localisation only (weights from the scan-match score alone) */
+    float sigma[3];        /* motion noise (x, y, theta) per frame */
+    float meas_var;        /* landmark observation variance */
+    float score_gain;      /* logw = loglik - score_gain * score */
+    uint64_t seed;
+} slam_pf_config;
+
+int slam_pf_create(slam_engine *e, const slam_pf_config *cfg, slam_pf **out);
+int slam_pf_destroy(slam_pf *pf);
+/* all particles at `pose`; maps (if any) marked "not seen yet" */
+int slam_pf_reset(slam_pf *pf, const float pose[3]);
+int slam_pf_set_poses_host(slam_pf *pf, const float *x, const float *y, const float *theta);
+int slam_pf_set_map_host(slam_pf *pf, const float *planes /* [5][n_landmarks][n_particles] */);
+/* one frame against grid `slot`; asynchronous */
+int slam_pf_step(slam_pf *pf, int slot, const float dp[3], int use_observations);
+/* heaviest particle of the last frame (lowest index on ties): its pose, log-weight and index; synchronises */
+int slam_pf_best(slam_pf *pf, float pose[3], float *logw, int32_t *index);
+/* current particles with the pending resample gather applied; synchronises */
+int slam_pf_get_poses_host(slam_pf *pf, float *x, float *y, float *theta);
+int slam_pf_get_map_host(slam_pf *pf, float *planes);
 
 #ifdef __cplusplus
 }

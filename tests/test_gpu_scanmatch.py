@@ -266,3 +266,30 @@ def test_unmodified_reference_program_on_the_engine(orc, tmp_path):
     assert "\n".join(poses) + "\n" == (GOLDEN / "loop_pose.txt").read_text()
     assert (tmp_path / "map.csv").read_bytes() == (GOLDEN / "loop_map.csv").read_bytes()
     print([ln for ln in r.stdout.splitlines() if ln.startswith("time taken")])
+
+
+def test_particle_filter_host_program_tracks_the_reference_trajectory(orc, tmp_path):
+    """slam_pf_main = the reference's frame loop with the lattice search replaced by a particle-filter step
+    (4096 particles).  A stochastic estimator cannot reproduce main.c bit for bit; the stated tolerance is:
+    every pose within 0.20 m (two cells of the 0.1 m grid the score is piecewise constant on) and 0.02 rad
+    of the reference's own pose log (golden parity_pose.txt) over the 1000 frames — measured 0.14 m /
+    0.010 rad — and the run is deterministic (same seed => identical output)."""
+    info = json.loads((GOLDEN / "datasets.json").read_text())["parity"]
+    csv = tmp_path / "parity.csv"
+    orc.run_tool("gen_dataset", csv, *info["gen_args"])
+    exe = PKG_DIR / "lib" / "slam_pf_main"
+    runs = []
+    for k in range(2):
+        r = subprocess.run([str(exe), str(csv), "1000", str(NB), str(tmp_path / f"map{k}.csv"), "4096", "7"], check=True,
+                           capture_output=True, text=True)
+        runs.append([ln for ln in r.stdout.splitlines() if ln.startswith("pose =")])
+        print(r.stderr.strip())
+    assert runs[0] == runs[1] and (tmp_path / "map0.csv").read_bytes() == (tmp_path / "map1.csv").read_bytes()
+    got = np.array([[float(v) for v in ln.split("=")[1].split()] for ln in runs[0]])
+    ref = np.array([[float(v) for v in ln.split("=")[1].split()] for ln in (GOLDEN / "parity_pose.txt").read_text().splitlines()])
+    assert got.shape == ref.shape == (999, 3)
+    err_xy = np.hypot(got[:, 0] - ref[:, 0], got[:, 1] - ref[:, 1])
+    err_th = np.abs(got[:, 2] - ref[:, 2])
+    print(f"PF vs reference trajectory: max |dxy| {err_xy.max():.4f} m, max |dtheta| {err_th.max():.5f} rad, "
+          f"final {err_xy[-1]:.4f} m / {err_th[-1]:.5f} rad")
+    assert err_xy.max() < 0.20 and err_th.max() < 0.02
