@@ -84,6 +84,9 @@ SIGNATURES = {
     "slam_offspring_offsets_dev": (_i, [_vp, _vp, _i, _vp, _vp, _u64, _u32, _i64, _vp]),
     "slam_ancestors_dev": (_i, [_vp, _vp, _i64, _i64, _i, _vp]),
     "slam_comb_offset": (_u64, [_u64, _u32, _u64]),
+    "slam_ancestors_sharded_dev": (_i, [_vp, _vp, _i64, _i, _i, _i, _vp]),
+    "slam_migrate_pack_dev": (_i, [_vp, _vp, _i64, _i, _i, _i, _vp, _vp, _vp, _i64, _vp, _i64, _i, _i, _vp]),
+    "slam_migrate_unpack_dev": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i64, _vp, _i64, _i, _i]),
     "slam_argmax_dev": (_i, [_vp, _vp, _i, _vp, _vp]),
     "slam_gather_f32_dev": (_i, [_vp, _vp, _vp, _i, _vp]),
     "slam_gather_map_dev": (_i, [_vp, _vp, _vp, _i64, _i64, _i, _i, _i, _vp, _i]),
@@ -321,6 +324,23 @@ class Engine:
     def ancestors_dev(self, d_first_all, n_total, slot0, nslots, d_anc):
         self._ck(self.lib.slam_ancestors_dev(self.h, _ptr(d_first_all), n_total, slot0, nslots, _ptr(d_anc)),
                  "ancestors_dev")
+
+    def ancestors_sharded_dev(self, d_first_all, n_total, n_local, rank, world, d_src):
+        self._ck(self.lib.slam_ancestors_sharded_dev(self.h, _ptr(d_first_all), n_total, n_local, rank, world,
+                                                     _ptr(d_src)), "ancestors_sharded_dev")
+
+    def migrate_pack_dev(self, d_first_all, n_total, n_local, rank, world, send_lo, send_cnt, d_pose, pose_ld, d_map,
+                         plane_stride, ld_map, nlandmarks, d_out):
+        lo, cnt = _np(send_lo, np.int64), _np(send_cnt, np.int32)
+        self._ck(self.lib.slam_migrate_pack_dev(self.h, _ptr(d_first_all), n_total, n_local, rank, world, _ptr(lo),
+                                                _ptr(cnt), _ptr(d_pose), pose_ld, _ptr(d_map), plane_stride, ld_map,
+                                                nlandmarks, _ptr(d_out)), "migrate_pack_dev")
+
+    def migrate_unpack_dev(self, d_in, world, recv_cnt, n_local, d_pose, pose_ld, d_map, plane_stride, ld_map,
+                           nlandmarks):
+        cnt = _np(recv_cnt, np.int32)
+        self._ck(self.lib.slam_migrate_unpack_dev(self.h, _ptr(d_in), world, _ptr(cnt), n_local, _ptr(d_pose), pose_ld,
+                                                  _ptr(d_map), plane_stride, ld_map, nlandmarks), "migrate_unpack_dev")
 
     def gather_f32_dev(self, d_src, d_idx, n, d_dst):
         self._ck(self.lib.slam_gather_f32_dev(self.h, _ptr(d_src), _ptr(d_idx), n, _ptr(d_dst)), "gather_f32_dev")

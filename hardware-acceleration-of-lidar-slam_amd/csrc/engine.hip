@@ -818,6 +818,66 @@ uint64_t slam_comb_offset(uint64_t seed, uint32_t frame, uint64_t total)
     return (uint64_t)(((unsigned __int128)r64 * total) >> 64);
 }
 
+static bool make_plan(MigratePlan& plan, const int64_t* lo, const int32_t* cnt, int world)
+{
+    if (world < 1 || world > kMaxRanks || !lo || !cnt) return false;
+    plan.world = world;
+    int64_t off = 0;
+    for (int q = 0; q < world; ++q) {
+        if (cnt[q] < 0 || lo[q] < 0) return false;
+        plan.lo[q] = lo[q];
+        plan.off[q] = (int32_t)off;
+        off += cnt[q];
+        if (off > 0x7fffffff) return false;
+    }
+    plan.off[world] = (int32_t)off;
+    return true;
+}
+
+int slam_ancestors_sharded_dev(slam_engine* e, const int32_t* d_first_all, int64_t n_total, int n_local, int rank,
+                               int world, int32_t* d_src)
+{
+    ENTER(e);
+    if (n_local <= 0 || world < 1 || world > kMaxRanks || rank < 0 || rank >= world ||
+        n_total != (int64_t)n_local * world || !d_first_all || !d_src)
+        return SLAM_ERR_INVALID_ARG;
+    HIP_TRY(launch_ancestors_sharded(e->stream, d_first_all, n_total, n_local, rank, world, d_src));
+    return SLAM_OK;
+}
+
+int slam_migrate_pack_dev(slam_engine* e, const int32_t* d_first_all, int64_t n_total, int n_local, int rank, int world,
+                          const int64_t* send_lo, const int32_t* send_cnt, const float* d_pose, int64_t pose_ld,
+                          const float* d_map, int64_t plane_stride, int ld_map, int nlandmarks, float* d_out)
+{
+    ENTER(e);
+    MigratePlan plan;
+    if (!make_plan(plan, send_lo, send_cnt, world) || n_local <= 0 || rank < 0 || rank >= world || nlandmarks < 0 ||
+        n_total != (int64_t)n_local * world || !d_first_all || !d_pose || (nlandmarks > 0 && !d_map))
+        return SLAM_ERR_INVALID_ARG;
+    if (plan.off[world] > 0 && !d_out) return SLAM_ERR_INVALID_ARG;
+    HIP_TRY(launch_migrate_pack(e->stream, d_first_all, n_total, n_local, rank, plan, d_pose, pose_ld, d_map,
+                                plane_stride, ld_map, nlandmarks, d_out));
+    return SLAM_OK;
+}
+
+int slam_migrate_unpack_dev(slam_engine* e, const float* d_in, int world, const int32_t* recv_cnt, int n_local,
+                            float* d_pose, int64_t pose_ld, float* d_map, int64_t plane_stride, int ld_map,
+                            int nlandmarks)
+{
+    ENTER(e);
+    MigratePlan plan;
+    int64_t zeros[kMaxRanks] = { 0 };
+    if (!make_plan(plan, zeros, recv_cnt, world) || n_local <= 0 || nlandmarks < 0 || !d_pose ||
+        (nlandmarks > 0 && !d_map))
+        return SLAM_ERR_INVALID_ARG;
+    if (plan.off[world] > 0 && !d_in) return SLAM_ERR_INVALID_ARG;
+    if ((int64_t)n_local + plan.off[world] > pose_ld || (nlandmarks > 0 && (int64_t)n_local + plan.off[world] > ld_map))
+        return SLAM_ERR_CAPACITY;
+    HIP_TRY(launch_migrate_unpack(e->stream, d_in, plan, n_local, d_pose, pose_ld, d_map, plane_stride, ld_map,
+                                  nlandmarks));
+    return SLAM_OK;
+}
+
 int slam_argmax_dev(slam_engine* e, const float* d_values, int n, int32_t* d_index, float* d_value)
 {
     ENTER(e);

@@ -95,6 +95,20 @@ hipError_t launch_offspring_offsets(hipStream_t stream, const uint64_t* cdf, int
                                     int32_t* first);
 hipError_t launch_ancestors(hipStream_t stream, const int32_t* first_all, int64_t n_total, int64_t slot0, int nslots,
                             int32_t* anc);
+// multi-GPU resample (see pf_kernels.hip): per-peer slot runs, offsets in the packed exchange buffers
+enum { kMaxRanks = 16 };
+struct MigratePlan {
+    int64_t lo[kMaxRanks];       // first global slot of the run exchanged with peer q
+    int32_t off[kMaxRanks + 1];  // running particle offset of peer q's run in the buffer (off[world] = total)
+    int32_t world;
+};
+hipError_t launch_ancestors_sharded(hipStream_t stream, const int32_t* first_all, int64_t n_total, int n, int rank,
+                                    int world, int32_t* src);
+hipError_t launch_migrate_pack(hipStream_t stream, const int32_t* first_all, int64_t n_total, int n, int rank,
+                               const MigratePlan& plan, const float* pose, int64_t pose_ld, const float* map,
+                               int64_t plane_stride, int ld, int nlandmarks, float* out);
+hipError_t launch_migrate_unpack(hipStream_t stream, const float* in, const MigratePlan& plan, int n, float* pose,
+                                 int64_t pose_ld, float* map, int64_t plane_stride, int ld, int nlandmarks);
 hipError_t launch_argmax(hipStream_t stream, const float* v, int n, int32_t* idx_out, float* val_out);
 hipError_t launch_gather_f32(hipStream_t stream, const float* src, const int32_t* idx, int n, float* dst);
 hipError_t launch_gather_map(hipStream_t stream, const float* in, float* out, int64_t in_stride, int64_t out_stride,

@@ -474,6 +474,110 @@ __global__ __launch_bounds__(kBlock) void ancestors_kernel(const int32_t* __rest
     anc[s] = (int32_t)(lo - 1);
 }
 
+// ------------------------------------------------------------------ multi-GPU resample: sharded gather index + migration
+// Slots of rank r are [r*n, (r+1)*n).  The particles of rank s fill the slot range [A_s, B_s) with
+// A_s = first_all[s*n], B_s = A_(s+1) (B of the last rank = n_total) because `first` is non-decreasing.
+// So what rank r receives from rank s is ONE contiguous run of its slots, and everything below follows
+// from the world+1 boundary values — no host-computed plan is needed for the index kernel.
+__device__ __forceinline__ int64_t first_or_total(const int32_t* __restrict__ first_all, int64_t idx, int64_t n_total)
+{
+    return idx < n_total ? (int64_t)first_all[idx] : n_total;
+}
+
+__device__ __forceinline__ int64_t last_with_first_le(const int32_t* __restrict__ first_all, int64_t n_total, int64_t j)
+{
+    int64_t lo = 0, hi = n_total;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if ((int64_t)first_all[mid] <= j) lo = mid + 1; else hi = mid;
+    }
+    return lo - 1;
+}
+
+// src[jl]: where slot r*n + jl finds its ancestor — a local particle index, or n + (position in the staging
+// tail, which holds the runs received from ranks 0..world-1 in rank order, each run in slot order).
+__global__ __launch_bounds__(kBlock) void ancestors_sharded_kernel(const int32_t* __restrict__ first_all,
+                                                                   int64_t n_total, int n, int rank, int world,
+                                                                   int32_t* __restrict__ src)
+{
+    __shared__ int64_t s_lo[kMaxRanks];    // first of my slots served by rank s
+    __shared__ int32_t s_off[kMaxRanks];   // staging offset of rank s's run
+    if (threadIdx.x == 0) {
+        const int64_t my_lo = (int64_t)rank * n, my_hi = my_lo + n;
+        int32_t off = 0;
+        for (int q = 0; q < world; ++q) {
+            const int64_t a = first_or_total(first_all, (int64_t)q * n, n_total);
+            const int64_t b = first_or_total(first_all, (int64_t)(q + 1) * n, n_total);
+            const int64_t lo = a > my_lo ? a : my_lo, hi = b < my_hi ? b : my_hi;
+            s_lo[q] = lo;
+            s_off[q] = off;
+            if (q != rank && hi > lo) off += (int32_t)(hi - lo);
+        }
+    }
+    __syncthreads();
+    const int jl = blockIdx.x * kBlock + threadIdx.x;
+    if (jl >= n) return;
+    const int64_t j = (int64_t)rank * n + jl;
+    const int64_t g = last_with_first_le(first_all, n_total, j);
+    const int owner = (int)(g / n);
+    src[jl] = owner == rank ? (int32_t)(g - (int64_t)rank * n) : n + s_off[owner] + (int32_t)(j - s_lo[owner]);
+}
+
+// Pack what the other ranks need from me into one buffer: block d (for rank d) is [3 + 5L][cnt_d] floats —
+// rows x, y, theta, then the 5 map planes landmark by landmark — for the cnt_d consecutive slots starting
+// at lo_d whose ancestors are my particles.  One launch for every destination.
+__global__ __launch_bounds__(kBlock) void migrate_pack_kernel(const int32_t* __restrict__ first_all, int64_t n_total,
+                                                              int n, int rank, MigratePlan plan,
+                                                              const float* __restrict__ pose, int64_t pose_ld,
+                                                              const float* __restrict__ map, int64_t plane_stride,
+                                                              int ld, int nlandmarks, float* __restrict__ out)
+{
+    const int p = blockIdx.x * kBlock + threadIdx.x;
+    if (p >= plan.off[plan.world]) return;
+    int d = 0;
+    while (p >= plan.off[d + 1]) ++d;
+    const int q = p - plan.off[d], cnt = plan.off[d + 1] - plan.off[d];
+    const int64_t j = plan.lo[d] + q;
+    const int loc = (int)(last_with_first_le(first_all, n_total, j) - (int64_t)rank * n);
+    const int rows = 3 + 5 * nlandmarks;
+    float* __restrict__ blk = out + (int64_t)rows * plan.off[d] + q;
+    for (int k = blockIdx.y; k < rows; k += gridDim.y) {
+        float v;
+        if (k < 3) {
+            v = pose[k * pose_ld + loc];
+        } else {
+            const int m = k - 3, pl = m / nlandmarks, l = m - pl * nlandmarks;
+            v = map[pl * plane_stride + (int64_t)l * ld + loc];
+        }
+        blk[(int64_t)k * cnt] = v;
+    }
+}
+
+// Unpack the received blocks into the staging tail behind the n local particles (position = running index
+// over sources in rank order, matching ancestors_sharded_kernel).
+__global__ __launch_bounds__(kBlock) void migrate_unpack_kernel(const float* __restrict__ in, MigratePlan plan, int n,
+                                                                float* __restrict__ pose, int64_t pose_ld,
+                                                                float* __restrict__ map, int64_t plane_stride, int ld,
+                                                                int nlandmarks)
+{
+    const int p = blockIdx.x * kBlock + threadIdx.x;
+    if (p >= plan.off[plan.world]) return;
+    int s = 0;
+    while (p >= plan.off[s + 1]) ++s;
+    const int q = p - plan.off[s], cnt = plan.off[s + 1] - plan.off[s];
+    const int rows = 3 + 5 * nlandmarks;
+    const float* __restrict__ blk = in + (int64_t)rows * plan.off[s] + q;
+    for (int k = blockIdx.y; k < rows; k += gridDim.y) {
+        const float v = blk[(int64_t)k * cnt];
+        if (k < 3) {
+            pose[k * pose_ld + n + p] = v;
+        } else {
+            const int m = k - 3, pl = m / nlandmarks, l = m - pl * nlandmarks;
+            map[pl * plane_stride + (int64_t)l * ld + n + p] = v;
+        }
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void gather_f32_kernel(const float* __restrict__ src,
                                                             const int32_t* __restrict__ idx, int n,
                                                             float* __restrict__ dst)
@@ -636,6 +740,37 @@ hipError_t launch_ancestors(hipStream_t stream, const int32_t* first_all, int64_
 {
     if (nslots <= 0) return hipSuccess;
     ancestors_kernel<<<blocks_for(nslots), kBlock, 0, stream>>>(first_all, n_total, slot0, nslots, anc);
+    return hipGetLastError();
+}
+
+hipError_t launch_ancestors_sharded(hipStream_t stream, const int32_t* first_all, int64_t n_total, int n, int rank,
+                                    int world, int32_t* src)
+{
+    if (n <= 0) return hipSuccess;
+    ancestors_sharded_kernel<<<blocks_for(n), kBlock, 0, stream>>>(first_all, n_total, n, rank, world, src);
+    return hipGetLastError();
+}
+
+hipError_t launch_migrate_pack(hipStream_t stream, const int32_t* first_all, int64_t n_total, int n, int rank,
+                               const MigratePlan& plan, const float* pose, int64_t pose_ld, const float* map,
+                               int64_t plane_stride, int ld, int nlandmarks, float* out)
+{
+    const int total = plan.off[plan.world];
+    if (total <= 0) return hipSuccess;
+    const int rows = 3 + 5 * nlandmarks;
+    migrate_pack_kernel<<<dim3(blocks_for(total), rows < 512 ? rows : 512), kBlock, 0, stream>>>(
+        first_all, n_total, n, rank, plan, pose, pose_ld, map, plane_stride, ld, nlandmarks, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_migrate_unpack(hipStream_t stream, const float* in, const MigratePlan& plan, int n, float* pose,
+                                 int64_t pose_ld, float* map, int64_t plane_stride, int ld, int nlandmarks)
+{
+    const int total = plan.off[plan.world];
+    if (total <= 0) return hipSuccess;
+    const int rows = 3 + 5 * nlandmarks;
+    migrate_unpack_kernel<<<dim3(blocks_for(total), rows < 512 ? rows : 512), kBlock, 0, stream>>>(
+        in, plan, n, pose, pose_ld, map, plane_stride, ld, nlandmarks);
     return hipGetLastError();
 }
 

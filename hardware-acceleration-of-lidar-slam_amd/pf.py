@@ -79,6 +79,17 @@ class HipOps:
     def ancestors(self, first_all, n_total, slot0, nslots, anc):
         self.e.ancestors_dev(first_all, n_total, slot0, nslots, anc)
 
+    def ancestors_sharded(self, first_all, n_total, n_local, rank, world, src):
+        self.e.ancestors_sharded_dev(first_all, n_total, n_local, rank, world, src)
+
+    def migrate_pack(self, first_all, n_total, n_local, rank, world, send_lo, send_cnt, pose, pose_ld, mp, plane_stride,
+                     ld, nlandmarks, out):
+        self.e.migrate_pack_dev(first_all, n_total, n_local, rank, world, send_lo, send_cnt, pose, pose_ld, mp,
+                                plane_stride, ld, nlandmarks, out)
+
+    def migrate_unpack(self, inp, world, recv_cnt, n_local, pose, pose_ld, mp, plane_stride, ld, nlandmarks):
+        self.e.migrate_unpack_dev(inp, world, recv_cnt, n_local, pose, pose_ld, mp, plane_stride, ld, nlandmarks)
+
     def gather_f32(self, src, idx, n, dst):
         self.e.gather_f32_dev(src, idx, n, dst)
 
@@ -214,17 +225,18 @@ class ParticleFilter:
         else:
             d_base, d_total = None, None
         o.offspring_from_scan(n, d_base, d_total, self.seed, self.frame, self.n_total, self.first)
-        if self.world > 1:
-            self._all_gather(self.first_all, self.first)
         anc = self.anc[nxt]
-        o.ancestors(self.first_all, self.n_total, self.rank * n, n, anc)
-        # 6. particles whose ancestor lives on another GPU
         self.cur = nxt
-        if self.world == 1:
-            self.src_idx = anc
+        if not multi:
+            o.ancestors(self.first, self.n_total, 0, n, anc)
             self.migrated_last = 0
         else:
-            self.src_idx = self._migrate(anc)
+            # 6. particles whose ancestor lives on another GPU.  The gather index needs nothing from the host;
+            # only the split sizes of the all-to-all do (world+1 boundary values: one tiny device->host read).
+            self._all_gather(self.first_all, self.first)
+            o.ancestors_sharded(self.first_all, self.n_total, n, self.rank, self.world, anc)
+            self._migrate()
+        self.src_idx = anc
         self.frame += 1
 
     # ------------------------------------------------------------------ multi-GPU exchange
@@ -232,66 +244,39 @@ class ParticleFilter:
         """Slot ranges [A_s, B_s) filled by the particles of rank s: A_s = first_all[s*n]."""
         n, G = self.n, self.world
         sel = torch.arange(G, device=self.device) * n
-        bounds = self.first_all[sel].cpu().tolist() + [self.n_total]   # one small device->host sync per frame
+        bounds = self.first_all[sel].cpu().tolist() + [self.n_total]   # the one device->host sync of a frame
         r = self.rank
         send = [(max(bounds[r], d * n), min(bounds[r + 1], (d + 1) * n)) for d in range(G)]
         recv = [(max(bounds[s], r * n), min(bounds[s + 1], (r + 1) * n)) for s in range(G)]
         send = [(lo, hi) if hi > lo and d != r else (0, 0) for d, (lo, hi) in enumerate(send)]
         recv = [(lo, hi) if hi > lo and s != r else (0, 0) for s, (lo, hi) in enumerate(recv)]
-        return send, recv
+        # every rank sees the same boundaries, so all ranks agree on whether anything moves at all
+        anything = any(bounds[s] != s * n for s in range(1, G))
+        return send, recv, anything
 
-    def _migrate(self, anc):
-        o, n, r, G, dv = self.ops, self.n, self.rank, self.world, self.device
-        send, recv = self._plan()
+    def _migrate(self):
+        """pack (one launch) -> one all-to-all carrying poses and map rows -> unpack (one launch) into the
+        staging tail of the current buffers, where the next frame's fused gathers pick them up."""
+        o, n, r, G, dv, L = self.ops, self.n, self.rank, self.world, self.device, self.L
+        send, recv, anything = self._plan()
+        if not anything:   # every run boundary coincides with a rank boundary: no collective needed this frame
+            self.migrated_last = 0
+            return
         scnt = [hi - lo for lo, hi in send]
         rcnt = [hi - lo for lo, hi in recv]
         stot, rtot = sum(scnt), sum(rcnt)
         if rtot > self.recv_cap:
             raise RuntimeError(f"rank {r}: {rtot} particles to receive exceed recv_capacity {self.recv_cap}")
         self.migrated_last = rtot
-        pose, L = self.pose[self.cur], self.L
-        # pack: per destination a block [x | y | theta] (and [5][L][cnt] map rows)
-        sbuf = torch.empty(3 * stot, dtype=torch.float32, device=dv)
-        rbuf = torch.empty(3 * rtot, dtype=torch.float32, device=dv)
-        smap = torch.empty(5 * L * stot, dtype=torch.float32, device=dv) if L else None
-        rmap = torch.empty(5 * L * rtot, dtype=torch.float32, device=dv) if L else None
-        idx = torch.empty(stot, dtype=torch.int32, device=dv)
-        off = 0
-        for d, (lo, hi) in enumerate(send):
-            c = hi - lo
-            if c == 0:
-                continue
-            seg = idx[off: off + c]
-            o.ancestors(self.first_all, self.n_total, lo, c, seg)   # global ids, all inside my particle range
-            seg -= r * n
-            for k in range(3):
-                o.gather_f32(pose[k], seg, c, sbuf[3 * off + k * c: 3 * off + (k + 1) * c])
-            if L:
-                o.gather_map(self.map[self.cur], smap[5 * L * off:], L * self.cap, L * c, self.cap, c, L, seg, c)
-            off += c
-        self._all_to_all(rbuf, sbuf, [3 * c for c in rcnt], [3 * c for c in scnt])
-        if L:
-            self._all_to_all(rmap, smap, [5 * L * c for c in rcnt], [5 * L * c for c in scnt])
-        # unpack into the staging region behind the local particles, build the local gather index
-        lo_t = torch.zeros(G, dtype=torch.int64, device=dv)
-        off_t = torch.zeros(G, dtype=torch.int64, device=dv)
-        off = 0
-        for s, (lo, hi) in enumerate(recv):
-            c = hi - lo
-            if c == 0:
-                continue
-            blk = rbuf[3 * off: 3 * (off + c)].view(3, c)
-            pose[:, n + off: n + off + c] = blk
-            if L:
-                self.map[self.cur][:, :, n + off: n + off + c] = rmap[5 * L * off: 5 * L * (off + c)].view(5, L, c)
-            lo_t[s], off_t[s] = lo, off
-            off += c
-        a64 = anc.long()
-        owner = torch.div(a64, n, rounding_mode="floor")
-        slot = torch.arange(r * n, (r + 1) * n, dtype=torch.int64, device=dv)
-        remote = n + off_t[owner] + (slot - lo_t[owner])
-        src = torch.where(owner == r, a64 - r * n, remote).to(torch.int32)
-        return src
+        rows = 3 + 5 * L
+        sbuf = torch.empty(rows * stot, dtype=torch.float32, device=dv)
+        rbuf = torch.empty(rows * rtot, dtype=torch.float32, device=dv)
+        pose = self.pose[self.cur]
+        mp = self.map[self.cur] if L else None
+        o.migrate_pack(self.first_all, self.n_total, n, r, G, [lo for lo, _ in send], scnt, pose, self.cap, mp,
+                       L * self.cap, self.cap, L, sbuf)
+        self._all_to_all(rbuf, sbuf, [rows * c for c in rcnt], [rows * c for c in scnt])
+        o.migrate_unpack(rbuf, G, rcnt, n, pose, self.cap, mp, L * self.cap, self.cap, L)
 
     # ------------------------------------------------------------------ estimate
     def best_particle(self):

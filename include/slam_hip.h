@@ -239,6 +239,28 @@ int slam_ancestors_dev(slam_engine *e, const int32_t *d_first_all, int64_t n_tot
  * counter (0,0,frame,1).  Pure host function (every rank computes the same value). */
 uint64_t slam_comb_offset(uint64_t seed, uint32_t frame, uint64_t total);
 
+/* Several GPUs (one engine per rank; n_total = world * n_local particles; world <= 16).  After the `first`
+ * arrays of all ranks were all-gathered into d_first_all:
+ *  - slam_ancestors_sharded_dev: the gather index of this rank's n_local slots — a local particle index when
+ *    the ancestor is local, else n_local + its position in the staging tail behind the local particles,
+ *    which holds the runs received from ranks 0..world-1 in rank order (the particles of rank s fill one
+ *    contiguous slot run because `first` is sorted).  Needs nothing from the host.
+ *  - slam_migrate_pack_dev: one launch packs, for every destination q, the send_cnt[q] consecutive slots
+ *    starting at global slot send_lo[q] (host arrays of `world` entries, 0 for this rank itself) whose
+ *    ancestors are this rank's particles, as block q = [3 + 5*nlandmarks][send_cnt[q]] floats (x, y, theta,
+ *    then the five map planes landmark by landmark) — the layout of one all-to-all send buffer.
+ *  - slam_migrate_unpack_dev: the received blocks (recv_cnt[q] particles from rank q, same block layout)
+ *    into the staging tail of the pose arrays (leading dimension pose_ld, rows x|y|theta) and map planes. */
+int slam_ancestors_sharded_dev(slam_engine *e, const int32_t *d_first_all, int64_t n_total, int n_local, int rank,
+                               int world, int32_t *d_src);
+int slam_migrate_pack_dev(slam_engine *e, const int32_t *d_first_all, int64_t n_total, int n_local, int rank,
+                          int world, const int64_t *send_lo, const int32_t *send_cnt, const float *d_pose,
+                          int64_t pose_ld, const float *d_map, int64_t plane_stride, int ld_map, int nlandmarks,
+                          float *d_out);
+int slam_migrate_unpack_dev(slam_engine *e, const float *d_in, int world, const int32_t *recv_cnt, int n_local,
+                            float *d_pose, int64_t pose_ld, float *d_map, int64_t plane_stride, int ld_map,
+                            int nlandmarks);
+
 /* Index (lowest on ties) and value of the largest element: the heaviest particle. */
 int slam_argmax_dev(slam_engine *e, const float *d_values, int n, int32_t *d_index, float *d_value);
 

@@ -88,6 +88,48 @@ class OracleOps:
     def ancestors(self, first_all, n_total, slot0, nslots, anc):
         anc[:nslots] = torch.from_numpy(oracle.ancestors(_np(first_all)[:n_total], slot0, nslots))
 
+    def ancestors_sharded(self, first_all, n_total, n_local, rank, world, src):
+        fa = _np(first_all)[:n_total].astype(np.int64)
+        bounds = [int(fa[q * n_local]) for q in range(world)] + [n_total]
+        lo_me, hi_me = rank * n_local, (rank + 1) * n_local
+        lo, off, run = [], [], 0
+        for q in range(world):
+            a, b = max(bounds[q], lo_me), min(bounds[q + 1], hi_me)
+            lo.append(a); off.append(run)
+            if q != rank and b > a:
+                run += b - a
+        g = oracle.ancestors(_np(first_all)[:n_total], lo_me, n_local).astype(np.int64)
+        owner = g // n_local
+        j = np.arange(lo_me, hi_me, dtype=np.int64)
+        out = np.where(owner == rank, g - lo_me, n_local + np.array(off)[owner] + (j - np.array(lo)[owner]))
+        src[:n_local] = torch.from_numpy(out.astype(np.int32))
+
+    def migrate_pack(self, first_all, n_total, n_local, rank, world, send_lo, send_cnt, pose, pose_ld, mp, plane_stride,
+                     ld, nlandmarks, out):
+        rows, off = 3 + 5 * nlandmarks, 0
+        for d in range(world):
+            c = send_cnt[d]
+            if not c:
+                continue
+            loc = torch.from_numpy((oracle.ancestors(_np(first_all)[:n_total], send_lo[d], c) - rank * n_local).astype(np.int64))
+            blk = out[rows * off: rows * (off + c)].view(rows, c)
+            blk[:3] = pose[:, loc]
+            if nlandmarks:
+                blk[3:] = mp[:, :, loc].reshape(5 * nlandmarks, c)
+            off += c
+
+    def migrate_unpack(self, inp, world, recv_cnt, n_local, pose, pose_ld, mp, plane_stride, ld, nlandmarks):
+        rows, off = 3 + 5 * nlandmarks, 0
+        for s in range(world):
+            c = recv_cnt[s]
+            if not c:
+                continue
+            blk = inp[rows * off: rows * (off + c)].view(rows, c)
+            pose[:, n_local + off: n_local + off + c] = blk[:3]
+            if nlandmarks:
+                mp[:, :, n_local + off: n_local + off + c] = blk[3:].view(5, nlandmarks, c)
+            off += c
+
     def gather_f32(self, src, idx, n, dst):
         dst[:n] = src[idx[:n].long()]
 
