@@ -36,6 +36,9 @@ constexpr int kScoreBlock = 256;
 //         rounding.  4x the wavefronts and 4x the gathers in flight: 1.5x faster at 64k poses, where
 //         LPP 1 has a single wave per SIMD and is latency-bound; slower beyond ~128k poses (each wave
 //         gather then touches 4 beam neighbourhoods instead of 1).
+constexpr int kQuadDepth = 8;   // gathers in flight per lane in the 4-lanes-per-pose form (measured: 43 -> 39 us
+                                // at 64k poses x 360 beams, 84 -> 47 us at 16k x 1079)
+
 template <int CTRL>
 __device__ __forceinline__ float quad_bcast(float v)
 {
@@ -55,8 +58,9 @@ __global__ __launch_bounds__(kScoreBlock) void score_poses_kernel(ScoreGrid g, c
                                                                    MotionParams mpar)
 {
     extern __shared__ float2 s_beam[];
-    // beams padded to a multiple of LPP with NaN: a NaN beam is out of bounds and contributes +0
-    const int nb_pad = (nbeams + LPP - 1) / LPP * LPP;
+    // beams padded with NaN to a whole number of pipeline rounds: a NaN beam is out of bounds and adds +0
+    constexpr int kRound = LPP * kQuadDepth;
+    const int nb_pad = LPP == 1 ? nbeams : (nbeams + kRound - 1) / kRound * kRound;
     for (int b = threadIdx.x; b < nb_pad; b += kScoreBlock)
         s_beam[b] = b < nbeams ? make_float2(bx[b] * g.ipix, by[b] * g.ipix)
                                : make_float2(__builtin_nanf(""), __builtin_nanf(""));
@@ -115,9 +119,26 @@ __global__ __launch_bounds__(kScoreBlock) void score_poses_kernel(ScoreGrid g, c
 #pragma unroll UNROLL
         for (int b = 0; b < nbeams; ++b) total = total + beam(b);
     } else {
-        for (int b = sub; b < nb_pad; b += LPP) {
-            const float h = beam(b);
-            // beams 4j, 4j+1, 4j+2, 4j+3 in order, identically in all four lanes of the quad
+        // software pipeline: kQuadDepth gathers stay in flight per lane; the hit of step s is summed while
+        // the loads of steps s+1 .. s+kQuadDepth are outstanding (hipcc alone waits vmcnt(0) every step)
+        float hq[kQuadDepth];
+#pragma unroll
+        for (int k = 0; k < kQuadDepth; ++k) hq[k] = beam(sub + LPP * k);
+        for (int b0 = kRound; b0 < nb_pad; b0 += kRound) {
+#pragma unroll
+            for (int k = 0; k < kQuadDepth; ++k) {
+                const float h = hq[k];
+                hq[k] = beam(sub + b0 + LPP * k);
+                // beams 4j, 4j+1, 4j+2, 4j+3 in order, identically in all four lanes of the quad
+                total = total + quad_bcast<0x00>(h);
+                total = total + quad_bcast<0x55>(h);
+                total = total + quad_bcast<0xAA>(h);
+                total = total + quad_bcast<0xFF>(h);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < kQuadDepth; ++k) {
+            const float h = hq[k];
             total = total + quad_bcast<0x00>(h);
             total = total + quad_bcast<0x55>(h);
             total = total + quad_bcast<0xAA>(h);
@@ -264,7 +285,7 @@ hipError_t launch_score_any(hipStream_t stream, const ScoreGrid& g, const float*
     const bool quad = nposes < kQuadMaxPoses;
     const long threads = quad ? 4L * nposes : nposes;
     const int blocks = (int)((threads + kScoreBlock - 1) / kScoreBlock);
-    const size_t lds = sizeof(float2) * (size_t)(nbeams + 4);
+    const size_t lds = sizeof(float2) * (size_t)(nbeams + 4 * kQuadDepth);
     if (ev) (void)hipEventRecord(ev->start, stream);
 #define SLAM_LAUNCH_SCORE(CS, LPP, UNR)                                                                              \
     score_poses_kernel<CS, LPP, UNR, MOTION><<<blocks, kScoreBlock, lds, stream>>>(g, bx, by, nbeams, x, y, th_or_ct, \

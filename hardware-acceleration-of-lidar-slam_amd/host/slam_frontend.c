@@ -36,6 +36,37 @@ int fe_read_frame(FILE *f, fe_scan *s)
     return ok;
 }
 
+static const char k_magic[8] = { 'S', 'L', 'A', 'M', 'S', 'C', 'A', 'N' };
+
+int fe_bin_open(FILE *f, int *nbeams)
+{
+    char magic[8];
+    uint32_t hdr[2];
+    const long at = ftell(f);
+    if (fread(magic, 1, 8, f) == 8 && memcmp(magic, k_magic, 8) == 0 && fread(hdr, 4, 2, f) == 2 && hdr[0] == 1) {
+        *nbeams = (int)hdr[1];
+        return 0;
+    }
+    if (at >= 0) fseek(f, at, SEEK_SET);   /* not a binary stream: leave it where it was (text CSV) */
+    return -1;
+}
+
+int fe_read_frame_bin(FILE *f, fe_scan *s)
+{
+    return (int)fread(s->range, sizeof(float), (size_t)s->nbeams, f);
+}
+
+int fe_bin_write_header(FILE *f, int nbeams)
+{
+    const uint32_t hdr[2] = { 1u, (uint32_t)nbeams };
+    return fwrite(k_magic, 1, 8, f) == 8 && fwrite(hdr, 4, 2, f) == 2 ? 0 : -1;
+}
+
+int fe_bin_write_frame(FILE *f, const fe_scan *s)
+{
+    return fwrite(s->range, sizeof(float), (size_t)s->nbeams, f) == (size_t)s->nbeams ? 0 : -1;
+}
+
 void fe_clean(fe_scan *s, float range_min, int usable_range)
 {
     /* main.c:77-94: both comparisons false keeps the beam (so NaN survives) */

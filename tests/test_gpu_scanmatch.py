@@ -248,6 +248,23 @@ def test_slam_main_matches_reference_logs(orc, tmp_path, name, frames):
     print(r.stderr.strip())
 
 
+def test_binary_scan_frames_give_identical_results(orc, tmp_path):
+    """the binary scan-frame stream carries exactly the floats the CSV parser yields, so
+    slam_main's pose log and map are byte-identical to the CSV run (and to the reference), only faster."""
+    info = json.loads((GOLDEN / "datasets.json").read_text())["parity"]
+    csv, binf = tmp_path / "parity.csv", tmp_path / "parity.bin"
+    orc.run_tool("gen_dataset", csv, *info["gen_args"])
+    exe = PKG_DIR / "lib" / "slam_main"
+    subprocess.run([str(exe), "--to-binary", str(csv), "1000", str(NB), str(binf)], check=True)
+    assert binf.stat().st_size == 16 + 1000 * NB * 4
+    r = subprocess.run([str(exe), str(binf), "1000", str(NB), str(tmp_path / "map.csv")], check=True, capture_output=True,
+                       text=True)
+    poses = [ln for ln in r.stdout.splitlines() if ln.startswith("pose =")]
+    assert "\n".join(poses) + "\n" == (GOLDEN / "parity_pose.txt").read_text()
+    assert (tmp_path / "map.csv").read_bytes() == (GOLDEN / "parity_map.csv").read_bytes()
+    print("binary ingest:", r.stderr.strip())
+
+
 def test_unmodified_reference_program_on_the_engine(orc, tmp_path):
     """oracle/_ref/main_accel_dropin = the reference's own main_accelerated.c object (built in the build
     container, hot symbols weakened) linked with host/ref_compat.c + libslam_hip.so: the reference's
