@@ -80,6 +80,7 @@ SIGNATURES = {
     "slam_quantise_weights_dev": (_i, [_vp, _vp, _vp, _i, _vp, _vp]),
     "slam_quantise_scan_dev": (_i, [_vp, _vp, _vp, _i, _vp]),
     "slam_offspring_from_scan_dev": (_i, [_vp, _i, _vp, _vp, _u64, _u32, _i64, _vp]),
+    "slam_offspring_from_scan_sharded_dev": (_i, [_vp, _i, _vp, _i, _i, _u64, _u32, _i64, _vp]),
     "slam_prefix_sum_dev": (_i, [_vp, _vp, _i, _vp]),
     "slam_offspring_offsets_dev": (_i, [_vp, _vp, _i, _vp, _vp, _u64, _u32, _i64, _vp]),
     "slam_ancestors_dev": (_i, [_vp, _vp, _i64, _i64, _i, _vp]),
@@ -313,6 +314,10 @@ class Engine:
     def offspring_from_scan_dev(self, n, d_base, d_total, seed, frame, n_total, d_first):
         self._ck(self.lib.slam_offspring_from_scan_dev(self.h, n, _ptr(d_base), _ptr(d_total), seed, frame, n_total,
                                                        _ptr(d_first)), "offspring_from_scan_dev")
+
+    def offspring_from_scan_sharded_dev(self, n, d_shard_totals, rank, world, seed, frame, n_total, d_first):
+        self._ck(self.lib.slam_offspring_from_scan_sharded_dev(self.h, n, _ptr(d_shard_totals), rank, world, seed, frame,
+                                                               n_total, _ptr(d_first)), "offspring_from_scan_sharded_dev")
 
     def prefix_sum_dev(self, d_wq, n, d_cdf):
         self._ck(self.lib.slam_prefix_sum_dev(self.h, _ptr(d_wq), n, _ptr(d_cdf)), "prefix_sum_dev")

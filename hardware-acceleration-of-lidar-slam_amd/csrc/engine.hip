@@ -766,7 +766,22 @@ int slam_offspring_from_scan_dev(slam_engine* e, int n, const uint64_t* d_base, 
     if (n <= 0 || n_total < n || n_total > 0x7fffffff || !d_first) return SLAM_ERR_INVALID_ARG;
     if (e->scan_n != n) return SLAM_ERR_NOT_READY;
     const uint64_t* cdf = e->scan_state.as<uint64_t>();
-    HIP_TRY(launch_offspring_from_scan(e->stream, cdf, cdf + n, n, d_base, d_total, seed, frame, n_total, d_first));
+    HIP_TRY(launch_offspring_from_scan(e->stream, cdf, cdf + n, n, d_base, d_total, nullptr, 0, 1, seed, frame, n_total,
+                                       d_first));
+    return SLAM_OK;
+}
+
+int slam_offspring_from_scan_sharded_dev(slam_engine* e, int n, const uint64_t* d_shard_totals, int rank, int world,
+                                         uint64_t seed, uint32_t frame, int64_t n_total, int32_t* d_first)
+{
+    ENTER(e);
+    if (n <= 0 || world < 1 || world > kMaxRanks || rank < 0 || rank >= world || n_total != (int64_t)n * world ||
+        n_total > 0x7fffffff || !d_shard_totals || !d_first)
+        return SLAM_ERR_INVALID_ARG;
+    if (e->scan_n != n) return SLAM_ERR_NOT_READY;
+    const uint64_t* cdf = e->scan_state.as<uint64_t>();
+    HIP_TRY(launch_offspring_from_scan(e->stream, cdf, cdf + n, n, nullptr, nullptr, d_shard_totals, rank, world, seed,
+                                       frame, n_total, d_first));
     return SLAM_OK;
 }
 

@@ -86,8 +86,9 @@ hipError_t launch_quantise_weights(hipStream_t stream, const float* logw, const 
 hipError_t launch_quantise_scan(hipStream_t stream, const float* logw, const float* d_max, const float* block_max,
                                 int nblock_max, int n, uint64_t* cdf_local, uint64_t* tile_total, uint64_t* d_sum);
 hipError_t launch_offspring_from_scan(hipStream_t stream, const uint64_t* cdf_local, const uint64_t* tile_total, int n,
-                                      const uint64_t* d_base, const uint64_t* d_total, uint64_t seed, uint32_t frame,
-                                      int64_t n_total, int32_t* first);
+                                      const uint64_t* d_base, const uint64_t* d_total, const uint64_t* d_shard_totals,
+                                      int rank, int world, uint64_t seed, uint32_t frame, int64_t n_total,
+                                      int32_t* first);
 hipError_t launch_prefix_sum(hipStream_t stream, const uint64_t* in, int n, uint64_t* out, uint64_t* block_scratch);
 int prefix_sum_scratch_elems(int n);
 hipError_t launch_offspring_offsets(hipStream_t stream, const uint64_t* cdf, int n, const uint64_t* d_base,

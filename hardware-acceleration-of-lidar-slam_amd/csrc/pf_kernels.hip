@@ -440,8 +440,10 @@ __global__ __launch_bounds__(kBlock) void offspring_from_scan_kernel(const uint6
                                                                      int ntiles, int n,
                                                                      const uint64_t* __restrict__ d_base,
                                                                      const uint64_t* __restrict__ d_total,
-                                                                     uint32_t key0, uint32_t key1, uint32_t frame,
-                                                                     uint64_t n_total, int32_t* __restrict__ first)
+                                                                     const uint64_t* __restrict__ d_shard_totals,
+                                                                     int rank, int world, uint32_t key0,
+                                                                     uint32_t key1, uint32_t frame, uint64_t n_total,
+                                                                     int32_t* __restrict__ first)
 {
     __shared__ uint64_t s_red[kBlock / 64];
     const int i = blockIdx.x * kBlock + threadIdx.x;
@@ -453,9 +455,20 @@ __global__ __launch_bounds__(kBlock) void offspring_from_scan_kernel(const uint6
         before += t < tile ? v : 0ull;
     }
     before = block_sum_u64(before, s_red);
-    const uint64_t total = d_total ? *d_total : block_sum_u64(all, s_red);
+    uint64_t total, shard_base = d_base ? *d_base : 0ull;
+    if (d_shard_totals) {   // several GPUs: the all-gathered shard totals give both the base and the grand total
+        total = 0;
+        shard_base = 0;
+        for (int q = 0; q < world; ++q) {
+            const uint64_t v = d_shard_totals[q];
+            total += v;
+            shard_base += q < rank ? v : 0ull;
+        }
+    } else {
+        total = d_total ? *d_total : block_sum_u64(all, s_red);
+    }
     if (i >= n) return;
-    const uint64_t base = (d_base ? *d_base : 0ull) + before;
+    const uint64_t base = shard_base + before;
     const uint64_t c_excl = base + ((i % kScanTile) ? cdf_local[i - 1] : 0ull);
     first[i] = comb_first(c_excl, total, n_total, key0, key1, frame);
 }
@@ -713,14 +726,16 @@ hipError_t launch_quantise_scan(hipStream_t stream, const float* logw, const flo
 }
 
 hipError_t launch_offspring_from_scan(hipStream_t stream, const uint64_t* cdf_local, const uint64_t* tile_total, int n,
-                                      const uint64_t* d_base, const uint64_t* d_total, uint64_t seed, uint32_t frame,
-                                      int64_t n_total, int32_t* first)
+                                      const uint64_t* d_base, const uint64_t* d_total, const uint64_t* d_shard_totals,
+                                      int rank, int world, uint64_t seed, uint32_t frame, int64_t n_total,
+                                      int32_t* first)
 {
     if (n <= 0) return hipSuccess;
     const int ntiles = (n + kScanTile - 1) / kScanTile;
     offspring_from_scan_kernel<<<blocks_for(n), kBlock, 0, stream>>>(cdf_local, tile_total, ntiles, n, d_base, d_total,
-                                                                     (uint32_t)seed, (uint32_t)(seed >> 32), frame,
-                                                                     (uint64_t)n_total, first);
+                                                                     d_shard_totals, rank, world, (uint32_t)seed,
+                                                                     (uint32_t)(seed >> 32), frame, (uint64_t)n_total,
+                                                                     first);
     return hipGetLastError();
 }
 

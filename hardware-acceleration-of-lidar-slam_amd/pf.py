@@ -73,6 +73,9 @@ class HipOps:
     def offspring_from_scan(self, n, d_base, d_total, seed, frame, n_total, first):
         self.e.offspring_from_scan_dev(n, d_base, d_total, seed, frame, n_total, first)
 
+    def offspring_from_scan_sharded(self, n, totals, rank, world, seed, frame, n_total, first):
+        self.e.offspring_from_scan_sharded_dev(n, totals, rank, world, seed, frame, n_total, first)
+
     def offspring_offsets(self, cdf, n, d_base, d_total, seed, frame, n_total, first):
         self.e.offspring_offsets_dev(cdf, n, d_base, d_total, seed, frame, n_total, first)
 
@@ -128,9 +131,8 @@ class ParticleFilter:
         self.anc = torch.zeros((2, self.n), dtype=i32, device=dv)                # double-buffered: the fused gathers
         self.d_max = torch.zeros(1, dtype=f32, device=dv)                         # of frame t+1 read frame t's indices
         self.d_sum = torch.zeros(1, dtype=i64, device=dv)
-        self.d_base = torch.zeros(1, dtype=i64, device=dv)
-        self.d_total = torch.zeros(1, dtype=i64, device=dv)
         self.totals = torch.zeros(world, dtype=i64, device=dv)
+        self._bound_sel = (torch.arange(world, device=dv) * self.n).long()   # first_all[q*n]: start of rank q's slot run
         self.frame = 0
         self.migrated_last = 0
         # gloo cannot move GPU tensors for every collective used here: stage them through the host then
@@ -219,12 +221,10 @@ class ParticleFilter:
         # 5. resample on the integer CDF
         if multi:
             self._all_gather(self.totals, self.d_sum)
-            self.d_base.copy_(self.totals[: self.rank].sum().reshape(1))
-            self.d_total.copy_(self.totals.sum().reshape(1))
-            d_base, d_total = self.d_base, self.d_total
+            o.offspring_from_scan_sharded(n, self.totals, self.rank, self.world, self.seed, self.frame, self.n_total,
+                                          self.first)
         else:
-            d_base, d_total = None, None
-        o.offspring_from_scan(n, d_base, d_total, self.seed, self.frame, self.n_total, self.first)
+            o.offspring_from_scan(n, None, None, self.seed, self.frame, self.n_total, self.first)
         anc = self.anc[nxt]
         self.cur = nxt
         if not multi:
@@ -243,8 +243,7 @@ class ParticleFilter:
     def _plan(self):
         """Slot ranges [A_s, B_s) filled by the particles of rank s: A_s = first_all[s*n]."""
         n, G = self.n, self.world
-        sel = torch.arange(G, device=self.device) * n
-        bounds = self.first_all[sel].cpu().tolist() + [self.n_total]   # the one device->host sync of a frame
+        bounds = self.first_all[self._bound_sel].cpu().tolist() + [self.n_total]   # the one device->host sync of a frame
         r = self.rank
         send = [(max(bounds[r], d * n), min(bounds[r + 1], (d + 1) * n)) for d in range(G)]
         recv = [(max(bounds[s], r * n), min(bounds[s + 1], (r + 1) * n)) for s in range(G)]

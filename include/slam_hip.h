@@ -219,6 +219,10 @@ int slam_quantise_scan_dev(slam_engine *e, const float *d_logw, const float *d_m
  * single GPU (the grand total is then the shard total, derived inside the kernel). */
 int slam_offspring_from_scan_dev(slam_engine *e, int n, const uint64_t *d_base, const uint64_t *d_total,
                                  uint64_t seed, uint32_t frame, int64_t n_total, int32_t *d_first);
+/* Several GPUs: base offset and grand total derived inside the kernel from the all-gathered shard totals
+ * (d_shard_totals[world], what slam_quantise_scan_dev wrote to d_sum on every rank). */
+int slam_offspring_from_scan_sharded_dev(slam_engine *e, int n, const uint64_t *d_shard_totals, int rank, int world,
+                                         uint64_t seed, uint32_t frame, int64_t n_total, int32_t *d_first);
 
 /* A12: systematic resampling on the exact integer CDF.
  *  step 1 (per shard): d_cdf[i] = inclusive prefix sum of wq within the shard.

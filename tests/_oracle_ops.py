@@ -79,6 +79,12 @@ class OracleOps:
         u = oracle.comb_offset(seed, frame, total)
         first[:n] = torch.from_numpy(oracle.offspring_offsets(self._cdf, base, total, u, n_total))
 
+    def offspring_from_scan_sharded(self, n, totals, rank, world, seed, frame, n_total, first):
+        t = [int(v) for v in totals.tolist()]
+        base, total = sum(t[:rank]), sum(t)
+        u = oracle.comb_offset(seed, frame, total)
+        first[:n] = torch.from_numpy(oracle.offspring_offsets(self._cdf, base, total, u, n_total))
+
     def offspring_offsets(self, cdf, n, d_base, d_total, seed, frame, n_total, first):
         base = int(d_base[0]) if d_base is not None else 0
         total = int(d_total[0])
