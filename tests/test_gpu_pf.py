@@ -344,9 +344,9 @@ def test_full_filter_matches_oracle_over_frames(eng, orc):
     assert gpu.best_particle() == cpu.best_particle()
 
 
-@pytest.mark.parametrize("L", [6, 0])
-def test_two_ranks_on_one_card_equal_unsharded_oracle(orc, tmp_path, L):
-    """The multi-GPU path with the real HIP stages: two processes share this GPU, exchange through gloo
+@pytest.mark.parametrize("L,world", [(6, 2), (0, 2), (6, 4)])
+def test_ranks_on_one_card_equal_unsharded_oracle(orc, tmp_path, L, world):
+    """The multi-GPU path with the real HIP stages: 2 or 4 processes share this GPU, exchange through gloo
     (host-staged), and must reproduce the unsharded CPU specification bit for bit — poses, landmark maps,
     log-weights — with particles really migrating between the ranks."""
     import socket
@@ -360,14 +360,15 @@ def test_two_ranks_on_one_card_equal_unsharded_oracle(orc, tmp_path, L):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    mp.spawn(W.worker_gpu, args=(2, port, n_total, L, frames, str(tmp_path)), nprocs=2, join=True)
-    parts = [np.load(tmp_path / f"rank{r}.npz") for r in range(2)]
+    mp.spawn(W.worker_gpu, args=(world, port, n_total, L, frames, str(tmp_path)), nprocs=world, join=True)
+    parts = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
     assert np.array_equal(bits(np.concatenate([p["pose"] for p in parts], axis=1)), bits(ref["pose"]))
     assert np.array_equal(bits(np.concatenate([p["logw"] for p in parts])), bits(ref["logw"]))
     if L:
         assert np.array_equal(bits(np.concatenate([p["map"] for p in parts], axis=2)), bits(ref["map"]))
-    assert parts[1]["migrated"].max() > 200
-    assert tuple(parts[0]["best"]) == tuple(parts[1]["best"]) == tuple(np.array(ref["best"]))
+    assert parts[-1]["migrated"].max() > 200
+    for p in parts:
+        assert tuple(p["best"]) == tuple(np.array(ref["best"]))
 
 
 def test_c_session_equals_python_frame_loop_and_oracle(eng, orc):
