@@ -23,7 +23,6 @@ exact integer arithmetic, and the comb offset is a pure function of (seed, frame
 """
 from __future__ import annotations
 
-import numpy as np
 import torch
 import torch.distributed as dist
 

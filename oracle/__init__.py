@@ -12,7 +12,6 @@ stages have no reference counterpart and are "parity unpinned".
 from __future__ import annotations
 
 import ctypes as C
-import os
 import subprocess
 from pathlib import Path
 
