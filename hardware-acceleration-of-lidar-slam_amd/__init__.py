@@ -91,6 +91,11 @@ SIGNATURES = {
     "slam_argmax_dev": (_i, [_vp, _vp, _i, _vp, _vp]),
     "slam_gather_f32_dev": (_i, [_vp, _vp, _vp, _i, _vp]),
     "slam_gather_map_dev": (_i, [_vp, _vp, _vp, _i64, _i64, _i, _i, _i, _vp, _i]),
+    "slam_mapper_create": (_i, [_vp, _i, _f, _f, C.POINTER(_vp)]),
+    "slam_mapper_destroy": (_i, [_vp]),
+    "slam_mapper_first_frame": (_i, [_vp, _vp]),
+    "slam_mapper_next_frame": (_i, [_vp, _vp, _fp]),
+    "slam_mapper_get_map_host": (_i, [_vp, _vp, _vp, C.c_int32, C.POINTER(C.c_int32)]),
     "slam_pf_create": (_i, [_vp, _vp, C.POINTER(_vp)]),
     "slam_pf_destroy": (_i, [_vp]),
     "slam_pf_reset": (_i, [_vp, _fp]),

@@ -15,122 +15,9 @@
 #include <new>
 #include <vector>
 
-#include "kernels.h"
+#include "engine_internal.h"
 
 using namespace slam;
-
-namespace {
-
-struct DevBuf {
-    void* p = nullptr;
-    size_t cap = 0;
-    hipError_t ensure(size_t bytes)
-    {
-        if (bytes <= cap) return hipSuccess;
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        cap = 0;
-        const size_t want = bytes + bytes / 4 + 256;
-        hipError_t err = hipMalloc(&p, want);
-        if (err == hipSuccess) cap = want;
-        return err;
-    }
-    void release()
-    {
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        cap = 0;
-    }
-    template <class T> T* as() const { return static_cast<T*>(p); }
-};
-
-struct GridSlot {
-    bool ready = false;
-    slam_grid_meta meta{};
-    const float* d_edt = nullptr;   // owned (edt_buf) or adopted
-    DevBuf occ_buf, edt_buf;
-};
-
-constexpr int kLattice = 27;
-// device/host staging layout of one FastMatch call (floats):
-//   in : X[27] Y[27] CT[27] ST[27] LAST[4]
-//   out: SCORE[27] COUNT[27] NLAST[1] HITS[SLAM_MAX_BEAMS]
-constexpr int kFmIn = 4 * kLattice + 4;
-constexpr int kFmOut = 2 * kLattice + 1 + SLAM_MAX_BEAMS;
-constexpr unsigned kStageSlots = 8;
-constexpr size_t kStageFloats = 3 * SLAM_MAX_OBS > 2 * SLAM_MAX_BEAMS ? 3 * SLAM_MAX_OBS : 2 * SLAM_MAX_BEAMS;
-
-}  // namespace
-
-struct slam_engine {
-    int device = 0;
-    hipStream_t own_stream = nullptr;
-    hipStream_t stream = nullptr;
-    char err[512] = { 0 };
-
-    GridSlot grid[SLAM_MAX_GRID_SLOTS];
-
-    const float *d_bx = nullptr, *d_by = nullptr;   // owned (scan_buf) or adopted
-    int nbeams = -1;
-    DevBuf scan_buf;
-
-    // observation list of the current frame
-    DevBuf obs_buf;   // ids[MAX_OBS] zx[MAX_OBS] zy[MAX_OBS] unobs[...]
-    int nobs = -1, nunobs = 0, obs_nlandmarks = 0;
-    const int32_t *d_obs_id = nullptr, *d_unobs_id = nullptr;
-    const float *d_obs_zx = nullptr, *d_obs_zy = nullptr;
-
-    DevBuf fm_buf;             // kFmIn + kFmOut floats
-    DevBuf fm_work;            // 27 x SLAM_MAX_BEAMS floats: per-candidate hit rows of the lattice kernel
-    float* h_fm = nullptr;     // pinned mirror
-    DevBuf scratch;            // per-call temporaries of the *_dev stages
-    DevBuf bmax_buf;           // block maxima left by slam_logweight_dev (read by slam_quantise_scan_dev)
-    int bmax_count = 0, bmax_n = -1;
-    DevBuf scan_state;         // tile-local CDF u64[n] + tile totals, left by slam_quantise_scan_dev
-    int scan_n = -1;
-    DevBuf ll_buf;             // per-chunk log-likelihood partials [nchunks][n] of the last EKF call
-    int ll_n = -1, ll_chunks = 0;
-    // pinned staging ring for the per-frame sensor uploads: one host-to-device copy per upload, and the
-    // host only waits if kStageSlots uploads are still in flight
-    float* h_stage = nullptr;
-    hipEvent_t stage_ev[8] = {};
-    unsigned stage_next = 0;
-
-    float* stage_acquire()
-    {
-        const unsigned k = stage_next++ % kStageSlots;
-        if (stage_ev[k]) (void)hipEventSynchronize(stage_ev[k]);
-        return h_stage + (size_t)k * kStageFloats;
-    }
-    hipError_t stage_release(const float* slot)
-    {
-        const unsigned k = (unsigned)((slot - h_stage) / kStageFloats);
-        if (!stage_ev[k]) {
-            hipError_t err = hipEventCreateWithFlags(&stage_ev[k], hipEventDisableTiming);
-            if (err != hipSuccess) return err;
-        }
-        return hipEventRecord(stage_ev[k], stream);
-    }
-    DevBuf host_io[6];         // temporaries of the *_host convenience calls
-
-    // per-kernel HIP-event timing (slam_profile_*)
-    int prof_mask = 0;
-    std::vector<EventPair> prof_pool[SLAM_PROF_COUNT];   // grown on demand, reused after each read
-    size_t prof_used[SLAM_PROF_COUNT] = { 0, 0, 0 };
-    EventPair prof_cur{};
-
-    const EventPair* prof_next(int k)
-    {
-        if (!(prof_mask & (1 << k))) return nullptr;
-        auto& pool = prof_pool[k];
-        if (prof_used[k] == pool.size()) {
-            EventPair p;
-            if (hipEventCreate(&p.start) != hipSuccess || hipEventCreate(&p.stop) != hipSuccess) return nullptr;
-            pool.push_back(p);
-        }
-        return &pool[prof_used[k]++];
-    }
-};
 
 namespace {
 
@@ -516,13 +403,17 @@ int slam_pose_hits_host(slam_engine* e, int slot, float x, float y, float ct, fl
     return SLAM_OK;
 }
 
-int slam_fastmatch_host(slam_engine* e, int slot, const float pose[3], const float res[3], float out_pose[3],
-                        float* best_hits, int32_t* best_hits_size, float* best_score)
-{
-    ENTER(e);
-    if (!pose || !res || !out_pose || !best_hits || !best_hits_size) return SLAM_ERR_INVALID_ARG;
-    if (int rc = check_score_inputs(e, slot)) return rc;
+}  // extern "C"
 
+// ---- internal entry points shared with mapper.hip (C++ linkage, declared in engine_internal.h)
+int slam_engine_fail_hip(slam_engine* e, hipError_t err, const char* what) { return fail_hip(e, err, what); }
+
+slam::ScoreGrid slam_engine_score_grid(const slam_engine* e, int slot) { return score_grid(e->grid[slot]); }
+
+int slam_engine_fastmatch(slam_engine* e, int slot, const float* d_bx, const float* d_by, int nbeams_max,
+                          const int32_t* d_nbeams, const float pose[3], const float res[3], float out_pose[3],
+                          float* best_hits, int32_t* best_hits_size, float* best_score, float* d_hits_persist)
+{
     // main.c:386-387, :424-426 — the lattice is laid out once around the input pose; res[0] steps x
     // AND y, res[2] steps theta, res[1] is never read.  Heading trig with the host libm, as the
     // reference does (main.c:433-435).
@@ -547,8 +438,9 @@ int slam_fastmatch_host(slam_engine* e, int slot, const float pose[3], const flo
     float* d_out = d_in + kFmIn;
     const ScoreGrid g = score_grid(e->grid[slot]);
     HIP_TRY(hipMemcpyAsync(d_in, h_in, sizeof(float) * 4 * kLattice, hipMemcpyHostToDevice, e->stream));
-    HIP_TRY(launch_lattice(e->stream, g, e->d_bx, e->d_by, e->nbeams, d_in, e->fm_work.as<float>(), d_out));
-    HIP_TRY(hipMemcpyAsync(h_out, d_out, sizeof(float) * (2 * kLattice + 1 + (size_t)e->nbeams), hipMemcpyDeviceToHost,
+    HIP_TRY(launch_lattice(e->stream, g, d_bx, d_by, nbeams_max, d_nbeams, d_in, e->fm_work.as<float>(), d_out,
+                           d_hits_persist));
+    HIP_TRY(hipMemcpyAsync(h_out, d_out, sizeof(float) * (2 * kLattice + 1 + (size_t)nbeams_max), hipMemcpyDeviceToHost,
                            e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
 
@@ -574,9 +466,21 @@ int slam_fastmatch_host(slam_engine* e, int slot, const float pose[3], const flo
     // prefix every candidate overwrote, last writer wins; entries beyond the longest candidate untouched
     int32_t maxc;
     memcpy(&maxc, h_out + 2 * kLattice, sizeof maxc);
-    if (maxc > 0) memcpy(best_hits, h_out + 2 * kLattice + 1, sizeof(float) * (size_t)maxc);
+    if (maxc > 0 && best_hits) memcpy(best_hits, h_out + 2 * kLattice + 1, sizeof(float) * (size_t)maxc);
     if (best_score) *best_score = best;
     return SLAM_OK;
+}
+
+extern "C" {
+
+int slam_fastmatch_host(slam_engine* e, int slot, const float pose[3], const float res[3], float out_pose[3],
+                        float* best_hits, int32_t* best_hits_size, float* best_score)
+{
+    ENTER(e);
+    if (!pose || !res || !out_pose || !best_hits || !best_hits_size) return SLAM_ERR_INVALID_ARG;
+    if (int rc = check_score_inputs(e, slot)) return rc;
+    return slam_engine_fastmatch(e, slot, e->d_bx, e->d_by, e->nbeams, nullptr, pose, res, out_pose, best_hits,
+                                 best_hits_size, best_score, nullptr);
 }
 
 /* ------------------------------------------------------------------ particle-filter stages */

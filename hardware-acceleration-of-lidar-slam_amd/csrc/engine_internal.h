@@ -1,0 +1,142 @@
+// engine_internal.h — the engine object shared by the translation units that implement the C ABI
+// (engine.hip, mapper.hip).  Not part of the public interface.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <vector>
+
+#include "kernels.h"
+
+using slam::EventPair;
+
+namespace slam_detail {
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        const size_t want = bytes + bytes / 4 + 256;
+        hipError_t err = hipMalloc(&p, want);
+        if (err == hipSuccess) cap = want;
+        return err;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <class T> T* as() const { return static_cast<T*>(p); }
+};
+
+struct GridSlot {
+    bool ready = false;
+    slam_grid_meta meta{};
+    const float* d_edt = nullptr;   // owned (edt_buf) or adopted
+    DevBuf occ_buf, edt_buf;
+};
+
+constexpr int kLattice = 27;
+// device/host staging layout of one FastMatch call (floats):
+//   in : X[27] Y[27] CT[27] ST[27] LAST[4]
+//   out: SCORE[27] COUNT[27] NLAST[1] HITS[SLAM_MAX_BEAMS]
+constexpr int kFmIn = 4 * kLattice + 4;
+constexpr int kFmOut = 2 * kLattice + 1 + SLAM_MAX_BEAMS;
+constexpr unsigned kStageSlots = 8;
+constexpr size_t kStageFloats = 3 * SLAM_MAX_OBS > 2 * SLAM_MAX_BEAMS ? 3 * SLAM_MAX_OBS : 2 * SLAM_MAX_BEAMS;
+
+}  // namespace slam_detail
+
+using namespace slam_detail;
+
+struct slam_engine {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    char err[512] = { 0 };
+
+    GridSlot grid[SLAM_MAX_GRID_SLOTS];
+
+    const float *d_bx = nullptr, *d_by = nullptr;   // owned (scan_buf) or adopted
+    int nbeams = -1;
+    DevBuf scan_buf;
+
+    // observation list of the current frame
+    DevBuf obs_buf;   // ids[MAX_OBS] zx[MAX_OBS] zy[MAX_OBS] unobs[...]
+    int nobs = -1, nunobs = 0, obs_nlandmarks = 0;
+    const int32_t *d_obs_id = nullptr, *d_unobs_id = nullptr;
+    const float *d_obs_zx = nullptr, *d_obs_zy = nullptr;
+
+    DevBuf fm_buf;             // kFmIn + kFmOut floats
+    DevBuf fm_work;            // 27 x SLAM_MAX_BEAMS floats: per-candidate hit rows of the lattice kernel
+    float* h_fm = nullptr;     // pinned mirror
+    DevBuf scratch;            // per-call temporaries of the *_dev stages
+    DevBuf bmax_buf;           // block maxima left by slam_logweight_dev (read by slam_quantise_scan_dev)
+    int bmax_count = 0, bmax_n = -1;
+    DevBuf scan_state;         // tile-local CDF u64[n] + tile totals, left by slam_quantise_scan_dev
+    int scan_n = -1;
+    DevBuf ll_buf;             // per-chunk log-likelihood partials [nchunks][n] of the last EKF call
+    int ll_n = -1, ll_chunks = 0;
+    // pinned staging ring for the per-frame sensor uploads: one host-to-device copy per upload, and the
+    // host only waits if kStageSlots uploads are still in flight
+    float* h_stage = nullptr;
+    hipEvent_t stage_ev[8] = {};
+    unsigned stage_next = 0;
+
+    float* stage_acquire()
+    {
+        const unsigned k = stage_next++ % kStageSlots;
+        if (stage_ev[k]) (void)hipEventSynchronize(stage_ev[k]);
+        return h_stage + (size_t)k * kStageFloats;
+    }
+    hipError_t stage_release(const float* slot)
+    {
+        const unsigned k = (unsigned)((slot - h_stage) / kStageFloats);
+        if (!stage_ev[k]) {
+            hipError_t err = hipEventCreateWithFlags(&stage_ev[k], hipEventDisableTiming);
+            if (err != hipSuccess) return err;
+        }
+        return hipEventRecord(stage_ev[k], stream);
+    }
+    DevBuf host_io[6];         // temporaries of the *_host convenience calls
+
+    // per-kernel HIP-event timing (slam_profile_*)
+    int prof_mask = 0;
+    std::vector<EventPair> prof_pool[SLAM_PROF_COUNT];   // grown on demand, reused after each read
+    size_t prof_used[SLAM_PROF_COUNT] = { 0, 0, 0 };
+    EventPair prof_cur{};
+
+    const EventPair* prof_next(int k)
+    {
+        if (!(prof_mask & (1 << k))) return nullptr;
+        auto& pool = prof_pool[k];
+        if (prof_used[k] == pool.size()) {
+            EventPair p;
+            if (hipEventCreate(&p.start) != hipSuccess || hipEventCreate(&p.stop) != hipSuccess) return nullptr;
+            pool.push_back(p);
+        }
+        return &pool[prof_used[k]++];
+    }
+};
+
+
+// helpers implemented in engine.hip
+int slam_engine_fail_hip(slam_engine* e, hipError_t err, const char* what);
+slam::ScoreGrid slam_engine_score_grid(const slam_engine* e, int slot);
+// FastMatch on grid `slot` with the beam count read from device memory (d_nbeams, at most nbeams_max) and the
+// scan at d_bx/d_by; optionally mirrors the hit scratch into d_hits_persist.  Synchronises.
+int slam_engine_fastmatch(slam_engine* e, int slot, const float* d_bx, const float* d_by, int nbeams_max,
+                          const int32_t* d_nbeams, const float pose[3], const float res[3], float out_pose[3],
+                          float* best_hits, int32_t* best_hits_size, float* best_score, float* d_hits_persist);
+
+#define SLAM_HIP_TRY(e, call)                                                     \
+    do {                                                                          \
+        hipError_t err__ = (call);                                                \
+        if (err__ != hipSuccess) return slam_engine_fail_hip((e), err__, #call); \
+    } while (0)

@@ -43,8 +43,24 @@ hipError_t launch_pose_hits(hipStream_t stream, const ScoreGrid& g, const float*
 // bestHits[] scratch after the sweep — entry j holds the hit of the LAST candidate (in evaluation
 // order) that had more than j in-bounds beams (main.c:515 overwrites the prefix for every candidate).
 // work: device scratch of 27*nbeams floats.  out layout: score[27] | count[27] (int) | maxcount (int) | merged[nbeams]
+// d_nbeams (optional): the beam count lives on the device (<= nbeams, which then is the capacity / row stride).
+// persist (optional): device mirror of the caller's persistent hit scratch, updated like the host copy.
 hipError_t launch_lattice(hipStream_t stream, const ScoreGrid& g, const float* bx, const float* by, int nbeams,
-                          const float* cand_xycs /* X[27] Y[27] CT[27] ST[27] */, float* work, float* out);
+                          const int32_t* d_nbeams, const float* cand_xycs /* X[27] Y[27] CT[27] ST[27] */, float* work,
+                          float* out, float* persist);
+
+// ---- mapper_kernels.hip (reference: main.c:71-198, 271-354, 941-953)
+hipError_t launch_clean_scan(hipStream_t s, const float* range, const float* cos_tab, const float* sin_tab, int nbeams,
+                             float range_min, float usable, float* bx, float* by, int32_t* nscan);
+hipError_t launch_transform(hipStream_t s, const float* bx, const float* by, const int32_t* nscan, float px, float py,
+                            float ct, float st, float* tx, float* ty);
+hipError_t launch_crop(hipStream_t s, const float* tx, const float* ty, const int32_t* nscan, float border,
+                       const float* mx, const float* my, const int32_t* msize, int local_cap, float* lx, float* ly,
+                       int32_t* lsize);
+hipError_t launch_rasterise(hipStream_t s, const float* lx, const float* ly, const int32_t* lsize, float pixel, int ld,
+                            int32_t* grid, slam_grid_meta* meta);
+hipError_t launch_map_append(hipStream_t s, const float* hits, int nhits, const float* tx, const float* ty, float* mx,
+                             float* my, int32_t* msize, int map_cap);
 
 // ---- edt_kernels.hip (row A6; reference: main.c:223-269, main_accelerated.c:215-283)
 enum { EDT_MAX_RADIUS = 32 };

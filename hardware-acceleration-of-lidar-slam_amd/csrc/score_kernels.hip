@@ -198,19 +198,23 @@ constexpr int kLatticeN = 27;
 // (for the ordered sum) and to this candidate's row of `work` (for the merge below).  The score is
 // then accumulated by lane 0 in slot order — the reference's sequential float sum (main.c:516).
 __global__ __launch_bounds__(64) void lattice_kernel(ScoreGrid g, const float* __restrict__ bx,
-                                                     const float* __restrict__ by, int nbeams,
+                                                     const float* __restrict__ by, int nbeams_max,
+                                                     const int32_t* __restrict__ d_nbeams,
                                                      const float* __restrict__ cand, float* __restrict__ work,
                                                      float* __restrict__ out)
 {
     extern __shared__ float s_hit[];
     const int c = blockIdx.x, lane = threadIdx.x;
+    // the beam count may live on the device (scan cleaned up there); rows of `work` keep the max stride
+    int nbeams = d_nbeams ? *d_nbeams : nbeams_max;
+    nbeams = nbeams < nbeams_max ? nbeams : nbeams_max;
     const float x = cand[c], y = cand[kLatticeN + c], ct = cand[2 * kLatticeN + c], st = cand[3 * kLatticeN + c];
     const float nst = -st;
     const float off_x = (x - g.min_x) * g.ipix;
     const float off_y = (y - g.min_y) * g.ipix;
     const float lim_x = (float)(g.cols - 1);
     const float lim_y = (float)(g.rows - 1);
-    float* __restrict__ row = work + (size_t)c * nbeams;
+    float* __restrict__ row = work + (size_t)c * nbeams_max;
     int base = 0;
     for (int b0 = 0; b0 < nbeams; b0 += 64) {
         const int b = b0 + lane;
@@ -243,7 +247,7 @@ __global__ __launch_bounds__(64) void lattice_kernel(ScoreGrid g, const float* _
 }
 
 __global__ __launch_bounds__(256) void lattice_merge_kernel(const float* __restrict__ work, int nbeams,
-                                                            float* __restrict__ out)
+                                                            float* __restrict__ out, float* __restrict__ persist)
 {
     __shared__ int s_cnt[kLatticeN];
     const int32_t* cnt = reinterpret_cast<const int32_t*>(out) + kLatticeN;
@@ -256,18 +260,20 @@ __global__ __launch_bounds__(256) void lattice_merge_kernel(const float* __restr
     for (int j = threadIdx.x; j < maxc; j += 256) {
         int c = kLatticeN - 1;
         while (s_cnt[c] <= j) --c;   // terminates: some candidate has count == maxc > j
-        merged[j] = work[(size_t)c * nbeams + j];
+        const float v = work[(size_t)c * nbeams + j];
+        merged[j] = v;
+        if (persist) persist[j] = v;   // device-resident copy of the caller's persistent hit scratch
     }
 }
 
 }  // namespace
 
 hipError_t launch_lattice(hipStream_t stream, const ScoreGrid& g, const float* bx, const float* by, int nbeams,
-                          const float* cand_xycs, float* work, float* out)
+                          const int32_t* d_nbeams, const float* cand_xycs, float* work, float* out, float* persist)
 {
     const size_t lds = sizeof(float) * (size_t)(nbeams > 0 ? nbeams : 1);
-    lattice_kernel<<<kLatticeN, 64, lds, stream>>>(g, bx, by, nbeams, cand_xycs, work, out);
-    lattice_merge_kernel<<<1, 256, 0, stream>>>(work, nbeams, out);
+    lattice_kernel<<<kLatticeN, 64, lds, stream>>>(g, bx, by, nbeams, d_nbeams, cand_xycs, work, out);
+    lattice_merge_kernel<<<1, 256, 0, stream>>>(work, nbeams, out, persist);
     return hipGetLastError();
 }
 

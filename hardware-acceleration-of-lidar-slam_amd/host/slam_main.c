@@ -9,8 +9,10 @@
  *     FastMatch / FastMatch2        -> slam_fastmatch_host     (replaces main.c:381-809)
  * The grids and the scan stay resident on the GPU between the calls of one frame.
  *
- * usage: slam_main dataset frames beams map_out.csv [angle_min angle_inc]
+ * usage: slam_main [--mapper] dataset frames beams map_out.csv [angle_min angle_inc]
  *        slam_main --to-binary dataset.csv frames beams dataset.bin      (no GPU needed)
+ * --mapper runs the whole per-frame pipeline through slam_mapper_* (scan clean-up, local map, rasters and map
+ * update on the device too) instead of the host front end below; same results.
  * `dataset` is the reference's CSV or the binary scan-frame stream of slam_frontend.h (auto-detected; the
  * binary form carries exactly the floats the CSV parser yields, results are identical, ingest is ~20x
  * cheaper).  Fails (non-zero exit) when no gfx950 GPU is available: there is no CPU fallback.
@@ -54,8 +56,14 @@ int main(int argc, char **argv)
         fe_scan_free(&tmp);
         return 0;
     }
+    int use_mapper = 0;
+    if (argc >= 2 && strcmp(argv[1], "--mapper") == 0) {
+        use_mapper = 1;
+        --argc;
+        ++argv;
+    }
     if (argc < 5) {
-        fprintf(stderr, "usage: %s dataset frames beams map_out.csv [angle_min angle_inc]\n", argv[0]);
+        fprintf(stderr, "usage: %s [--mapper] dataset frames beams map_out.csv [angle_min angle_inc]\n", argv[0]);
         return 2;
     }
     FILE *in = fopen(argv[1], "rb");
@@ -85,6 +93,37 @@ int main(int argc, char **argv)
             fprintf(stderr, "slam_engine_create: %s\n", slam_status_string(rc));
             return 1;
         }
+    }
+    if (use_mapper) {   /* the device-resident form of the same loop */
+        fe_scan rd;
+        slam_mapper *mp = NULL;
+        if (fe_scan_init(&rd, beams, angle_min, angle_inc)) return 1;
+        CHECK(slam_mapper_create(eng, beams, angle_min, angle_inc, &mp));
+        const double t0 = now_s();
+        if (binary) fe_read_frame_bin(in, &rd); else fe_read_frame(in, &rd);
+        CHECK(slam_mapper_first_frame(mp, rd.range));
+        for (int k = 1; k < frames; ++k) {
+            float p[3];
+            printf("scan %d\n", k + 1);
+            if (binary) fe_read_frame_bin(in, &rd); else fe_read_frame(in, &rd);
+            CHECK(slam_mapper_next_frame(mp, rd.range, p));
+            printf("pose = %f  %f  %f\n", p[0], p[1], p[2]);
+        }
+        fprintf(stderr, "frames %d  wall %.6f s  (mapper: front end on the device)\n", frames, now_s() - t0);
+        int32_t n = 0;
+        CHECK(slam_mapper_get_map_host(mp, NULL, NULL, 0, &n));
+        float *mx = (float *)calloc((size_t)n + 1, sizeof(float)), *my = (float *)calloc((size_t)n + 1, sizeof(float));
+        CHECK(slam_mapper_get_map_host(mp, mx, my, n, &n));
+        FILE *mo = fopen(argv[4], "w");
+        if (!mo) { perror(argv[4]); return 1; }
+        for (int j = 0; j < n; ++j) fprintf(mo, "%f,%f\n", mx[j], my[j]);
+        fclose(mo);
+        fclose(in);
+        free(mx); free(my);
+        fe_scan_free(&rd);
+        slam_mapper_destroy(mp);
+        slam_engine_destroy(eng);
+        return 0;
     }
     fe_scan scan;
     fe_points map, local;

@@ -306,6 +306,22 @@ int slam_pf_best(slam_pf *pf, float pose[3], float *logw, int32_t *index);
 int slam_pf_get_poses_host(slam_pf *pf, float *x, float *y, float *theta);
 int slam_pf_get_map_host(slam_pf *pf, float *planes);
 
+/* ------------------------------------------------------------------ mapper: the reference's frame loop in one call
+ * (SURVEY.md §8f rows N1 + N2).  One slam_mapper_next_frame = one iteration of the reference's loop
+ * (main.c:859-969): scan clean-up, world transform, local-map crop, both rasters, both EDTs on key frames,
+ * constant-velocity guess, FastMatch + FastMatch2, key-frame test and map append — with the scan, the map,
+ * the local map and the grids resident on the device.  Only what the reference computes with libm (cos/sin
+ * of beam angles, pose and lattice headings) and the arg-min / key-frame decisions run on the host, so the
+ * pose sequence and the final map are bit-identical to the reference program's.  Uses grid slots 0 and 1 of
+ * the engine.  `ranges` = one raw scan frame of `nbeams` floats (what main.c:22-30 parses from the CSV). */
+typedef struct slam_mapper slam_mapper;
+int slam_mapper_create(slam_engine *e, int nbeams, float angle_min, float angle_inc, slam_mapper **out);
+int slam_mapper_destroy(slam_mapper *m);
+int slam_mapper_first_frame(slam_mapper *m, const float *ranges);                    /* main.c:844-858 */
+int slam_mapper_next_frame(slam_mapper *m, const float *ranges, float pose_out[3]);  /* main.c:859-969 */
+/* map points (main.c:982-985 writes them as "%f,%f" lines); x/y may be NULL to query the size only */
+int slam_mapper_get_map_host(slam_mapper *m, float *x, float *y, int32_t capacity, int32_t *n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -275,6 +275,22 @@ def test_slam_main_matches_reference_logs(orc, tmp_path, name, frames):
     print(r.stderr.strip())
 
 
+@pytest.mark.parametrize("name,frames", [("parity", 1000), ("loop", 3480)])
+def test_device_resident_mapper_matches_reference_logs(orc, tmp_path, name, frames):
+    """slam_mapper_* (scan clean-up, local map, rasters, EDTs, matcher and map update
+    with all state on the device) reproduces the reference programs' pose log and map byte for byte."""
+    info = json.loads((GOLDEN / "datasets.json").read_text())[name]
+    csv = tmp_path / f"{name}.csv"
+    orc.run_tool("gen_dataset", csv, *info["gen_args"])
+    exe = PKG_DIR / "lib" / "slam_main"
+    r = subprocess.run([str(exe), "--mapper", str(csv), str(frames), str(NB), str(tmp_path / "map.csv")], check=True,
+                       capture_output=True, text=True)
+    poses = [ln for ln in r.stdout.splitlines() if ln.startswith("pose =")]
+    assert "\n".join(poses) + "\n" == (GOLDEN / f"{name}_pose.txt").read_text()
+    assert (tmp_path / "map.csv").read_bytes() == (GOLDEN / f"{name}_map.csv").read_bytes()
+    print(r.stderr.strip())
+
+
 def test_binary_scan_frames_give_identical_results(orc, tmp_path):
     """the binary scan-frame stream carries exactly the floats the CSV parser yields, so
     slam_main's pose log and map are byte-identical to the CSV run (and to the reference), only faster."""
