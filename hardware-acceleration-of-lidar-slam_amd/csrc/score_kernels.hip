@@ -60,7 +60,8 @@ __global__ __launch_bounds__(kScoreBlock) void score_poses_kernel(ScoreGrid g, c
     extern __shared__ float2 s_beam[];
     // beams padded with NaN to a whole number of pipeline rounds: a NaN beam is out of bounds and adds +0
     constexpr int kRound = LPP * kQuadDepth;
-    const int nb_pad = LPP == 1 ? nbeams : (nbeams + kRound - 1) / kRound * kRound;
+    // (at least one round, so that an empty scan still runs the pipeline prologue on NaN beams)
+    const int nb_pad = LPP == 1 ? nbeams : (nbeams > 0 ? (nbeams + kRound - 1) / kRound * kRound : kRound);
     for (int b = threadIdx.x; b < nb_pad; b += kScoreBlock)
         s_beam[b] = b < nbeams ? make_float2(bx[b] * g.ipix, by[b] * g.ipix)
                                : make_float2(__builtin_nanf(""), __builtin_nanf(""));
