@@ -7,10 +7,12 @@
  * is the pose search: instead of the reference's two 27-pose lattice sweeps (main.c:901-918) every frame
  * runs one particle-filter step on the GPU — N particles are moved by the constant-velocity increment of
  * main.c:875-898 plus noise, each is scored against the fine EDT with the reference's own score function,
- * weights are normalised and the population is resampled; the frame's pose is the heaviest particle.
+ * weights are normalised and the population is resampled; the frame's pose is the mean of the resampled
+ * (hence equally weighted) population, accumulated in double in index order — or, with estimator "best", the
+ * heaviest particle.
  * All of it goes through the C ABI (slam_pf_* in include/slam_hip.h); no HIP type appears here.
  *
- * usage: slam_pf_main dataset.csv frames beams map_out.csv particles [seed]
+ * usage: slam_pf_main dataset.csv frames beams map_out.csv particles [seed [mean|best]]
  */
 #define _POSIX_C_SOURCE 200809L
 #include <math.h>
@@ -49,6 +51,9 @@ int main(int argc, char **argv)
     const int beams = atoi(argv[3]);
     const int particles = atoi(argv[5]);
     const unsigned long long seed = argc > 6 ? strtoull(argv[6], NULL, 10) : 1;
+    const int use_mean = !(argc > 7 && strcmp(argv[7], "best") == 0);
+    float *px = (float *)calloc((size_t)particles, sizeof(float)), *py = (float *)calloc((size_t)particles, sizeof(float)),
+          *pt = (float *)calloc((size_t)particles, sizeof(float));
 
     const float border = 1, pixel_coarse = 0.2f, pixel_fine = 0.1f;   /* main.c:834-836 */
     const float key_dt = 0.3f, key_dr = 0.0872665f, edt_cap = 10;     /* main.c:838-839, :224 */
@@ -113,7 +118,14 @@ int main(int argc, char **argv)
         const double t0 = now_s();
         CHECK(slam_pf_step(pf, 1, dp, 0));
         float best[3];
-        CHECK(slam_pf_best(pf, best, NULL, NULL));
+        if (use_mean) {   /* posterior mean = plain mean of the resampled population */
+            CHECK(slam_pf_get_poses_host(pf, px, py, pt));
+            double sx = 0, sy = 0, st = 0;
+            for (int i = 0; i < particles; ++i) { sx += px[i]; sy += py[i]; st += pt[i]; }
+            best[0] = (float)(sx / particles); best[1] = (float)(sy / particles); best[2] = (float)(st / particles);
+        } else {
+            CHECK(slam_pf_best(pf, best, NULL, NULL));
+        }
         t_step += now_s() - t0;
         memcpy(prev, pose, sizeof prev);
         memcpy(pose, best, sizeof pose);
@@ -147,7 +159,7 @@ int main(int argc, char **argv)
     if (!out) { perror(argv[4]); return 1; }
     for (int j = 0; j < map.size; ++j) fprintf(out, "%f,%f\n", map.x[j], map.y[j]);
     fclose(out);
-    free(hits);
+    free(hits); free(px); free(py); free(pt);
     fe_grid_free(&coarse); fe_grid_free(&fine);
     fe_points_free(&map); fe_points_free(&local);
     fe_scan_free(&scan);

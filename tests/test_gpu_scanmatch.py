@@ -330,10 +330,11 @@ def test_unmodified_reference_program_on_the_engine(orc, tmp_path):
 
 def test_particle_filter_host_program_tracks_the_reference_trajectory(orc, tmp_path):
     """slam_pf_main = the reference's frame loop with the lattice search replaced by a particle-filter step
-    (4096 particles).  A stochastic estimator cannot reproduce main.c bit for bit; the stated tolerance is:
-    every pose within 0.20 m (two cells of the 0.1 m grid the score is piecewise constant on) and 0.02 rad
-    of the reference's own pose log (golden parity_pose.txt) over the 1000 frames — measured 0.14 m /
-    0.010 rad — and the run is deterministic (same seed => identical output)."""
+    (4096 particles, pose = mean of the resampled population).  A stochastic estimator cannot reproduce main.c
+    bit for bit; the stated tolerance is: every pose within 0.10 m (one cell of the 0.1 m grid the score is
+    piecewise constant on) and 0.012 rad of the reference's own pose log (golden parity_pose.txt) over the 1000
+    frames — measured 0.066 m / 0.0087 rad —, the filter is at least as close to the generator's ground truth as
+    the reference is (measured 0.035 m vs 0.073 m), and the run is deterministic (same seed => identical output)."""
     info = json.loads((GOLDEN / "datasets.json").read_text())["parity"]
     csv = tmp_path / "parity.csv"
     orc.run_tool("gen_dataset", csv, *info["gen_args"])
@@ -350,6 +351,12 @@ def test_particle_filter_host_program_tracks_the_reference_trajectory(orc, tmp_p
     assert got.shape == ref.shape == (999, 3)
     err_xy = np.hypot(got[:, 0] - ref[:, 0], got[:, 1] - ref[:, 1])
     err_th = np.abs(got[:, 2] - ref[:, 2])
-    print(f"PF vs reference trajectory: max |dxy| {err_xy.max():.4f} m, max |dtheta| {err_th.max():.5f} rad, "
-          f"final {err_xy[-1]:.4f} m / {err_th[-1]:.5f} rad")
-    assert err_xy.max() < 0.20 and err_th.max() < 0.02
+    # ground truth of oracle/gen_dataset.c: 4 mm and 0.6 mrad per frame on an arc; the reference's theta is -phi
+    f = np.arange(1, 1000)
+    truth = np.stack([(0.004 / 0.0006) * np.sin(0.0006 * f), (0.004 / 0.0006) * (1 - np.cos(0.0006 * f)), -0.0006 * f], 1)
+    pf_truth = np.hypot(got[:, 0] - truth[:, 0], got[:, 1] - truth[:, 1]).max()
+    ref_truth = np.hypot(ref[:, 0] - truth[:, 0], ref[:, 1] - truth[:, 1]).max()
+    print(f"PF vs reference trajectory: max |dxy| {err_xy.max():.4f} m, max |dtheta| {err_th.max():.5f} rad; "
+          f"vs ground truth: PF {pf_truth:.4f} m, reference {ref_truth:.4f} m")
+    assert err_xy.max() < 0.10 and err_th.max() < 0.012
+    assert pf_truth <= ref_truth
