@@ -57,6 +57,7 @@ SIGNATURES = {
     "slam_engine_sync": (_i, [_vp]),
     "slam_profile_enable": (_i, [_vp, _i]),
     "slam_profile_read": (_i, [_vp, _i, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "slam_profile_bracket_overhead": (_i, [_vp, C.POINTER(C.c_double)]),
     "slam_edt_dev": (_i, [_vp, _vp, _i, _i, _i, _f, _vp]),
     "slam_edt_host": (_i, [_vp, _vp, _i, _i, _i, _f, _vp]),
     "slam_grid_upload_host": (_i, [_vp, _i, _vp, C.POINTER(GridMeta), _f, _vp]),
@@ -196,6 +197,12 @@ class Engine:
         ms, n = C.c_double(0), C.c_int64(0)
         self._ck(self.lib.slam_profile_read(self.h, kernel, C.byref(ms), C.byref(n)), "profile_read")
         return ms.value, n.value
+
+    def profile_bracket_overhead(self) -> float:
+        """Milliseconds an empty event bracket measures on the engine's stream."""
+        ms = C.c_double(0)
+        self._ck(self.lib.slam_profile_bracket_overhead(self.h, C.byref(ms)), "profile_bracket_overhead")
+        return ms.value
 
     # ---------------------------------------------------------------- host-buffer level (drop-in)
     def edt_host(self, occ: np.ndarray, rows: int, cols: int, cap: float = 10.0, out: np.ndarray | None = None):

@@ -191,6 +191,30 @@ int slam_profile_read(slam_engine* e, int kernel, double* total_ms, int64_t* lau
     return SLAM_OK;
 }
 
+int slam_profile_bracket_overhead(slam_engine* e, double* overhead_ms)
+{
+    ENTER(e);
+    if (!overhead_ms) return SLAM_ERR_INVALID_ARG;
+    enum { kPairs = 64 };
+    hipEvent_t ev[2 * kPairs];
+    for (auto& x : ev) HIP_TRY(hipEventCreate(&x));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    for (int k = 0; k < kPairs; ++k) {
+        HIP_TRY(hipEventRecord(ev[2 * k], e->stream));
+        HIP_TRY(hipEventRecord(ev[2 * k + 1], e->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    double sum = 0.0;
+    for (int k = 0; k < kPairs; ++k) {
+        float ms = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&ms, ev[2 * k], ev[2 * k + 1]));
+        sum += (double)ms;
+    }
+    for (auto& x : ev) (void)hipEventDestroy(x);
+    *overhead_ms = sum / kPairs;
+    return SLAM_OK;
+}
+
 int slam_engine_set_stream(slam_engine* e, void* hip_stream)
 {
     ENTER(e);

@@ -86,6 +86,9 @@ int slam_engine_sync(slam_engine *e);
 typedef enum { SLAM_PROF_SCORE = 0, SLAM_PROF_EDT = 1, SLAM_PROF_EKF = 2, SLAM_PROF_COUNT = 3 } slam_prof_kernel;
 int slam_profile_enable(slam_engine *e, int mask);
 int slam_profile_read(slam_engine *e, int kernel, double *total_ms, int64_t *launches);
+/* What an EMPTY start/stop bracket measures on this stream (mean of 64 back-to-back pairs, ms): the part of a
+ * bracketed duration that is event bookkeeping rather than kernel time.  Synchronises. */
+int slam_profile_bracket_overhead(slam_engine *e, double *overhead_ms);
 
 /* ------------------------------------------------------------------ EDT */
 
