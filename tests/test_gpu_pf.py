@@ -411,3 +411,58 @@ def test_c_session_equals_python_frame_loop_and_oracle(eng, orc):
         if L:
             assert np.array_equal(bits(ses.maps()), bits(cpu.maps().numpy()))
         ses.close()
+
+
+def test_full_size_ekf_config2_vs_oracle(eng, orc):
+    """BASELINE config 2 at full size — 65 536 particles x 500 landmarks, every landmark observed, resample
+    gather fused in: the whole 2 x 655 MB update against the CPU specification, bit for bit."""
+    import ctypes as C
+    n, L = 65536, 500
+    rng = np.random.default_rng(65536)
+    mp = _rand_map(rng, L, n, n)
+    x, y, th = (rng.normal(0, 1, n).astype(np.float32) for _ in range(3))
+    u = rng.random(n) ** 3
+    anc = np.sort(rng.choice(n, n, p=u / u.sum())).astype(np.int32)    # resample-like: sorted, with repeats and gaps
+    ids = rng.permutation(L).astype(np.int32)
+    zx, zy = rng.normal(0, 2, L).astype(np.float32), rng.normal(0, 2, L).astype(np.float32)
+    d_out = torch.empty((5, L, n), device=DEV)
+    ll = torch.empty(n, device=DEV)
+    eng.obs_upload(ids, zx, zy, L)
+    eng.ekf_update_dev(dev(mp), d_out, L * n, n, L, dev(x), dev(y), dev(th), dev(anc), n, 0.0016, ll)
+    want = np.empty((5, L, n), np.float32)
+    wl = np.empty(n, np.float32)
+    orc.lib().orc_ekf_update(mp, want, L * n, n, L, x, y, th, anc.ctypes.data_as(C.c_void_p), n, ids, zx, zy, L, 0.0016, wl)
+    got = host(d_out)
+    assert np.array_equal(bits(got), bits(want))
+    assert np.array_equal(bits(host(ll)), bits(wl))
+    # size-independent properties: covariances stay symmetric positive definite and never grow
+    seen = mp[2][:, anc] >= 0
+    det = got[2] * got[4] - got[3] * got[3]
+    assert (got[2][seen] > 0).all() and (det[seen] > 0).all() and (got[2][seen] <= mp[2][:, anc][seen] * (1 + 1e-5)).all()
+
+
+def test_full_size_resample_8m_vs_oracle(eng, orc):
+    """BASELINE config 4 scale: 8M particles (here in one shard).  Ancestors equal the oracle's; plus the
+    properties that hold at any size: sorted, offspring counts within 1 of N*w/S, zero weight => no offspring."""
+    n = 8 * 1024 * 1024
+    rng = np.random.default_rng(8)
+    w = (rng.random(n) ** 4 * 2**32).astype(np.uint64)
+    w[rng.integers(0, n, n // 20)] = 0
+    seed, frame = 2024, 9
+    cdf = torch.empty(n, dtype=torch.int64, device=DEV)
+    eng.prefix_sum_dev(dev(w.view(np.int64)), n, cdf)
+    cdf_ref = np.cumsum(w, dtype=np.uint64)
+    assert np.array_equal(host(cdf).view(np.uint64), cdf_ref)
+    total = int(cdf_ref[-1])
+    first = torch.empty(n, dtype=torch.int32, device=DEV)
+    eng.offspring_offsets_dev(cdf, n, None, dev(np.array([total], np.int64)), seed, frame, n, first)
+    anc = torch.empty(n, dtype=torch.int32, device=DEV)
+    eng.ancestors_dev(first, n, 0, n, anc)
+    got = host(anc)
+    want_first = orc.offspring_offsets(cdf_ref, 0, total, orc.comb_offset(seed, frame, total), n)
+    assert np.array_equal(host(first), want_first)
+    assert np.array_equal(got, orc.ancestors(want_first, 0, n))
+    assert (np.diff(got) >= 0).all()
+    cnt = np.bincount(got, minlength=n)
+    assert cnt.sum() == n and (cnt[w == 0] == 0).all()
+    assert (np.abs(cnt - n * w.astype(np.float64) / total) < 1.0 + 1e-6).all()

@@ -234,6 +234,33 @@ def test_score_dispatch_boundaries_and_max_beams(eng, orc, npose, nbeams):
         assert np.array_equal(bits(hits), bits(h2))
 
 
+def test_full_size_score_config3_properties(eng, orc):
+    """BASELINE config 3 at full size: 1 048 576 poses, 360 beams, 2048^2 EDT.  A 16k-pose sample is checked
+    against the oracle bit for bit; the size-independent property — a pose's score does not depend on which
+    other poses are in the batch or on the lane mapping — is checked by re-scoring slices of the batch (the
+    small slices take the 4-lanes-per-pose kernel, the full batch the 1-lane-per-pose kernel)."""
+    pkg = load_package()
+    grid, n, nb = 2048, 1 << 20, 360
+    rng = np.random.default_rng(3)
+    occ = (rng.random((grid, grid)) < 0.012).astype(np.int32)
+    meta = pkg.grid_meta(grid, grid, grid, 0.01, -10.24, -10.24)
+    edt = eng.grid_upload(2, occ, meta, 10.0, want_edt=True)
+    ang = np.linspace(-np.pi, np.pi, nb, endpoint=False)
+    rad = rng.uniform(0.5, 9.0, nb)
+    bx, by = (rad * np.cos(ang)).astype(np.float32), (rad * np.sin(ang)).astype(np.float32)
+    eng.scan_upload(bx, by)
+    x = (0.5 + 0.05 * rng.standard_normal(n)).astype(np.float32)
+    y = (-0.3 + 0.05 * rng.standard_normal(n)).astype(np.float32)
+    th = (0.2 + 0.01 * rng.standard_normal(n)).astype(np.float32)
+    s_all, c_all = eng.score_poses_host(2, x, y, th)
+    sel = rng.choice(n, 16384, replace=False)
+    s_cpu, c_cpu = orc.score_poses_det(orc.meta(grid, grid, grid, 0.01, -10.24, -10.24), edt, bx, by, x[sel], y[sel], th[sel])
+    assert np.array_equal(c_all[sel], c_cpu) and np.array_equal(bits(s_all[sel]), bits(s_cpu))
+    for lo, hi in ((0, 1000), (500_000, 565_536), (n - 7, n)):
+        s_part, c_part = eng.score_poses_host(2, x[lo:hi].copy(), y[lo:hi].copy(), th[lo:hi].copy())
+        assert np.array_equal(bits(s_part), bits(s_all[lo:hi])) and np.array_equal(c_part, c_all[lo:hi])
+
+
 def test_score_edge_cases(eng, golden):
     pkg = load_package()
     _load_state_grid(eng, golden, 1)
