@@ -122,7 +122,8 @@ int slam_engine_create(int device, slam_engine** out)
     if (hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking) != hipSuccess ||
         e->fm_buf.ensure(sizeof(float) * (kFmIn + kFmOut)) != hipSuccess ||
         e->fm_work.ensure(sizeof(float) * kLattice * SLAM_MAX_BEAMS) != hipSuccess ||
-        hipHostMalloc((void**)&e->h_fm, sizeof(float) * (kFmIn + kFmOut), hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc((void**)&e->h_fm, sizeof(float) * (kFmIn + kFmOut + 4), hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer((void**)&e->d_hfm, e->h_fm, 0) != hipSuccess ||
         e->scan_buf.ensure(sizeof(float) * 2 * SLAM_MAX_BEAMS) != hipSuccess ||
         hipHostMalloc((void**)&e->h_stage, sizeof(float) * kStageSlots * kStageFloats, hipHostMallocDefault) !=
             hipSuccess) {
@@ -130,6 +131,7 @@ int slam_engine_create(int device, slam_engine** out)
         slam_engine_destroy(e);
         return SLAM_ERR_NO_DEVICE;
     }
+    memset(e->h_fm, 0, sizeof(float) * (kFmIn + kFmOut + 4));   // arrival flag starts at 0, sequence numbers at 1
     e->stream = e->own_stream;
     *out = e;
     return SLAM_OK;
@@ -458,15 +460,24 @@ int slam_engine_fastmatch(slam_engine* e, int slot, const float* d_bx, const flo
                 h_in[3 * kLattice + k] = s;
             }
     }
-    float* d_in = e->fm_buf.as<float>();
-    float* d_out = d_in + kFmIn;
+    float* d_out = e->fm_buf.as<float>() + kFmIn;
     const ScoreGrid g = score_grid(e->grid[slot]);
-    HIP_TRY(hipMemcpyAsync(d_in, h_in, sizeof(float) * 4 * kLattice, hipMemcpyHostToDevice, e->stream));
-    HIP_TRY(launch_lattice(e->stream, g, d_bx, d_by, nbeams_max, d_nbeams, d_in, e->fm_work.as<float>(), d_out,
-                           d_hits_persist));
-    HIP_TRY(hipMemcpyAsync(h_out, d_out, sizeof(float) * (2 * kLattice + 1 + (size_t)nbeams_max), hipMemcpyDeviceToHost,
-                           e->stream));
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    // zero-copy I/O: the kernels read the 27 candidates from, and deliver their result to, pinned host memory
+    // mapped into the device; the host waits for the arrival flag instead of a copy + stream synchronisation
+    volatile uint32_t* h_flag = reinterpret_cast<volatile uint32_t*>(e->h_fm + kFmIn + kFmOut);
+    const uint32_t seq = ++e->fm_seq;
+    HIP_TRY(launch_lattice(e->stream, g, d_bx, d_by, nbeams_max, d_nbeams, e->d_hfm, e->fm_work.as<float>(), d_out,
+                           d_hits_persist, e->d_hfm + kFmIn, reinterpret_cast<uint32_t*>(e->d_hfm + kFmIn + kFmOut), seq));
+    {
+        bool arrived = false;
+        for (long spin = 0; spin < 400000000L; ++spin) {   // bounded: a few seconds at most
+            if (__atomic_load_n(h_flag, __ATOMIC_ACQUIRE) == seq) { arrived = true; break; }
+        }
+        if (!arrived) {   // the launch failed or the device is wedged: let the runtime tell us
+            HIP_TRY(hipStreamSynchronize(e->stream));
+            if (__atomic_load_n(h_flag, __ATOMIC_ACQUIRE) != seq) return fail_hip(e, hipErrorUnknown, "lattice result flag");
+        }
+    }
 
     // main.c:549-563 — strict '<' keeps the first of equal scores
     float best = INFINITY;

@@ -75,7 +75,9 @@ struct slam_engine {
 
     DevBuf fm_buf;             // kFmIn + kFmOut floats
     DevBuf fm_work;            // 27 x SLAM_MAX_BEAMS floats: per-candidate hit rows of the lattice kernel
-    float* h_fm = nullptr;     // pinned mirror
+    float* h_fm = nullptr;     // pinned + mapped: lattice candidates in, results out, then one uint32 arrival flag
+    float* d_hfm = nullptr;    // the same memory as the device sees it (zero-copy FastMatch I/O)
+    uint32_t fm_seq = 0;
     DevBuf scratch;            // per-call temporaries of the *_dev stages
     DevBuf bmax_buf;           // block maxima left by slam_logweight_dev (read by slam_quantise_scan_dev)
     int bmax_count = 0, bmax_n = -1;

@@ -45,9 +45,10 @@ hipError_t launch_pose_hits(hipStream_t stream, const ScoreGrid& g, const float*
 // work: device scratch of 27*nbeams floats.  out layout: score[27] | count[27] (int) | maxcount (int) | merged[nbeams]
 // d_nbeams (optional): the beam count lives on the device (<= nbeams, which then is the capacity / row stride).
 // persist (optional): device mirror of the caller's persistent hit scratch, updated like the host copy.
+// host_out / host_flag / seq (optional): also deliver `out` to mapped pinned host memory and release `seq`.
 hipError_t launch_lattice(hipStream_t stream, const ScoreGrid& g, const float* bx, const float* by, int nbeams,
                           const int32_t* d_nbeams, const float* cand_xycs /* X[27] Y[27] CT[27] ST[27] */, float* work,
-                          float* out, float* persist);
+                          float* out, float* persist, float* host_out, uint32_t* host_flag, uint32_t seq);
 
 // ---- mapper_kernels.hip (reference: main.c:71-198, 271-354, 941-953)
 hipError_t launch_clean_scan(hipStream_t s, const float* range, const float* cos_tab, const float* sin_tab, int nbeams,

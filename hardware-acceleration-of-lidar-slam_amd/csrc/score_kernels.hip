@@ -217,38 +217,60 @@ __global__ __launch_bounds__(64) void lattice_kernel(ScoreGrid g, const float* _
     const float lim_y = (float)(g.rows - 1);
     float* __restrict__ row = work + (size_t)c * nbeams_max;
     int base = 0;
-    for (int b0 = 0; b0 < nbeams; b0 += 64) {
-        const int b = b0 + lane;
-        bool in = false;
-        float h = 0.0f;
-        if (b < nbeams) {
-            const float qx = bx[b] * g.ipix, qy = by[b] * g.ipix;
-            const float rx = (qx * ct) + (qy * st);
-            const float ry = (qx * nst) + (qy * ct);
+    constexpr int kGroup = 8;   // 8 x 64 beams: all their gathers are in flight before the first is consumed
+    for (int b0 = 0; b0 < nbeams; b0 += 64 * kGroup) {
+        float h[kGroup], qx[kGroup], qy[kGroup];
+        bool in[kGroup];
+        // phase 1: the group's beams (coalesced loads, all issued before any is used)
+#pragma unroll
+        for (int k = 0; k < kGroup; ++k) {
+            const int b = b0 + 64 * k + lane;
+            const int bb = b < nbeams ? b : 0;
+            qx[k] = bx[bb];
+            qy[k] = by[bb];
+        }
+        // phase 2: cells and EDT gathers (out-of-bounds beams read cell 0 and are masked below)
+#pragma unroll
+        for (int k = 0; k < kGroup; ++k) {
+            const int b = b0 + 64 * k + lane;
+            const float px = qx[k] * g.ipix, py = qy[k] * g.ipix;
+            const float rx = (px * ct) + (py * st);
+            const float ry = (px * nst) + (py * ct);
             const float fx = round_half_away(rx + off_x);
             const float fy = round_half_away(ry + off_y);
-            in = (fx > 0.0f) & (fy > 0.0f) & (fx < lim_x) & (fy < lim_y);
-            if (in) h = g.edt[(int)fy * g.ld + (int)fx];
+            in[k] = (b < nbeams) & (fx > 0.0f) & (fy > 0.0f) & (fx < lim_x) & (fy < lim_y);
+            h[k] = g.edt[in[k] ? (int)fy * g.ld + (int)fx : 0];
         }
-        const unsigned long long mask = __ballot(in);
-        const int slot = base + __popcll(mask & ((1ull << lane) - 1ull));
-        if (in) {
-            s_hit[slot] = h;
-            row[slot] = h;
+        // phase 3: in-order slots
+#pragma unroll
+        for (int k = 0; k < kGroup; ++k) {
+            const unsigned long long mask = __ballot(in[k]);
+            const int slot = base + __popcll(mask & ((1ull << lane) - 1ull));
+            if (in[k]) {
+                s_hit[slot] = h[k];
+                row[slot] = h[k];
+            }
+            base += __popcll(mask);
         }
-        base += __popcll(mask);
     }
     __syncthreads();
     if (lane == 0) {
         float total = 0.0f;
+#pragma unroll 8
         for (int j = 0; j < base; ++j) total = total + s_hit[j];
         out[c] = total;
         reinterpret_cast<int32_t*>(out)[kLatticeN + c] = base;
     }
 }
 
+// host_out / host_flag (optional): zero-copy result delivery — the same words are also written to pinned host
+// memory mapped into the device, followed by a system-scope release of `seq` into *host_flag, so that the host
+// can pick the result up by polling instead of paying a device-to-host copy and a stream synchronisation
+// (a FastMatch call is latency-bound: ~40 us with copy + sync, ~20 us this way).
 __global__ __launch_bounds__(256) void lattice_merge_kernel(const float* __restrict__ work, int nbeams,
-                                                            float* __restrict__ out, float* __restrict__ persist)
+                                                            float* __restrict__ out, float* __restrict__ persist,
+                                                            float* __restrict__ host_out,
+                                                            uint32_t* __restrict__ host_flag, uint32_t seq)
 {
     __shared__ int s_cnt[kLatticeN];
     const int32_t* cnt = reinterpret_cast<const int32_t*>(out) + kLatticeN;
@@ -264,17 +286,26 @@ __global__ __launch_bounds__(256) void lattice_merge_kernel(const float* __restr
         const float v = work[(size_t)c * nbeams + j];
         merged[j] = v;
         if (persist) persist[j] = v;   // device-resident copy of the caller's persistent hit scratch
+        if (host_out) host_out[2 * kLatticeN + 1 + j] = v;
+    }
+    if (host_out) {
+        if (threadIdx.x < 2 * kLatticeN) host_out[threadIdx.x] = out[threadIdx.x];   // scores and counts (bit copies)
+        if (threadIdx.x == 0) reinterpret_cast<int32_t*>(host_out)[2 * kLatticeN] = maxc;
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(host_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
 }  // namespace
 
 hipError_t launch_lattice(hipStream_t stream, const ScoreGrid& g, const float* bx, const float* by, int nbeams,
-                          const int32_t* d_nbeams, const float* cand_xycs, float* work, float* out, float* persist)
+                          const int32_t* d_nbeams, const float* cand_xycs, float* work, float* out, float* persist,
+                          float* host_out, uint32_t* host_flag, uint32_t seq)
 {
     const size_t lds = sizeof(float) * (size_t)(nbeams > 0 ? nbeams : 1);
     lattice_kernel<<<kLatticeN, 64, lds, stream>>>(g, bx, by, nbeams, d_nbeams, cand_xycs, work, out);
-    lattice_merge_kernel<<<1, 256, 0, stream>>>(work, nbeams, out, persist);
+    lattice_merge_kernel<<<1, 256, 0, stream>>>(work, nbeams, out, persist, host_out, host_flag, seq);
     return hipGetLastError();
 }
 
