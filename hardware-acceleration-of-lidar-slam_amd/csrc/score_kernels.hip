@@ -156,6 +156,93 @@ __global__ __launch_bounds__(kScoreBlock) void score_poses_kernel(ScoreGrid g, c
     }
 }
 
+// Small batches (< ~8k poses): ONE WAVEFRONT PER POSE.  The 64 lanes gather 64 beams at a time (8 x 64 in flight),
+// park the hits — 0 for out-of-bounds beams, which leaves the sum's bits unchanged — in LDS in beam order, and
+// lane 0 adds them up in that order.  19 vs 45 us at 1k poses x 1024 beams, 30 vs 45 us at 4k; slower than the
+// quad form from ~8k poses on.
+template <bool HAS_CS, bool MOTION>
+__global__ __launch_bounds__(kScoreBlock) void score_poses_wave_kernel(ScoreGrid g, const float* __restrict__ bx,
+                                                                        const float* __restrict__ by, int nbeams,
+                                                                        float* __restrict__ px, float* __restrict__ py,
+                                                                        float* __restrict__ p2,
+                                                                        const float* __restrict__ p3, int nposes,
+                                                                        float* __restrict__ score,
+                                                                        int32_t* __restrict__ count, MotionIO mio,
+                                                                        MotionParams mpar)
+{
+    extern __shared__ float s_wave_hits[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int i = blockIdx.x * (kScoreBlock / 64) + wave;
+    if (i >= nposes) return;   // whole waves leave together; no workgroup barrier below
+    float* __restrict__ sh = s_wave_hits + (size_t)wave * nbeams;
+    float ct, st, pose_x, pose_y;
+    if constexpr (MOTION) {
+        const int j = mio.anc ? mio.anc[i] : i;
+        float pose_t;
+        motion_sample_one(mpar, (uint64_t)i, mio.sx[j], mio.sy[j], mio.sth[j], pose_x, pose_y, pose_t);
+        if (lane == 0) {
+            px[i] = pose_x;
+            py[i] = pose_y;
+            p2[i] = pose_t;
+        }
+        det_sincosf(pose_t, st, ct);
+    } else {
+        pose_x = px[i];
+        pose_y = py[i];
+        if (HAS_CS) {
+            ct = p2[i];
+            st = p3[i];
+        } else {
+            det_sincosf(p2[i], st, ct);
+        }
+    }
+    const float nst = -st;
+    const float off_x = (pose_x - g.min_x) * g.ipix;
+    const float off_y = (pose_y - g.min_y) * g.ipix;
+    const float lim_x = (float)(g.cols - 1);
+    const float lim_y = (float)(g.rows - 1);
+    int n_in = 0;
+    constexpr int kGroup = 8;
+    for (int b0 = 0; b0 < nbeams; b0 += 64 * kGroup) {
+        float qx[kGroup], qy[kGroup], h[kGroup];
+        bool in[kGroup];
+#pragma unroll
+        for (int k = 0; k < kGroup; ++k) {
+            const int b = b0 + 64 * k + lane;
+            const int bb = b < nbeams ? b : 0;
+            qx[k] = bx[bb];
+            qy[k] = by[bb];
+        }
+#pragma unroll
+        for (int k = 0; k < kGroup; ++k) {
+            const int b = b0 + 64 * k + lane;
+            const float x = qx[k] * g.ipix, y = qy[k] * g.ipix;
+            const float rx = (x * ct) + (y * st);
+            const float ry = (x * nst) + (y * ct);
+            const float fx = round_half_away(rx + off_x);
+            const float fy = round_half_away(ry + off_y);
+            in[k] = (b < nbeams) & (fx > 0.0f) & (fy > 0.0f) & (fx < lim_x) & (fy < lim_y);
+            h[k] = g.edt[in[k] ? (int)fy * g.ld + (int)fx : 0];
+        }
+#pragma unroll
+        for (int k = 0; k < kGroup; ++k) {
+            const int b = b0 + 64 * k + lane;
+            if (b < nbeams) sh[b] = in[k] ? h[k] : 0.0f;
+            n_in += __popcll(__ballot(in[k]));
+        }
+    }
+    // hand-off inside one wavefront: drain this wave's LDS writes, then lane 0 reads them
+    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
+        float total = 0.0f;
+#pragma unroll 8
+        for (int b = 0; b < nbeams; ++b) total = total + sh[b];
+        score[i] = total;
+        count[i] = n_in;
+    }
+}
+
 // One pose, hits written compacted in beam order (FastMatchParameters.bestHits, main.c:515).
 // Single wave: each step handles 64 consecutive beams; ballot + lane prefix give the in-order slot.
 __global__ __launch_bounds__(64) void pose_hits_kernel(ScoreGrid g, const float* __restrict__ bx,
@@ -313,6 +400,9 @@ namespace {
 // Pose-count threshold below which the 4-lanes-per-pose form wins (measured on MI355X, 360 beams:
 // 64k poses 43 vs 64 us; 128k poses equal; 256k poses 154 vs 125 us).
 constexpr int kQuadMaxPoses = 131072;
+// ... and below which one wavefront per pose wins over the quad form (1k poses 19 vs 45 us, 4k 30 vs 45 us,
+// 16k 74 vs 46 us at 1024 beams).
+constexpr int kWaveMaxPoses = 8192;
 
 template <bool MOTION>
 hipError_t launch_score_any(hipStream_t stream, const ScoreGrid& g, const float* bx, const float* by, int nbeams,
@@ -320,6 +410,19 @@ hipError_t launch_score_any(hipStream_t stream, const ScoreGrid& g, const float*
                             int32_t* count, const MotionIO& mio, const MotionParams& mpar, const EventPair* ev)
 {
     if (nposes <= 0) return hipSuccess;
+    if (nposes < kWaveMaxPoses) {   // one wavefront per pose
+        const int blocks = (nposes + kScoreBlock / 64 - 1) / (kScoreBlock / 64);
+        const size_t lds = sizeof(float) * (size_t)(kScoreBlock / 64) * (size_t)(nbeams > 0 ? nbeams : 1);
+        if (ev) (void)hipEventRecord(ev->start, stream);
+        if (st_or_null && !MOTION)
+            score_poses_wave_kernel<true, MOTION><<<blocks, kScoreBlock, lds, stream>>>(
+                g, bx, by, nbeams, x, y, th_or_ct, st_or_null, nposes, score, count, mio, mpar);
+        else
+            score_poses_wave_kernel<false, MOTION><<<blocks, kScoreBlock, lds, stream>>>(
+                g, bx, by, nbeams, x, y, th_or_ct, st_or_null, nposes, score, count, mio, mpar);
+        if (ev) (void)hipEventRecord(ev->stop, stream);
+        return hipGetLastError();
+    }
     const bool quad = nposes < kQuadMaxPoses;
     const long threads = quad ? 4L * nposes : nposes;
     const int blocks = (int)((threads + kScoreBlock - 1) / kScoreBlock);
