@@ -17,10 +17,13 @@
  * sine/cosine below is a Taylor kernel + three angle doublings), so the same command line gives
  * the same bytes on the build container and on the GPU box.  Build with -ffp-contract=off.
  *
- * usage: gen_dataset out.csv frames beams angle_min angle_inc seed [step_m turn_rad]
+ * usage: gen_dataset out.csv frames beams angle_min angle_inc seed [step_m turn_rad [world]]
  *        parity set : 1000 1079 -2.351831 0.004363 1            (arc, 4 mm + 0.6 mrad per frame)
  *        loop set   : 3480 1079 -2.351831 0.004363 2 0.004 0.0018  (one full 2.2 m-radius loop,
  *                     the frame count main_accelerated.c:6 is compiled for)
+ *        hall set   : 1000 1079 -2.351831 0.004363 3 0.012 0.0002 1  (world 1 = 34 x 20 m hall: the far end is
+ *                     beyond the 24 m usable range at first, so newly seen walls fall OUTSIDE the matcher's
+ *                     grid for a while — beams out of bounds, the Q2 hit-scratch quirk in action)
  *        bench sets use 360 beams over 2*pi
  */
 #include <stdio.h>
@@ -50,9 +53,11 @@ static void det_sincos(double a, double *s, double *c)
 
 typedef struct { double x0, y0, x1, y1; } box_t;
 
-/* room first (hit from inside), then obstacles (hit from outside) */
-static const box_t k_room = { -3.0, -5.5, 12.0, 5.5 };
-static const box_t k_obst[2] = { { 5.0, 2.0, 7.0, 3.5 }, { 2.0, -4.0, 3.0, -3.0 } };
+/* room first (hit from inside), then obstacles (hit from outside); world 0 = room, world 1 = long hall */
+static box_t k_room = { -3.0, -5.5, 12.0, 5.5 };
+static box_t k_obst[2] = { { 5.0, 2.0, 7.0, 3.5 }, { 2.0, -4.0, 3.0, -3.0 } };
+static const box_t k_hall = { -3.0, -10.0, 31.0, 10.0 };
+static const box_t k_hall_obst[2] = { { 9.0, 4.0, 11.0, 6.5 }, { 16.0, -7.0, 18.0, -5.0 } };
 
 static double ray_box(double ox, double oy, double dx, double dy, const box_t *b, double best)
 {
@@ -86,8 +91,8 @@ static uint32_t lcg_next(void)
 
 int main(int argc, char **argv)
 {
-    if (argc != 7 && argc != 9) {
-        fprintf(stderr, "usage: %s out.csv frames beams angle_min angle_inc seed [step_m turn_rad]\n", argv[0]);
+    if (argc != 7 && argc != 9 && argc != 10) {
+        fprintf(stderr, "usage: %s out.csv frames beams angle_min angle_inc seed [step_m turn_rad [world]]\n", argv[0]);
         return 2;
     }
     FILE *out = fopen(argv[1], "w");
@@ -97,8 +102,13 @@ int main(int argc, char **argv)
     const double amin = atof(argv[4]);
     const double ainc = atof(argv[5]);
     g_lcg = (uint32_t)strtoul(argv[6], NULL, 10) * 2654435761u + 12345u;
-    const double step = argc == 9 ? atof(argv[7]) : 0.004;
-    const double turn = argc == 9 ? atof(argv[8]) : 0.0006;
+    const double step = argc >= 9 ? atof(argv[7]) : 0.004;
+    const double turn = argc >= 9 ? atof(argv[8]) : 0.0006;
+    if (argc == 10 && atoi(argv[9]) == 1) {
+        k_room = k_hall;
+        k_obst[0] = k_hall_obst[0];
+        k_obst[1] = k_hall_obst[1];
+    }
 
     /* robot truth in the usual convention (heading phi, +CCW); the reference's theta is -phi */
     double px = 0.0, py = 0.0, phi = 0.0;

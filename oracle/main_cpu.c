@@ -49,9 +49,9 @@ int main(int argc, char **argv)
     double edt_s, match_s;
     long edt_calls, match_calls;
     orc_slam_timers(s, &edt_s, &edt_calls, &match_s, &match_calls);
-    fprintf(stderr, "frames %d  wall %.6f s  edt %.6f s / %ld calls  match %.6f s / %ld calls\n", frames,
-            (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec), edt_s, edt_calls, match_s,
-            match_calls);
+    fprintf(stderr, "frames %d  wall %.6f s  edt %.6f s / %ld calls  match %.6f s / %ld calls  partial-inbounds frames %ld\n",
+            frames, (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec), edt_s, edt_calls, match_s,
+            match_calls, orc_slam_partial_frames(s));
 
     FILE *out = fopen(argv[5], "w");
     if (!out) { perror(argv[5]); return 1; }

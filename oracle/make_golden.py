@@ -13,6 +13,8 @@ What it writes (SURVEY.md §8c "Fixtures to commit"):
   tests/golden/parity_map.csv       its map_output.csv
   tests/golden/loop_pose.txt        same for Subsystem_1/main_accelerated.c, 3480 frames
   tests/golden/loop_map.csv
+  tests/golden/hall_pose.txt        Subsystem_1/main.c on the "hall" set (out-of-bounds beams on ~390 frames)
+  tests/golden/hall_map.csv
   tests/golden/frames_head.csv      first 3 text frames of the parity set (parser fixture)
   tests/golden/functions.npz        per-function inputs/outputs: angle table, scan clean-up,
                                     transform, local map, raster, EDT (both reference variants),
@@ -41,6 +43,9 @@ NB = 1079
 DATASETS = {
     "parity": ["1000", str(NB), "-2.351831", "0.004363", "1"],
     "loop": ["3480", str(NB), "-2.351831", "0.004363", "2", "0.004", "0.0018"],
+    # 34 x 20 m hall whose far end starts beyond the 24 m usable range: ~390 of the 1000 frames match with
+    # beams outside the grid, i.e. the hit-scratch quirk shapes the map that the run builds
+    "hall": ["1000", str(NB), "-2.351831", "0.004363", "3", "0.012", "0.0002", "1"],
 }
 
 
@@ -116,7 +121,7 @@ def whole_program(tmp: Path, out: dict):
         oracle.run_tool("gen_dataset", csv, *args)
         out[name] = {"gen_args": args, "sha256": sha256(csv), "bytes": csv.stat().st_size}
     env = dict(os.environ)
-    for name, exe in (("parity", "main_ref"), ("loop", "main_accel_ref")):
+    for name, exe in (("parity", "main_ref"), ("loop", "main_accel_ref"), ("hall", "main_ref")):
         env["ORACLE_DATASET"] = str(tmp / f"{name}.csv")
         env["ORACLE_MAP_OUT"] = str(GOLD / f"{name}_map.csv")
         r = subprocess.run([str(oracle.REF / exe)], env=env, check=True, capture_output=True, text=True)

@@ -320,6 +320,7 @@ struct orc_slam {
     int edt_variant;
     double edt_s, match_s;
     long edt_calls, match_calls;
+    long partial_frames;   /* frames whose best candidate had beams out of bounds (the Q2 quirk matters there) */
 };
 
 static double now_s(void)
@@ -368,6 +369,8 @@ void orc_slam_set_edt_variant(orc_slam *s, int v) { s->edt_variant = v; }
 int orc_slam_map_size(const orc_slam *s) { return s->map_n; }
 const float *orc_slam_map_x(const orc_slam *s) { return s->map_x; }
 const float *orc_slam_map_y(const orc_slam *s) { return s->map_y; }
+
+long orc_slam_partial_frames(const orc_slam *s) { return s->partial_frames; }
 
 void orc_slam_timers(const orc_slam *s, double *edt_s, long *edt_calls, double *match_s, long *match_calls)
 {
@@ -439,6 +442,7 @@ void orc_slam_next_frame(orc_slam *s, const float *ranges, float pose_out[3])
     match(s, 1, m1, fine, m2);
     memcpy(s->prev, s->pose, sizeof s->prev);
     memcpy(s->pose, m2, sizeof s->pose);
+    if (s->hits_n < s->scan_n) s->partial_frames++;
 
     /* main.c:928-961 — per-axis key-frame test against the pose of the last map update */
     const float dx = fabsf(s->pose[0] - s->map_pose[0]);

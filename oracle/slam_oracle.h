@@ -109,6 +109,8 @@ void orc_slam_next_frame(orc_slam *s, const float *ranges, float pose_out[3]);
 int orc_slam_map_size(const orc_slam *s);
 const float *orc_slam_map_x(const orc_slam *s);
 const float *orc_slam_map_y(const orc_slam *s);
+/* frames whose matched pose had beams outside the grid (where SURVEY Q2's hit-scratch quirk has an effect) */
+long orc_slam_partial_frames(const orc_slam *s);
 /* instrumentation for the CPU baseline: seconds spent and calls made in EDT / matcher */
 void orc_slam_timers(const orc_slam *s, double *edt_s, long *edt_calls, double *match_s, long *match_calls);
 

@@ -287,7 +287,7 @@ def test_score_edge_cases(eng, golden):
 
 
 # ------------------------------------------------------------------ A8: whole program on the engine
-@pytest.mark.parametrize("name,frames", [("parity", 1000), ("loop", 3480)])
+@pytest.mark.parametrize("name,frames", [("parity", 1000), ("loop", 3480), ("hall", 1000)])
 def test_slam_main_matches_reference_logs(orc, tmp_path, name, frames):
     """The C host program (reference frame loop + engine) reproduces the reference programs' stdout
     pose lines and map file byte for byte: parity = Subsystem_1/main.c, loop = main_accelerated.c."""
@@ -303,7 +303,7 @@ def test_slam_main_matches_reference_logs(orc, tmp_path, name, frames):
     print(r.stderr.strip())
 
 
-@pytest.mark.parametrize("name,frames", [("parity", 1000), ("loop", 3480)])
+@pytest.mark.parametrize("name,frames", [("parity", 1000), ("loop", 3480), ("hall", 1000)])
 def test_device_resident_mapper_matches_reference_logs(orc, tmp_path, name, frames):
     """slam_mapper_* (scan clean-up, local map, rasters, EDTs, matcher and map update
     with all state on the device) reproduces the reference programs' pose log and map byte for byte."""
