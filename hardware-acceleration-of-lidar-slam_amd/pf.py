@@ -104,16 +104,19 @@ class ParticleFilter:
 
     def __init__(self, ops, n_local: int, nlandmarks: int = 0, *, device, rank: int = 0, world: int = 1, group=None,
                  seed: int = 1, sigma=(0.01, 0.01, 0.002), meas_var: float = 0.01, score_gain: float = 1.0,
-                 grid_slot: int = 0, recv_capacity: int | None = None):
+                 grid_slot: int = 0, recv_capacity: int | None = None, force_collectives: bool = False):
         self.ops, self.n, self.L = ops, int(n_local), int(nlandmarks)
         self.rank, self.world, self.group = rank, world, group
+        # force_collectives: take the multi-GPU code path (every collective, the sharded kernels) even with one
+        # rank — lets a single GPU exercise the RCCL calls themselves
+        self.multi = world > 1 or force_collectives
         self.n_total = self.n * world
         if self.n_total >= 2**31:
             raise ValueError("total particle count must stay below 2^31 (int32 ancestor indices)")
         self.device = torch.device(device)
         self.seed, self.sigma, self.meas_var, self.score_gain = seed, tuple(sigma), meas_var, score_gain
         self.grid_slot = grid_slot
-        self.recv_cap = 0 if world == 1 else (self.n if recv_capacity is None else int(recv_capacity))
+        self.recv_cap = 0 if not self.multi else (self.n if recv_capacity is None else int(recv_capacity))
         self.cap = self.n + self.recv_cap
         dv = self.device
         f32, i32, i64 = torch.float32, torch.int32, torch.int64
@@ -126,7 +129,7 @@ class ParticleFilter:
         self.loglik = torch.zeros(self.n, dtype=f32, device=dv)
         self.logw = torch.zeros(self.n, dtype=f32, device=dv)
         self.first = torch.zeros(self.n, dtype=i32, device=dv)
-        self.first_all = self.first if world == 1 else torch.zeros(self.n_total, dtype=i32, device=dv)
+        self.first_all = self.first if not self.multi else torch.zeros(self.n_total, dtype=i32, device=dv)
         self.anc = torch.zeros((2, self.n), dtype=i32, device=dv)                # double-buffered: the fused gathers
         self.d_max = torch.zeros(1, dtype=f32, device=dv)                         # of frame t+1 read frame t's indices
         self.d_sum = torch.zeros(1, dtype=i64, device=dv)
@@ -136,7 +139,7 @@ class ParticleFilter:
         self.migrated_last = 0
         # gloo cannot move GPU tensors for every collective used here: stage them through the host then
         # (functional rehearsal of the multi-rank path on one card; the production backend is nccl = RCCL)
-        self._host_staged = world > 1 and self.device.type == "cuda" and dist.get_backend(group) == "gloo"
+        self._host_staged = self.multi and self.device.type == "cuda" and dist.get_backend(group) == "gloo"
         if hasattr(ops, "bind_stream"):
             ops.bind_stream()
 
@@ -209,7 +212,7 @@ class ParticleFilter:
             o.gather_map(self.map[cur], self.map[nxt], self.L * self.cap, self.L * self.cap, self.cap, self.cap,
                          self.L, idx, n)
         # 4. weights (fused form: the fixed-point weights are scanned as they are produced, never stored)
-        multi = self.world > 1
+        multi = self.multi
         if use_ll:
             o.logweight_ekf(self.score, self.score_gain, n, self.logw, self.d_max if multi else None)
         else:
@@ -257,7 +260,7 @@ class ParticleFilter:
         staging tail of the current buffers, where the next frame's fused gathers pick them up."""
         o, n, r, G, dv, L = self.ops, self.n, self.rank, self.world, self.device, self.L
         send, recv, anything = self._plan()
-        if not anything:   # every run boundary coincides with a rank boundary: no collective needed this frame
+        if not anything and self.world > 1:   # every run boundary coincides with a rank boundary: all ranks skip
             self.migrated_last = 0
             return
         scnt = [hi - lo for lo, hi in send]

@@ -466,3 +466,55 @@ def test_full_size_resample_8m_vs_oracle(eng, orc):
     cnt = np.bincount(got, minlength=n)
     assert cnt.sum() == n and (cnt[w == 0] == 0).all()
     assert (np.abs(cnt - n * w.astype(np.float64) / total) < 1.0 + 1e-6).all()
+
+
+def test_rccl_collectives_single_rank(eng, orc, tmp_path):
+    """The multi-GPU code path over the real RCCL backend, as far as one GPU allows: a world_size-1 `nccl` group,
+    every collective of the frame loop issued for real (all-reduce MAX on float32, all-gather of int64 totals and of
+    int32 offsets, all-to-all with empty splits), the sharded kernels used instead of the single-GPU ones — and the
+    result must equal the plain single-GPU path bit for bit."""
+    import socket
+    import subprocess
+    import sys
+    import textwrap
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    script = tmp_path / "rccl_one_rank.py"
+    script.write_text(textwrap.dedent(f"""
+        import os, sys
+        sys.path.insert(0, {str(__import__('pathlib').Path(__file__).resolve().parents[1])!r}); sys.path.insert(0, {str(__import__('pathlib').Path(__file__).resolve().parent)!r})
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="{port}")
+        import numpy as np, torch, torch.distributed as dist
+        import _shard_worker as W
+        from __graft_entry__ import load_package
+        pkg = load_package()
+        from hardware_acceleration_of_lidar_slam_amd.pf import HipOps, ParticleFilter
+        dev = torch.device("cuda", 0); torch.cuda.set_device(dev)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        L, n, frames = 6, 8192, 5
+        meta, edt, bx, by, lm = W.make_world(L=L)
+        eng = pkg.Engine(0); eng.set_stream(torch.cuda.current_stream().cuda_stream)
+        d_edt = torch.from_numpy(edt).to(dev)
+        eng.grid_set_dev(0, d_edt, pkg.grid_meta(meta.rows, meta.cols, meta.ld, meta.pixel, meta.min_x, meta.min_y))
+        eng.scan_upload(bx, by)
+        x, y, th, mp = W.init_state(n, L, lm)
+        out = []
+        for force in (False, True):
+            pf = ParticleFilter(HipOps(eng), n, L, device=dev, seed=77, sigma=(0.02, 0.02, 0.004), meas_var=0.02,
+                                score_gain=0.05, force_collectives=force)
+            pf.set_poses(x, y, th); pf.set_map(mp)
+            for f in range(frames):
+                pf.step([0.01, -0.005, 0.002], W.observations(lm, f))
+            torch.cuda.synchronize()
+            out.append((pf.poses().cpu().numpy(), pf.maps().cpu().numpy(), pf.logw.cpu().numpy(), pf.best_particle()))
+        dist.destroy_process_group()
+        a, b = out
+        assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32)), "poses differ"
+        assert np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32)), "maps differ"
+        assert np.array_equal(a[2].view(np.uint32), b[2].view(np.uint32)) and a[3] == b[3]
+        print("RCCL single-rank path == single-GPU path")
+    """))
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "RCCL single-rank path == single-GPU path" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
