@@ -127,12 +127,12 @@ def cpu_baseline(args, occ, meta_t, frames, landmarks, budget_s=12.0):
     y = (p0[1] + rng.normal(0, 0.05, n)).astype(np.float32)
     th = (p0[2] + rng.normal(0, 0.01, n)).astype(np.float32)
     L = len(landmarks)
-    mp = np.zeros((5, max(L, 1), n), np.float32)
+    mp = np.zeros((n, 5, max(L, 1)), np.float32)   # one row per particle, like the engine
     if L:
-        mp[0] = landmarks[:, 0:1] + rng.normal(0, 0.1, (L, n))
-        mp[1] = landmarks[:, 1:2] + rng.normal(0, 0.1, (L, n))
-        mp[2] = 0.05
-        mp[4] = 0.05
+        mp[:, 0] = landmarks[:, 0] + rng.normal(0, 0.1, (n, L))
+        mp[:, 1] = landmarks[:, 1] + rng.normal(0, 0.1, (n, L))
+        mp[:, 2] = 0.05
+        mp[:, 4] = 0.05
     anc = None
     done = 0
     t0 = time.perf_counter()
@@ -171,6 +171,8 @@ def main():
     ap.add_argument("--host-sensor", action="store_true", help="upload scan + observations from the host every frame")
     ap.add_argument("--events", choices=["dominant", "all", "none"], default="dominant",
                     help="kernels bracketed by HIP events inside the timed region (a pair costs a few us of stream time)")
+    ap.add_argument("--stats", action="store_true",
+                    help="diagnostics: print the number of distinct resample ancestors per frame (synchronises; not for timing)")
     args = ap.parse_args()
     args.sigma = (0.01, 0.01, 0.002)
     args.meas_var = 0.02 ** 2 * 4
@@ -231,19 +233,22 @@ def main():
                  p0[2] + 0.01 * torch.randn(n, generator=g))
     if L:
         lm = torch.from_numpy(landmarks.astype(np.float32)).to(dev)
-        m0 = pf.map[pf.cur]
-        m0[0, :, :n] = lm[:, 0:1] + 0.1 * torch.randn((L, n), device=dev)
-        m0[1, :, :n] = lm[:, 1:2] + 0.1 * torch.randn((L, n), device=dev)
-        m0[2, :, :n] = 0.05
-        m0[3, :, :n] = 0.0
-        m0[4, :, :n] = 0.05
+        m0 = pf.map[pf.cur]                               # [particle][plane][Lp]
+        m0[:n, 0, :L] = lm[:, 0] + 0.1 * torch.randn((n, L), device=dev)
+        m0[:n, 1, :L] = lm[:, 1] + 0.1 * torch.randn((n, L), device=dev)
+        m0[:n, 2, :L] = 0.05
+        m0[:n, 3, :L] = 0.0
+        m0[:n, 4, :L] = 0.05
 
     # sensor data of every frame resident in HBM before the timed region (bench contract); --host-sensor
     # uploads it frame by frame through the host-buffer entry points instead (8.9 KB per frame over PCIe)
     d_scan = torch.from_numpy(np.stack([np.stack([f["bx"], f["by"]]) for f in frames])).to(dev)        # [F][2][B]
-    if L:
-        d_ids = torch.from_numpy(np.stack([f["ids"] for f in frames])).to(dev)                           # [F][L]
-        d_z = torch.from_numpy(np.stack([np.stack([f["zx"], f["zy"]]) for f in frames])).to(dev)       # [F][2][L]
+    if L:   # observation tables indexed by landmark (NaN = not observed; here every landmark is observed)
+        tab = np.full((len(frames), 2, L), np.nan, np.float32)
+        for k, f in enumerate(frames):
+            tab[k, 0, f["ids"]] = f["zx"]
+            tab[k, 1, f["ids"]] = f["zy"]
+        d_z = torch.from_numpy(tab).to(dev)                                                              # [F][2][L]
 
     def one_step(k):
         fr = frames[k]
@@ -252,9 +257,13 @@ def main():
             obs, obs_dev = ((fr["ids"], fr["zx"], fr["zy"]) if L else None), None
         else:
             eng.scan_set_dev(d_scan[k, 0], d_scan[k, 1], args.beams)
-            obs, obs_dev = None, ((d_ids[k], d_z[k, 0], d_z[k, 1], L, None, 0) if L else None)
+            obs, obs_dev = None, ((d_z[k, 0], d_z[k, 1]) if L else None)
         if args.mode == "pf":
             pf.step(fr["dp"], obs, obs_dev)
+            if args.stats:
+                w = torch.exp((pf.logw - pf.logw.max()).double())
+                print(f"[stats] rank {rank} frame {k}: distinct ancestors {torch.unique(pf.src_idx).numel()} of {n}, "
+                      f"ESS {float(w.sum() ** 2 / (w * w).sum()):.1f}, received rows {pf.migrated_last}", file=sys.stderr)
         elif args.mode == "score":
             p = pf.pose[0]
             eng.score_poses_dev(0, p[0], p[1], p[2], n, pf.score, pf.count)
@@ -264,7 +273,7 @@ def main():
                 eng.obs_set_dev(*obs_dev, L)
             else:
                 eng.obs_upload(*obs, L)
-            eng.ekf_update_dev(pf.map[k & 1], pf.map[1 - (k & 1)], L * pf.cap, pf.cap, L, p[0], p[1], p[2], None, n,
+            eng.ekf_update_dev(pf.map[k & 1], pf.map[1 - (k & 1)], 5 * pf.Lp, pf.Lp, L, p[0], p[1], p[2], None, n,
                                args.meas_var, pf.loglik)
 
     def barrier():
@@ -281,9 +290,11 @@ def main():
     eng.profile_enable(*timed)
     for kk in (eng.PROF_SCORE, eng.PROF_EKF):
         eng.profile_read(kk)
+    migrated = 0
     t0 = time.perf_counter()
     for k in range(args.warmup, args.warmup + args.steps):
         one_step(k)
+        migrated += pf.migrated_last
     barrier()
     elapsed = time.perf_counter() - t0
     eng.profile_enable()
@@ -291,6 +302,9 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t[0])
+        t[0] = migrated / max(args.steps, 1)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        migrated = float(t[0])
 
     score_ms, score_n = eng.profile_read(eng.PROF_SCORE)
     ekf_ms, ekf_n = eng.profile_read(eng.PROF_EKF)
@@ -339,7 +353,8 @@ def main():
                                       "EKF over all landmarks, weights, resample)",
                                 "score": "scan-match score only", "ekf": "EKF sweep only"}[args.mode],
                    "mode": args.mode, "particles_per_gpu": n, "particles_total": n_total, "beams": args.beams,
-                   "landmarks": L, "edt_grid": f"{args.grid}x{args.grid}", "parallelism": f"particle-shard x{world}"},
+                   "landmarks": L, "edt_grid": f"{args.grid}x{args.grid}", "parallelism": f"particle-shard x{world}",
+                   "rows_received_per_frame_max_rank": migrated if world > 1 else 0},
         "roofline": {"bound": "hbm", "kernel": kern, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": alg,
                      "avg_launch_ms": dur_ms, "avg_event_bracket_ms": raw_ms,

@@ -74,7 +74,7 @@ SIGNATURES = {
     "slam_motion_sample_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _fp, _fp, _u64, _u32]),
     "slam_motion_score_dev": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _fp, _fp, _u64, _u32, _vp, _vp]),
     "slam_obs_upload_host": (_i, [_vp, _vp, _vp, _vp, _i, _i]),
-    "slam_obs_set_dev": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _i, _i]),
+    "slam_obs_set_dev": (_i, [_vp, _vp, _vp, _i]),
     "slam_logweight_ekf_dev": (_i, [_vp, _vp, _f, _i, _vp, _vp]),
     "slam_ekf_update_dev": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _i, _f, _vp]),
     "slam_logweight_dev": (_i, [_vp, _vp, _vp, _f, _i, _vp, _vp]),
@@ -293,9 +293,10 @@ class Engine:
                                                 _ptr(dst[0]), _ptr(dst[1]), _ptr(dst[2]), n, first_id, _f3(dp),
                                                 _f3(sigma), seed, frame, _ptr(d_score), _ptr(d_count)), "motion_score_dev")
 
-    def obs_set_dev(self, d_ids, d_zx, d_zy, nobs, d_unobs, nunobs, nlandmarks):
-        self._ck(self.lib.slam_obs_set_dev(self.h, _ptr(d_ids), _ptr(d_zx), _ptr(d_zy), nobs, _ptr(d_unobs), nunobs,
-                                           nlandmarks), "obs_set_dev")
+    def obs_set_dev(self, d_zx_by_landmark, d_zy_by_landmark, nlandmarks):
+        """Observation table on the device: entry l = observation of landmark l, NaN in zx = not observed."""
+        self._ck(self.lib.slam_obs_set_dev(self.h, _ptr(d_zx_by_landmark), _ptr(d_zy_by_landmark), nlandmarks),
+                 "obs_set_dev")
 
     def logweight_ekf_dev(self, d_score, gain, n, d_logw, d_max):
         self._ck(self.lib.slam_logweight_ekf_dev(self.h, _ptr(d_score), gain, n, _ptr(d_logw), _ptr(d_max)),
@@ -306,9 +307,10 @@ class Engine:
         self._ck(self.lib.slam_obs_upload_host(self.h, _ptr(ids), _ptr(zx), _ptr(zy), len(ids), nlandmarks),
                  "obs_upload")
 
-    def ekf_update_dev(self, d_map_in, d_map_out, plane_stride, ld_map, nlandmarks, d_x, d_y, d_th, d_anc, n, meas_var,
+    def ekf_update_dev(self, d_map_in, d_map_out, row_stride, plane_stride, nlandmarks, d_x, d_y, d_th, d_anc, n, meas_var,
                        d_loglik):
-        self._ck(self.lib.slam_ekf_update_dev(self.h, _ptr(d_map_in), _ptr(d_map_out), plane_stride, ld_map, nlandmarks,
+        """Maps are one row per particle: [particle][5 planes][plane_stride] floats (include/slam_hip.h)."""
+        self._ck(self.lib.slam_ekf_update_dev(self.h, _ptr(d_map_in), _ptr(d_map_out), row_stride, plane_stride, nlandmarks,
                                               _ptr(d_x), _ptr(d_y), _ptr(d_th), _ptr(d_anc), n, meas_var,
                                               _ptr(d_loglik)), "ekf_update_dev")
 
@@ -347,24 +349,26 @@ class Engine:
                                                      _ptr(d_src)), "ancestors_sharded_dev")
 
     def migrate_pack_dev(self, d_first_all, n_total, n_local, rank, world, send_lo, send_cnt, d_pose, pose_ld, d_map,
-                         plane_stride, ld_map, nlandmarks, d_out):
+                         row_stride, plane_stride, nlandmarks, d_out):
         lo, cnt = _np(send_lo, np.int64), _np(send_cnt, np.int32)
         self._ck(self.lib.slam_migrate_pack_dev(self.h, _ptr(d_first_all), n_total, n_local, rank, world, _ptr(lo),
-                                                _ptr(cnt), _ptr(d_pose), pose_ld, _ptr(d_map), plane_stride, ld_map,
+                                                _ptr(cnt), _ptr(d_pose), pose_ld, _ptr(d_map), row_stride, plane_stride,
                                                 nlandmarks, _ptr(d_out)), "migrate_pack_dev")
 
-    def migrate_unpack_dev(self, d_in, world, recv_cnt, n_local, d_pose, pose_ld, d_map, plane_stride, ld_map,
+    def migrate_unpack_dev(self, d_in, world, recv_cnt, n_local, d_pose, pose_ld, d_map, row_stride, plane_stride,
                            nlandmarks):
         cnt = _np(recv_cnt, np.int32)
         self._ck(self.lib.slam_migrate_unpack_dev(self.h, _ptr(d_in), world, _ptr(cnt), n_local, _ptr(d_pose), pose_ld,
-                                                  _ptr(d_map), plane_stride, ld_map, nlandmarks), "migrate_unpack_dev")
+                                                  _ptr(d_map), row_stride, plane_stride, nlandmarks), "migrate_unpack_dev")
 
     def gather_f32_dev(self, d_src, d_idx, n, d_dst):
         self._ck(self.lib.slam_gather_f32_dev(self.h, _ptr(d_src), _ptr(d_idx), n, _ptr(d_dst)), "gather_f32_dev")
 
-    def gather_map_dev(self, d_in, d_out, in_stride, out_stride, ld_in, ld_out, nlandmarks, d_idx, n):
-        self._ck(self.lib.slam_gather_map_dev(self.h, _ptr(d_in), _ptr(d_out), in_stride, out_stride, ld_in, ld_out,
-                                              nlandmarks, _ptr(d_idx), n), "gather_map_dev")
+    def gather_map_dev(self, d_in, d_out, in_row_stride, out_row_stride, in_plane_stride, out_plane_stride, nlandmarks,
+                       d_idx, n):
+        self._ck(self.lib.slam_gather_map_dev(self.h, _ptr(d_in), _ptr(d_out), in_row_stride, out_row_stride,
+                                              in_plane_stride, out_plane_stride, nlandmarks, _ptr(d_idx), n),
+                 "gather_map_dev")
 
 
 class PfConfig(C.Structure):
@@ -397,10 +401,11 @@ class PfSession:
         x, y, th = (_np(a, np.float32) for a in (x, y, th))
         self.e._ck(self.e.lib.slam_pf_set_poses_host(self.h, _ptr(x), _ptr(y), _ptr(th)), "pf_set_poses")
 
-    def set_map(self, planes):
-        planes = _np(planes, np.float32)
-        assert planes.shape == (5, self.L, self.n)
-        self.e._ck(self.e.lib.slam_pf_set_map_host(self.h, _ptr(planes)), "pf_set_map")
+    def set_map(self, rows):
+        """rows: float32 [n_particles][5][n_landmarks] (mu_x, mu_y, P_xx, P_xy, P_yy)"""
+        rows = _np(rows, np.float32)
+        assert rows.shape == (self.n, 5, self.L)
+        self.e._ck(self.e.lib.slam_pf_set_map_host(self.h, _ptr(rows)), "pf_set_map")
 
     def step(self, slot, dp, use_observations=False):
         self.e._ck(self.e.lib.slam_pf_step(self.h, slot, _f3(dp), 1 if use_observations else 0), "pf_step")
@@ -417,7 +422,7 @@ class PfSession:
         return np.stack([x, y, th])
 
     def maps(self):
-        m = np.empty((5, self.L, self.n), np.float32)
+        m = np.empty((self.n, 5, self.L), np.float32)
         self.e._ck(self.e.lib.slam_pf_get_map_host(self.h, _ptr(m)), "pf_get_map")
         return m
 

@@ -13,6 +13,7 @@
 #include <string.h>
 
 #include <new>
+#include <limits>
 #include <vector>
 
 #include "engine_internal.h"
@@ -555,116 +556,91 @@ int slam_obs_upload_host(slam_engine* e, const int32_t* landmark_id, const float
                          int nlandmarks)
 {
     ENTER(e);
-    if (nobs < 0 || nlandmarks < 0 || (nobs > 0 && (!landmark_id || !zx || !zy))) return SLAM_ERR_INVALID_ARG;
-    if (nobs > SLAM_MAX_OBS) return SLAM_ERR_CAPACITY;
-    std::vector<char> seen((size_t)nlandmarks, 0);
-    for (int k = 0; k < nobs; ++k) {
+    if (nobs < 0 || nlandmarks < 0 || nobs > nlandmarks || (nobs > 0 && (!landmark_id || !zx || !zy)))
+        return SLAM_ERR_INVALID_ARG;
+    if (nlandmarks > SLAM_MAX_OBS) return SLAM_ERR_CAPACITY;
+    // the engine works on a table indexed by landmark: zx[l], zy[l], NaN = no observation of l this frame
+    float* h = e->stage_acquire();
+    const size_t L = (size_t)nlandmarks;
+    float* hx = h;
+    float* hy = h + L;
+    const float nan = std::numeric_limits<float>::quiet_NaN();
+    for (size_t l = 0; l < L; ++l) hx[l] = hy[l] = nan;
+    int rc = SLAM_OK;
+    for (int k = 0; k < nobs && rc == SLAM_OK; ++k) {
         const int32_t id = landmark_id[k];
-        if (id < 0 || id >= nlandmarks || seen[id]) return SLAM_ERR_INVALID_ARG;
-        seen[id] = 1;
+        if (id < 0 || id >= nlandmarks || hx[id] == hx[id] || zx[k] != zx[k] || zy[k] != zy[k])
+            rc = SLAM_ERR_INVALID_ARG;   // out of range, listed twice, or a NaN measurement
+        else {
+            hx[id] = zx[k];
+            hy[id] = zy[k];
+        }
     }
-    std::vector<int32_t> unobs;
-    unobs.reserve((size_t)(nlandmarks - nobs));
-    for (int l = 0; l < nlandmarks; ++l)
-        if (!seen[l]) unobs.push_back(l);
-    const size_t words = 3 * (size_t)SLAM_MAX_OBS + (size_t)nlandmarks;
-    if (e->obs_buf.cap < words * 4) {
-        HIP_TRY(hipStreamSynchronize(e->stream));   // a running kernel may still read the old list
-        HIP_TRY(e->obs_buf.ensure(words * 4));
+    if (rc != SLAM_OK) {
+        (void)e->stage_release(h);   // nothing was queued from this slot
+        return rc;
     }
-    int32_t* d_id = e->obs_buf.as<int32_t>();
-    float* d_zx = e->obs_buf.as<float>() + nobs;
-    float* d_zy = e->obs_buf.as<float>() + 2 * nobs;
-    int32_t* d_un = e->obs_buf.as<int32_t>() + 3 * SLAM_MAX_OBS;
-    if (nobs > 0) {   // ids | zx | zy packed into one pinned block -> one copy
-        float* h = e->stage_acquire();
-        memcpy(h, landmark_id, sizeof(int32_t) * nobs);
-        memcpy(h + nobs, zx, sizeof(float) * nobs);
-        memcpy(h + 2 * nobs, zy, sizeof(float) * nobs);
-        HIP_TRY(hipMemcpyAsync(d_id, h, sizeof(float) * 3 * nobs, hipMemcpyHostToDevice, e->stream));
-        HIP_TRY(e->stage_release(h));
+    if (e->obs_buf.cap < 2 * L * 4) {
+        HIP_TRY(hipStreamSynchronize(e->stream));   // a running kernel may still read the old table
+        HIP_TRY(e->obs_buf.ensure(2 * L * 4 > 8 ? 2 * L * 4 : 8));
     }
-    if (!unobs.empty()) {
-        HIP_TRY(hipMemcpyAsync(d_un, unobs.data(), sizeof(int32_t) * unobs.size(), hipMemcpyHostToDevice, e->stream));
-        HIP_TRY(hipStreamSynchronize(e->stream));   // `unobs` is a stack-lifetime pageable buffer
-    }
-    e->d_obs_id = d_id;
-    e->d_obs_zx = d_zx;
-    e->d_obs_zy = d_zy;
-    e->d_unobs_id = d_un;
-    e->nobs = nobs;
-    e->nunobs = (int)unobs.size();
+    if (L > 0) HIP_TRY(hipMemcpyAsync(e->obs_buf.as<float>(), h, sizeof(float) * 2 * L, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(e->stage_release(h));
+    e->d_obs_zx = e->obs_buf.as<float>();
+    e->d_obs_zy = e->obs_buf.as<float>() + L;
     e->obs_nlandmarks = nlandmarks;
     return SLAM_OK;
 }
 
-int slam_obs_set_dev(slam_engine* e, const int32_t* d_landmark_id, const float* d_zx, const float* d_zy, int nobs,
-                     const int32_t* d_unobserved_id, int nunobserved, int nlandmarks)
+int slam_obs_set_dev(slam_engine* e, const float* d_zx_by_landmark, const float* d_zy_by_landmark, int nlandmarks)
 {
     ENTER(e);
-    if (nobs < 0 || nunobserved < 0 || nlandmarks < 0 || nobs + nunobserved != nlandmarks ||
-        (nobs > 0 && (!d_landmark_id || !d_zx || !d_zy)) || (nunobserved > 0 && !d_unobserved_id))
-        return SLAM_ERR_INVALID_ARG;
-    if (nobs > SLAM_MAX_OBS) return SLAM_ERR_CAPACITY;
-    e->d_obs_id = d_landmark_id;
-    e->d_obs_zx = d_zx;
-    e->d_obs_zy = d_zy;
-    e->d_unobs_id = d_unobserved_id;
-    e->nobs = nobs;
-    e->nunobs = nunobserved;
+    if (nlandmarks < 0 || (nlandmarks > 0 && (!d_zx_by_landmark || !d_zy_by_landmark))) return SLAM_ERR_INVALID_ARG;
+    e->d_obs_zx = d_zx_by_landmark;
+    e->d_obs_zy = d_zy_by_landmark;
     e->obs_nlandmarks = nlandmarks;
     return SLAM_OK;
 }
 
-int slam_ekf_update_dev(slam_engine* e, const float* d_map_in, float* d_map_out, int64_t plane_stride, int ld_map,
+int slam_ekf_update_dev(slam_engine* e, const float* d_map_in, float* d_map_out, int64_t row_stride, int plane_stride,
                         int nlandmarks, const float* d_x, const float* d_y, const float* d_th, const int32_t* d_anc,
                         int n, float meas_var, float* d_loglik)
 {
     ENTER(e);
-    if (n < 0 || nlandmarks < 0 || ld_map < n || plane_stride < (int64_t)nlandmarks * ld_map || !(meas_var > 0.0f) ||
-        (n > 0 && (!d_map_in || !d_map_out || !d_x || !d_y || !d_th)))
+    if (n < 0 || nlandmarks < 0 || plane_stride < nlandmarks || row_stride < 5 * (int64_t)plane_stride ||
+        !(meas_var > 0.0f) || (n > 0 && (!d_map_in || !d_map_out || !d_x || !d_y || !d_th)))
         return SLAM_ERR_INVALID_ARG;
     if (d_anc && d_map_in == d_map_out) return SLAM_ERR_INVALID_ARG;
-    if (e->nobs < 0 || e->obs_nlandmarks != nlandmarks) return SLAM_ERR_NOT_READY;
+    if (e->obs_nlandmarks < 0 || e->obs_nlandmarks != nlandmarks) return SLAM_ERR_NOT_READY;
     if (n == 0) return SLAM_OK;
-    const int nchunks = (e->nobs + EKF_OBS_CHUNK - 1) / EKF_OBS_CHUNK;
+    HIP_TRY(e->ll_buf.ensure(sizeof(float) * (size_t)n));
     EkfArgs a;
     a.map_in = d_map_in;
     a.map_out = d_map_out;
+    a.row_stride = row_stride;
     a.plane_stride = plane_stride;
-    a.ld = ld_map;
     a.nlandmarks = nlandmarks;
     a.x = d_x;
     a.y = d_y;
     a.th = d_th;
     a.anc = d_anc;
     a.n = n;
-    a.obs_id = e->d_obs_id;
     a.obs_zx = e->d_obs_zx;
     a.obs_zy = e->d_obs_zy;
-    a.nobs = e->nobs;
-    a.unobs_id = e->d_unobs_id;
-    a.nunobs = e->nunobs;
     a.meas_var = meas_var;
-    a.loglik = d_loglik;
-    a.ll_part = nullptr;
-    if (nchunks > 1 || !d_loglik) {
-        HIP_TRY(e->ll_buf.ensure(sizeof(float) * (size_t)(nchunks > 0 ? nchunks : 1) * (size_t)n));
-        a.ll_part = e->ll_buf.as<float>();
-    }
+    a.loglik = e->ll_buf.as<float>();   // what slam_logweight_ekf_dev will consume
+    a.loglik_user = d_loglik;
     HIP_TRY(launch_ekf_update(e->stream, a, e->prof_next(SLAM_PROF_EKF)));
-    e->ll_n = n;   // what slam_logweight_ekf_dev will consume
-    e->ll_chunks = nchunks;
+    e->ll_n = n;
     return SLAM_OK;
 }
 
-static int logweight_common(slam_engine* e, const float* d_score, const float* d_loglik, const float* ll_part,
-                            int nchunks, float score_gain, int n, float* d_logw, float* d_max)
+static int logweight_common(slam_engine* e, const float* d_score, const float* d_loglik, float score_gain, int n,
+                            float* d_logw, float* d_max)
 {
     if (n <= 0 || !d_logw) return SLAM_ERR_INVALID_ARG;
     HIP_TRY(e->bmax_buf.ensure(sizeof(float) * (size_t)logweight_scratch_elems(n)));
-    HIP_TRY(launch_logweight(e->stream, d_score, d_loglik, ll_part, nchunks, score_gain, n, d_logw,
-                             e->bmax_buf.as<float>(), d_max));
+    HIP_TRY(launch_logweight(e->stream, d_score, d_loglik, score_gain, n, d_logw, e->bmax_buf.as<float>(), d_max));
     e->bmax_count = logweight_scratch_elems(n);
     e->bmax_n = n;
     return SLAM_OK;
@@ -674,15 +650,14 @@ int slam_logweight_dev(slam_engine* e, const float* d_score, const float* d_logl
                        float* d_logw, float* d_max)
 {
     ENTER(e);
-    return logweight_common(e, d_score, d_loglik, nullptr, 0, score_gain, n, d_logw, d_max);
+    return logweight_common(e, d_score, d_loglik, score_gain, n, d_logw, d_max);
 }
 
 int slam_logweight_ekf_dev(slam_engine* e, const float* d_score, float score_gain, int n, float* d_logw, float* d_max)
 {
     ENTER(e);
     if (e->ll_n != n) return SLAM_ERR_NOT_READY;   // needs slam_ekf_update_dev(…, n, …) on this engine first
-    if (e->ll_chunks == 0) return logweight_common(e, d_score, nullptr, nullptr, 0, score_gain, n, d_logw, d_max);
-    return logweight_common(e, d_score, nullptr, e->ll_buf.as<float>(), e->ll_chunks, score_gain, n, d_logw, d_max);
+    return logweight_common(e, d_score, e->ll_buf.as<float>(), score_gain, n, d_logw, d_max);
 }
 
 int slam_quantise_scan_dev(slam_engine* e, const float* d_logw, const float* d_max, int n, uint64_t* d_sum)
@@ -801,33 +776,33 @@ int slam_ancestors_sharded_dev(slam_engine* e, const int32_t* d_first_all, int64
 
 int slam_migrate_pack_dev(slam_engine* e, const int32_t* d_first_all, int64_t n_total, int n_local, int rank, int world,
                           const int64_t* send_lo, const int32_t* send_cnt, const float* d_pose, int64_t pose_ld,
-                          const float* d_map, int64_t plane_stride, int ld_map, int nlandmarks, float* d_out)
+                          const float* d_map, int64_t row_stride, int plane_stride, int nlandmarks, float* d_out)
 {
     ENTER(e);
     MigratePlan plan;
     if (!make_plan(plan, send_lo, send_cnt, world) || n_local <= 0 || rank < 0 || rank >= world || nlandmarks < 0 ||
-        n_total != (int64_t)n_local * world || !d_first_all || !d_pose || (nlandmarks > 0 && !d_map))
+        n_total != (int64_t)n_local * world || !d_first_all || !d_pose ||
+        (nlandmarks > 0 && (!d_map || plane_stride < nlandmarks || row_stride < 5 * (int64_t)plane_stride)))
         return SLAM_ERR_INVALID_ARG;
     if (plan.off[world] > 0 && !d_out) return SLAM_ERR_INVALID_ARG;
     HIP_TRY(launch_migrate_pack(e->stream, d_first_all, n_total, n_local, rank, plan, d_pose, pose_ld, d_map,
-                                plane_stride, ld_map, nlandmarks, d_out));
+                                row_stride, plane_stride, nlandmarks, d_out));
     return SLAM_OK;
 }
 
 int slam_migrate_unpack_dev(slam_engine* e, const float* d_in, int world, const int32_t* recv_cnt, int n_local,
-                            float* d_pose, int64_t pose_ld, float* d_map, int64_t plane_stride, int ld_map,
+                            float* d_pose, int64_t pose_ld, float* d_map, int64_t row_stride, int plane_stride,
                             int nlandmarks)
 {
     ENTER(e);
     MigratePlan plan;
     int64_t zeros[kMaxRanks] = { 0 };
     if (!make_plan(plan, zeros, recv_cnt, world) || n_local <= 0 || nlandmarks < 0 || !d_pose ||
-        (nlandmarks > 0 && !d_map))
+        (nlandmarks > 0 && (!d_map || plane_stride < nlandmarks || row_stride < 5 * (int64_t)plane_stride)))
         return SLAM_ERR_INVALID_ARG;
     if (plan.off[world] > 0 && !d_in) return SLAM_ERR_INVALID_ARG;
-    if ((int64_t)n_local + plan.off[world] > pose_ld || (nlandmarks > 0 && (int64_t)n_local + plan.off[world] > ld_map))
-        return SLAM_ERR_CAPACITY;
-    HIP_TRY(launch_migrate_unpack(e->stream, d_in, plan, n_local, d_pose, pose_ld, d_map, plane_stride, ld_map,
+    if ((int64_t)n_local + plan.off[world] > pose_ld) return SLAM_ERR_CAPACITY;   // pose_ld = particle capacity
+    HIP_TRY(launch_migrate_unpack(e->stream, d_in, plan, n_local, d_pose, pose_ld, d_map, row_stride, plane_stride,
                                   nlandmarks));
     return SLAM_OK;
 }
@@ -848,15 +823,17 @@ int slam_gather_f32_dev(slam_engine* e, const float* d_src, const int32_t* d_idx
     return SLAM_OK;
 }
 
-int slam_gather_map_dev(slam_engine* e, const float* d_map_in, float* d_map_out, int64_t in_plane_stride,
-                        int64_t out_plane_stride, int ld_in, int ld_out, int nlandmarks, const int32_t* d_idx, int n)
+int slam_gather_map_dev(slam_engine* e, const float* d_map_in, float* d_map_out, int64_t in_row_stride,
+                        int64_t out_row_stride, int in_plane_stride, int out_plane_stride, int nlandmarks,
+                        const int32_t* d_idx, int n)
 {
     ENTER(e);
-    if (n < 0 || nlandmarks < 0 || ld_out < n || (n > 0 && nlandmarks > 0 && (!d_map_in || !d_map_out || !d_idx)) ||
-        d_map_in == d_map_out)
+    if (n < 0 || nlandmarks < 0 || in_plane_stride < nlandmarks || out_plane_stride < nlandmarks ||
+        in_row_stride < 5 * (int64_t)in_plane_stride || out_row_stride < 5 * (int64_t)out_plane_stride ||
+        (n > 0 && nlandmarks > 0 && (!d_map_in || !d_map_out || !d_idx)) || d_map_in == d_map_out)
         return SLAM_ERR_INVALID_ARG;
-    HIP_TRY(launch_gather_map(e->stream, d_map_in, d_map_out, in_plane_stride, out_plane_stride, ld_in, ld_out,
-                              nlandmarks, d_idx, n));
+    HIP_TRY(launch_gather_map(e->stream, d_map_in, d_map_out, in_row_stride, out_row_stride, in_plane_stride,
+                              out_plane_stride, nlandmarks, d_idx, n));
     return SLAM_OK;
 }
 

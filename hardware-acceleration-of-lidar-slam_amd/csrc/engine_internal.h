@@ -67,10 +67,9 @@ struct slam_engine {
     int nbeams = -1;
     DevBuf scan_buf;
 
-    // observation list of the current frame
-    DevBuf obs_buf;   // ids[MAX_OBS] zx[MAX_OBS] zy[MAX_OBS] unobs[...]
-    int nobs = -1, nunobs = 0, obs_nlandmarks = 0;
-    const int32_t *d_obs_id = nullptr, *d_unobs_id = nullptr;
+    // observations of the current frame as a table indexed by landmark (zx NaN = not observed)
+    DevBuf obs_buf;   // zx[L] zy[L] when uploaded from the host
+    int obs_nlandmarks = -1;
     const float *d_obs_zx = nullptr, *d_obs_zy = nullptr;
 
     DevBuf fm_buf;             // kFmIn + kFmOut floats
@@ -83,8 +82,8 @@ struct slam_engine {
     int bmax_count = 0, bmax_n = -1;
     DevBuf scan_state;         // tile-local CDF u64[n] + tile totals, left by slam_quantise_scan_dev
     int scan_n = -1;
-    DevBuf ll_buf;             // per-chunk log-likelihood partials [nchunks][n] of the last EKF call
-    int ll_n = -1, ll_chunks = 0;
+    DevBuf ll_buf;             // log-likelihood [n] of the last EKF call
+    int ll_n = -1;
     // pinned staging ring for the per-frame sensor uploads: one host-to-device copy per upload, and the
     // host only waits if kStageSlots uploads are still in flight
     float* h_stage = nullptr;

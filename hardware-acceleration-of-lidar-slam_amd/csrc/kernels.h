@@ -76,25 +76,21 @@ hipError_t launch_motion_sample(hipStream_t stream, const float* sx, const float
 struct EkfArgs {
     const float* map_in;
     float* map_out;
-    int64_t plane_stride;
-    int ld, nlandmarks;
+    int64_t row_stride;    // floats between consecutive particles' rows
+    int plane_stride;      // floats between the five planes inside a row (>= nlandmarks)
+    int nlandmarks;
     const float *x, *y, *th;
     const int32_t* anc;
     int n;
-    const int32_t* obs_id;   // device
-    const float *obs_zx, *obs_zy;
-    int nobs;
-    const int32_t* unobs_id;   // device list of landmarks without an observation (copy-through)
-    int nunobs;
+    const float *obs_zx, *obs_zy;   // device, indexed by landmark, padded to an even length; zx NaN = not observed
     float meas_var;
-    float* loglik;
-    float* ll_part;   // scratch [nchunks][n] (only read when nchunks > 1)
+    float* loglik;        // [n], always written
+    float* loglik_user;   // optional second copy for the caller
 };
-enum { EKF_OBS_CHUNK = 32 };
 hipError_t launch_ekf_update(hipStream_t stream, const EkfArgs& a, const EventPair* ev = nullptr);
 
-hipError_t launch_logweight(hipStream_t stream, const float* score, const float* loglik, const float* ll_part,
-                            int nchunks, float gain, int n, float* logw, float* block_max_scratch, float* d_max);
+hipError_t launch_logweight(hipStream_t stream, const float* score, const float* loglik, float gain, int n,
+                            float* logw, float* block_max_scratch, float* d_max);
 int logweight_scratch_elems(int n);
 hipError_t launch_quantise_weights(hipStream_t stream, const float* logw, const float* d_max, int n, uint64_t* wq,
                                    uint64_t* d_sum);
@@ -124,12 +120,13 @@ hipError_t launch_ancestors_sharded(hipStream_t stream, const int32_t* first_all
                                     int world, int32_t* src);
 hipError_t launch_migrate_pack(hipStream_t stream, const int32_t* first_all, int64_t n_total, int n, int rank,
                                const MigratePlan& plan, const float* pose, int64_t pose_ld, const float* map,
-                               int64_t plane_stride, int ld, int nlandmarks, float* out);
+                               int64_t row_stride, int plane_stride, int nlandmarks, float* out);
 hipError_t launch_migrate_unpack(hipStream_t stream, const float* in, const MigratePlan& plan, int n, float* pose,
-                                 int64_t pose_ld, float* map, int64_t plane_stride, int ld, int nlandmarks);
+                                 int64_t pose_ld, float* map, int64_t row_stride, int plane_stride, int nlandmarks);
 hipError_t launch_argmax(hipStream_t stream, const float* v, int n, int32_t* idx_out, float* val_out);
 hipError_t launch_gather_f32(hipStream_t stream, const float* src, const int32_t* idx, int n, float* dst);
-hipError_t launch_gather_map(hipStream_t stream, const float* in, float* out, int64_t in_stride, int64_t out_stride,
-                             int ld_in, int ld_out, int nlandmarks, const int32_t* idx, int n);
+hipError_t launch_gather_map(hipStream_t stream, const float* in, float* out, int64_t in_row_stride,
+                             int64_t out_row_stride, int in_plane_stride, int out_plane_stride, int nlandmarks,
+                             const int32_t* idx, int n);
 
 }  // namespace slam

@@ -39,97 +39,201 @@ __global__ __launch_bounds__(kBlock) void motion_sample_kernel(const float* __re
 }
 
 // ------------------------------------------------------------------ A10: 2x2 EKF per (particle, landmark)
-// grid = (particle tiles, observation chunks).  A thread owns one particle and walks one chunk of
-// EKF_OBS_CHUNK observations; consecutive lanes = consecutive particles, so each of the 5 loads and 5
-// stores per landmark is a 256-byte coalesced wave access.  The observation list (id, zx, zy) is
-// wave-uniform and read through the scalar path.
-__global__ __launch_bounds__(kBlock) void ekf_update_kernel(EkfArgs a)
+// The map is one row per particle (5 planes of plane_stride floats).  ONE WAVEFRONT OWNS ONE PARTICLE and its
+// lanes walk the landmarks of the row, two landmarks per lane (l and l + 64 of each batch of 128), so that every
+// load and store is a coalesced 256-byte access and the arithmetic runs on float2 (v_pk_mul_f32 / v_pk_add_f32:
+// IEEE per component, i.e. the same bits as the scalar form).  The observations of the frame come as a table indexed by
+// landmark (zx[l], zy[l], NaN = not observed), read alongside the row.  Why rows: after a resample most
+// particles are copies of few ancestors (the bench's filter keeps ~6 % distinct), the offspring of one ancestor
+// are neighbouring particles, so the 10 KB source row is fetched from HBM once and re-read from L2 by the other
+// offspring — the sweep's HBM traffic is the 20 B/(particle, landmark) it writes plus the distinct rows it reads,
+// not 40 B.  Row base addresses are wave-uniform (SGPR).
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f bc2(float a) { return (v2f){a, a}; }
+
+// det_logf on two values: the integer steps per component, the polynomial packed (same operation order)
+__device__ __forceinline__ v2f det_logf2(v2f x)
 {
-    const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= a.n) return;
-    const int chunk = blockIdx.y;
-    const int k0 = chunk * EKF_OBS_CHUNK;
-    const int k1 = min(k0 + EKF_OBS_CHUNK, a.nobs);
-
-    float st, ct;
-    det_sincosf(a.th[i], st, ct);
-    const float px = a.x[i], py = a.y[i];
-    const int src = a.anc ? a.anc[i] : i;
-    const float q = a.meas_var;
-    const int64_t ps = a.plane_stride;
-    const float* __restrict__ in = a.map_in;
-    float* __restrict__ out = a.map_out;
-
-    float part = 0.0f;
-#pragma unroll 4
-    for (int k = k0; k < k1; ++k) {
-        const int64_t row = (int64_t)a.obs_id[k] * a.ld;
-        const int64_t ri = row + src, wi = row + i;
-        const float mx = in[ri], my = in[ps + ri], pxx = in[2 * ps + ri], pxy = in[3 * ps + ri],
-                    pyy = in[4 * ps + ri];
-        const float zx = a.obs_zx[k], zy = a.obs_zy[k];
-        float omx, omy, oxx, oxy, oyy;
-        if (pxx < 0.0f) {   // first sighting
-            omx = px + (ct * zx + st * zy);
-            omy = py + (ct * zy - st * zx);
-            oxx = q;
-            oxy = 0.0f;
-            oyy = q;
-        } else {
-            const float dx = mx - px, dy = my - py;
-            const float vx = zx - (ct * dx - st * dy);
-            const float vy = zy - (st * dx + ct * dy);
-            const float a00 = ct * pxx - st * pxy, a01 = ct * pxy - st * pyy;
-            const float a10 = st * pxx + ct * pxy, a11 = st * pxy + ct * pyy;
-            const float s00 = (a00 * ct - a01 * st) + q;
-            const float s01 = a00 * st + a01 * ct;
-            const float s11 = (a10 * st + a11 * ct) + q;
-            const float det = s00 * s11 - s01 * s01;
-            const float idet = 1.0f / det;
-            const float i00 = s11 * idet, i01 = -s01 * idet, i11 = s00 * idet;
-            const float k00 = a00 * i00 + a10 * i01, k01 = a00 * i01 + a10 * i11;
-            const float k10 = a01 * i00 + a11 * i01, k11 = a01 * i01 + a11 * i11;
-            omx = mx + (k00 * vx + k01 * vy);
-            omy = my + (k10 * vx + k11 * vy);
-            oxx = pxx - (k00 * a00 + k01 * a10);
-            oxy = pxy - (k00 * a01 + k01 * a11);
-            oyy = pyy - (k10 * a01 + k11 * a11);
-            const float maha = vx * (i00 * vx + i01 * vy) + vy * (i01 * vx + i11 * vy);
-            part = ((part - 0.5f * maha) - 0.5f * det_logf(det)) - 1.8378770664f;
-        }
-        out[wi] = omx;
-        out[ps + wi] = omy;
-        out[2 * ps + wi] = oxx;
-        out[3 * ps + wi] = oxy;
-        out[4 * ps + wi] = oyy;
-    }
-    if (gridDim.y == 1 && a.loglik)
-        a.loglik[i] = 0.0f + part;
-    else
-        a.ll_part[(int64_t)chunk * a.n + i] = part;
-}
-
-__global__ __launch_bounds__(kBlock) void ekf_loglik_finalize_kernel(const float* __restrict__ part, int nchunks, int n,
-                                                                     float* __restrict__ loglik)
-{
-    const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
-    float total = 0.0f;
-    for (int c = 0; c < nchunks; ++c) total = total + part[(int64_t)c * n + i];
-    loglik[i] = total;
-}
-
-// landmarks without an observation: gathered copy in -> out (only for out-of-place updates)
-__global__ __launch_bounds__(kBlock) void map_copy_through_kernel(EkfArgs a)
-{
-    const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= a.n) return;
-    const int src = a.anc ? a.anc[i] : i;
-    const int64_t ps = a.plane_stride;
-    for (int u = blockIdx.y; u < a.nunobs; u += gridDim.y) {
-        const int64_t row = (int64_t)a.unobs_id[u] * a.ld;
+    float m_[2], ef_[2];
 #pragma unroll
-        for (int p = 0; p < 5; ++p) a.map_out[p * ps + row + i] = a.map_in[p * ps + row + src];
+    for (int t = 0; t < 2; ++t) {
+        float xv = x[t];
+        if (!(xv >= 1.17549435e-38f)) xv = 1.17549435e-38f;
+        const uint32_t u = __float_as_uint(xv);
+        int e = (int)(u >> 23) - 126;
+        const float m = __uint_as_float((u & 0x007fffffu) | 0x3f000000u);
+        const bool lo = m < 0.70710678f;
+        e = lo ? e - 1 : e;
+        m_[t] = lo ? m + m : m;
+        ef_[t] = (float)e;
+    }
+    const v2f f = (v2f){m_[0], m_[1]} - bc2(1.0f), ef = (v2f){ef_[0], ef_[1]};
+    const v2f z = f * f;
+    v2f y = bc2(7.0376836292e-2f) * f;
+    y = y + bc2(-1.1514610310e-1f); y = y * f;
+    y = y + bc2(1.1676998740e-1f);  y = y * f;
+    y = y + bc2(-1.2420140846e-1f); y = y * f;
+    y = y + bc2(1.4249322787e-1f);  y = y * f;
+    y = y + bc2(-1.6668057665e-1f); y = y * f;
+    y = y + bc2(2.0000714765e-1f);  y = y * f;
+    y = y + bc2(-2.4999993993e-1f); y = y * f;
+    y = y + bc2(3.3333331174e-1f);  y = y * f;
+    y = y * z;
+    y = y + ef * bc2(-2.12194440e-4f);
+    y = y - bc2(0.5f) * z;
+    v2f r = f + y;
+    r = r + ef * bc2(0.693359375f);
+    return r;
+}
+
+__device__ __forceinline__ float wave_xor_tree_sum(float v)   // t[j] = t[j] + t[j ^ s], s = 1 .. 32: all lanes equal
+{
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) v = v + __shfl_xor(v, s, 64);
+    return v;
+}
+
+constexpr int kEkfWaves = 4;   // particles per workgroup
+
+struct EkfLane {   // per-wavefront constants of one particle
+    const char* rin;
+    char* rout;
+    int64_t pl;   // plane stride in bytes
+    const char *ozx, *ozy;
+    unsigned L;
+    v2f s, c, px, py, q;
+};
+
+// NB batches of 128 landmarks starting at lb: all loads first, then the arithmetic, then the stores.  A lane owns
+// landmarks l and l + 64 of each batch, so every access is one 256-byte dword access per wavefront (8-byte
+// accesses, a lane owning neighbours, were measured ~20 % slower whenever the source rows come out of L2).
+// FULL: every lane's landmarks lie inside the row (lb + 128*NB <= plane_stride) and the update is out of place,
+// so nothing is predicated; landmarks at or beyond L (row padding) then simply count as "not observed" and their
+// padding values are copied along.  !FULL: the general form (row tails, in-place updates).
+template <int NB, bool FULL, bool COPY>
+__device__ __forceinline__ void ekf_batches(const EkfLane& w, unsigned lb, unsigned lane, v2f& acc)
+{
+    const float nan = __uint_as_float(0x7fc00000u);
+    v2f m[NB][5], zx[NB], zy[NB];
+    unsigned off[NB][2];
+    bool obs[NB][2], use[NB][2];
+#pragma unroll
+    for (int g = 0; g < NB; ++g)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const unsigned l = lb + (unsigned)g * 128u + 64u * t + lane;
+            const bool in = l < w.L;
+            off[g][t] = ((FULL || in) ? l : 0u) * 4u;
+            const unsigned zo = (in ? l : 0u) * 4u;   // clamped index + select instead of a predicated load
+            const float vx = *reinterpret_cast<const float*>(w.ozx + zo), vy = *reinterpret_cast<const float*>(w.ozy + zo);
+            zx[g][t] = in ? vx : nan;
+            zy[g][t] = in ? vy : nan;
+            // NaN = no observation (also what lanes beyond L were given).  Testing zy as well keeps its load up here
+            // with the others: the compiler otherwise sinks it into the arithmetic, two extra round trips per batch.
+            obs[g][t] = zx[g][t] == zx[g][t] && zy[g][t] == zy[g][t];
+            use[g][t] = FULL ? true : (COPY ? in : obs[g][t]);
+        }
+#pragma unroll
+    for (int g = 0; g < NB; ++g)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+            if (FULL || use[g][t]) {
+#pragma unroll
+                for (int p = 0; p < 5; ++p) m[g][p][t] = *reinterpret_cast<const float*>(w.rin + p * w.pl + off[g][t]);
+            }
+#pragma unroll
+    for (int g = 0; g < NB; ++g) {
+        if (!FULL && !(use[g][0] || use[g][1])) continue;
+        const v2f mx = m[g][0], my = m[g][1], pxx = m[g][2], pxy = m[g][3], pyy = m[g][4];
+        if (COPY && __ballot(obs[g][0] || obs[g][1]) == 0) {   // no observation among these 128 landmarks: plain copy
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+                if (FULL || use[g][t]) {
+#pragma unroll
+                    for (int p = 0; p < 5; ++p) *reinterpret_cast<float*>(w.rout + p * w.pl + off[g][t]) = m[g][p][t];
+                }
+            continue;
+        }
+        const v2f s = w.s, c = w.c, px = w.px, py = w.py, q = w.q;
+        const v2f dx = mx - px, dy = my - py;
+        const v2f vx = zx[g] - (c * dx - s * dy);
+        const v2f vy = zy[g] - (s * dx + c * dy);
+        const v2f a00 = c * pxx - s * pxy, a01 = c * pxy - s * pyy;
+        const v2f a10 = s * pxx + c * pxy, a11 = s * pxy + c * pyy;
+        const v2f s00 = (a00 * c - a01 * s) + q;
+        const v2f s01 = a00 * s + a01 * c;
+        const v2f s11 = (a10 * s + a11 * c) + q;
+        const v2f det = s00 * s11 - s01 * s01;
+        const v2f idet = (v2f){1.0f / det[0], 1.0f / det[1]};
+        const v2f i00 = s11 * idet, i01 = -s01 * idet, i11 = s00 * idet;
+        const v2f k00 = a00 * i00 + a10 * i01, k01 = a00 * i01 + a10 * i11;
+        const v2f k10 = a01 * i00 + a11 * i01, k11 = a01 * i01 + a11 * i11;
+        v2f o0 = mx + (k00 * vx + k01 * vy);
+        v2f o1 = my + (k10 * vx + k11 * vy);
+        v2f o2 = pxx - (k00 * a00 + k01 * a10);
+        v2f o3 = pxy - (k00 * a01 + k01 * a11);
+        v2f o4 = pyy - (k10 * a01 + k11 * a11);
+        const v2f maha = vx * (i00 * vx + i01 * vy) + vy * (i01 * vx + i11 * vy);
+        v2f ll = ((bc2(0.0f) - bc2(0.5f) * maha) - bc2(0.5f) * det_logf2(det)) - bc2(1.8378770664f);
+        const v2f f0 = px + (c * zx[g] + s * zy[g]);   // first sighting: the observed point, P = R, no likelihood
+        const v2f f1 = py + (c * zy[g] - s * zx[g]);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const bool ob = obs[g][t];
+            const bool first = pxx[t] < 0.0f;
+            o0[t] = !ob ? mx[t] : first ? f0[t] : o0[t];
+            o1[t] = !ob ? my[t] : first ? f1[t] : o1[t];
+            o2[t] = !ob ? pxx[t] : first ? q[t] : o2[t];
+            o3[t] = !ob ? pxy[t] : first ? 0.0f : o3[t];
+            o4[t] = !ob ? pyy[t] : first ? q[t] : o4[t];
+            ll[t] = (!ob || first) ? 0.0f : ll[t];
+            if (FULL || use[g][t]) {
+                char* wp = w.rout + off[g][t];
+                *reinterpret_cast<float*>(wp) = o0[t];
+                *reinterpret_cast<float*>(wp + w.pl) = o1[t];
+                *reinterpret_cast<float*>(wp + 2 * w.pl) = o2[t];
+                *reinterpret_cast<float*>(wp + 3 * w.pl) = o3[t];
+                *reinterpret_cast<float*>(wp + 4 * w.pl) = o4[t];
+            }
+        }
+        acc = acc + ll;
+    }
+}
+
+// NB: batches of 128 landmarks per pass of the fast path.  COPY: out of place.
+template <int NB, bool COPY>
+__global__ __launch_bounds__(kEkfWaves * 64) void ekf_update_kernel(EkfArgs a)
+{
+    const unsigned lane = threadIdx.x & 63u;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int i = blockIdx.x * kEkfWaves + wave;
+    if (i >= a.n) return;
+    const int src = a.anc ? a.anc[i] : i;
+    float st_, ct_;
+    det_sincosf(a.th[i], st_, ct_);
+    EkfLane w;
+    w.rin = reinterpret_cast<const char*>(a.map_in + (int64_t)src * a.row_stride);
+    w.rout = reinterpret_cast<char*>(a.map_out + (int64_t)i * a.row_stride);
+    w.pl = (int64_t)a.plane_stride * 4;
+    w.ozx = reinterpret_cast<const char*>(a.obs_zx);
+    w.ozy = reinterpret_cast<const char*>(a.obs_zy);
+    w.L = (unsigned)a.nlandmarks;
+    w.s = bc2(st_); w.c = bc2(ct_); w.px = bc2(a.x[i]); w.py = bc2(a.y[i]); w.q = bc2(a.meas_var);
+
+    v2f acc = bc2(0.0f);   // lane j: .x = accumulator j, .y = accumulator j + 64 of the spec (landmark l -> l mod 128)
+    unsigned lb = 0;
+    if (COPY) {   // whole batches that fit into the row, padding included: nothing predicated
+        const unsigned room = (unsigned)a.plane_stride;
+        for (; lb < w.L && lb + 128u * NB <= room; lb += 128u * NB) ekf_batches<NB, true, COPY>(w, lb, lane, acc);
+        if (NB > 1)
+            for (; lb < w.L && lb + 128u <= room; lb += 128u) ekf_batches<1, true, COPY>(w, lb, lane, acc);
+    }
+    for (; lb < w.L; lb += 128u) ekf_batches<1, false, COPY>(w, lb, lane, acc);
+
+    const float total = wave_xor_tree_sum(acc[0] + acc[1]);
+    if (lane == 0) {
+        a.loglik[i] = total;
+        if (a.loglik_user) a.loglik_user[i] = total;
     }
 }
 
@@ -141,22 +245,14 @@ __device__ __forceinline__ float wave_max(float v)
     return v;
 }
 
-// ll_part/nchunks: when the EKF left its per-chunk partial sums (nchunks > 1) they are added up here in
-// chunk order — the specified summation order — instead of in a separate finalize pass.
 __global__ __launch_bounds__(kBlock) void logweight_kernel(const float* __restrict__ score,
-                                                           const float* __restrict__ loglik,
-                                                           const float* __restrict__ ll_part, int nchunks, float gain,
-                                                           int n, float* __restrict__ logw,
-                                                           float* __restrict__ block_max)
+                                                           const float* __restrict__ loglik, float gain, int n,
+                                                           float* __restrict__ logw, float* __restrict__ block_max)
 {
     __shared__ float s_max[kBlock / 64];
     float m = -INFINITY;
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
-        float ll = loglik ? loglik[i] : 0.0f;
-        if (ll_part) {
-            ll = 0.0f;
-            for (int c = 0; c < nchunks; ++c) ll = ll + ll_part[(int64_t)c * n + i];
-        }
+        const float ll = loglik ? loglik[i] : 0.0f;
         const float sc = score ? score[i] * gain : 0.0f;
         const float lw = ll - sc;
         logw[i] = lw;
@@ -536,59 +632,42 @@ __global__ __launch_bounds__(kBlock) void ancestors_sharded_kernel(const int32_t
     src[jl] = owner == rank ? (int32_t)(g - (int64_t)rank * n) : n + s_off[owner] + (int32_t)(j - s_lo[owner]);
 }
 
-// Pack what the other ranks need from me into one buffer: block d (for rank d) is [3 + 5L][cnt_d] floats —
-// rows x, y, theta, then the 5 map planes landmark by landmark — for the cnt_d consecutive slots starting
-// at lo_d whose ancestors are my particles.  One launch for every destination.
+// Pack what the other ranks need from me into one buffer: block d (for rank d) is cnt_d records of 3 + 5L
+// floats — x, y, theta, then the five map planes (L values each) — one record per consecutive slot starting at
+// lo_d whose ancestor is one of my particles.  One workgroup per record, one launch for every destination.
 __global__ __launch_bounds__(kBlock) void migrate_pack_kernel(const int32_t* __restrict__ first_all, int64_t n_total,
                                                               int n, int rank, MigratePlan plan,
                                                               const float* __restrict__ pose, int64_t pose_ld,
-                                                              const float* __restrict__ map, int64_t plane_stride,
-                                                              int ld, int nlandmarks, float* __restrict__ out)
+                                                              const float* __restrict__ map, int64_t row_stride,
+                                                              int plane_stride, int nlandmarks,
+                                                              float* __restrict__ out)
 {
-    const int p = blockIdx.x * kBlock + threadIdx.x;
-    if (p >= plan.off[plan.world]) return;
+    const int p = blockIdx.x;
     int d = 0;
     while (p >= plan.off[d + 1]) ++d;
-    const int q = p - plan.off[d], cnt = plan.off[d + 1] - plan.off[d];
-    const int64_t j = plan.lo[d] + q;
+    const int64_t j = plan.lo[d] + (p - plan.off[d]);
     const int loc = (int)(last_with_first_le(first_all, n_total, j) - (int64_t)rank * n);
-    const int rows = 3 + 5 * nlandmarks;
-    float* __restrict__ blk = out + (int64_t)rows * plan.off[d] + q;
-    for (int k = blockIdx.y; k < rows; k += gridDim.y) {
-        float v;
-        if (k < 3) {
-            v = pose[k * pose_ld + loc];
-        } else {
-            const int m = k - 3, pl = m / nlandmarks, l = m - pl * nlandmarks;
-            v = map[pl * plane_stride + (int64_t)l * ld + loc];
-        }
-        blk[(int64_t)k * cnt] = v;
-    }
+    float* __restrict__ rec = out + (int64_t)(3 + 5 * nlandmarks) * p;
+    if (threadIdx.x < 3) rec[threadIdx.x] = pose[threadIdx.x * pose_ld + loc];
+    const float* __restrict__ row = map + (int64_t)loc * row_stride;
+    for (int pl = 0; pl < 5; ++pl)
+        for (int l = threadIdx.x; l < nlandmarks; l += kBlock) rec[3 + pl * nlandmarks + l] = row[pl * plane_stride + l];
 }
 
-// Unpack the received blocks into the staging tail behind the n local particles (position = running index
+// Unpack the received records into the staging tail behind the n local particles (position = running index
 // over sources in rank order, matching ancestors_sharded_kernel).
-__global__ __launch_bounds__(kBlock) void migrate_unpack_kernel(const float* __restrict__ in, MigratePlan plan, int n,
+__global__ __launch_bounds__(kBlock) void migrate_unpack_kernel(const float* __restrict__ in, int total, int n,
                                                                 float* __restrict__ pose, int64_t pose_ld,
-                                                                float* __restrict__ map, int64_t plane_stride, int ld,
-                                                                int nlandmarks)
+                                                                float* __restrict__ map, int64_t row_stride,
+                                                                int plane_stride, int nlandmarks)
 {
-    const int p = blockIdx.x * kBlock + threadIdx.x;
-    if (p >= plan.off[plan.world]) return;
-    int s = 0;
-    while (p >= plan.off[s + 1]) ++s;
-    const int q = p - plan.off[s], cnt = plan.off[s + 1] - plan.off[s];
-    const int rows = 3 + 5 * nlandmarks;
-    const float* __restrict__ blk = in + (int64_t)rows * plan.off[s] + q;
-    for (int k = blockIdx.y; k < rows; k += gridDim.y) {
-        const float v = blk[(int64_t)k * cnt];
-        if (k < 3) {
-            pose[k * pose_ld + n + p] = v;
-        } else {
-            const int m = k - 3, pl = m / nlandmarks, l = m - pl * nlandmarks;
-            map[pl * plane_stride + (int64_t)l * ld + n + p] = v;
-        }
-    }
+    const int p = blockIdx.x;
+    if (p >= total) return;
+    const float* __restrict__ rec = in + (int64_t)(3 + 5 * nlandmarks) * p;
+    if (threadIdx.x < 3) pose[threadIdx.x * pose_ld + n + p] = rec[threadIdx.x];
+    float* __restrict__ row = map + (int64_t)(n + p) * row_stride;
+    for (int pl = 0; pl < 5; ++pl)
+        for (int l = threadIdx.x; l < nlandmarks; l += kBlock) row[pl * plane_stride + l] = rec[3 + pl * nlandmarks + l];
 }
 
 __global__ __launch_bounds__(kBlock) void gather_f32_kernel(const float* __restrict__ src,
@@ -599,19 +678,18 @@ __global__ __launch_bounds__(kBlock) void gather_f32_kernel(const float* __restr
     if (i < n) dst[i] = src[idx[i]];
 }
 
+// out row i = in row idx[i]; one workgroup per particle
 __global__ __launch_bounds__(kBlock) void gather_map_kernel(const float* __restrict__ in, float* __restrict__ out,
-                                                            int64_t in_stride, int64_t out_stride, int ld_in,
-                                                            int ld_out, int nlandmarks,
-                                                            const int32_t* __restrict__ idx, int n)
+                                                            int64_t in_row_stride, int64_t out_row_stride,
+                                                            int in_plane_stride, int out_plane_stride,
+                                                            int nlandmarks, const int32_t* __restrict__ idx, int n)
 {
-    const int i = blockIdx.x * kBlock + threadIdx.x;
+    const int i = blockIdx.x;
     if (i >= n) return;
-    const int src = idx[i];
-    for (int l = blockIdx.y; l < nlandmarks; l += gridDim.y) {
-#pragma unroll
-        for (int p = 0; p < 5; ++p)
-            out[p * out_stride + (int64_t)l * ld_out + i] = in[p * in_stride + (int64_t)l * ld_in + src];
-    }
+    const float* __restrict__ src = in + (int64_t)idx[i] * in_row_stride;
+    float* __restrict__ dst = out + (int64_t)i * out_row_stride;
+    for (int pl = 0; pl < 5; ++pl)
+        for (int l = threadIdx.x; l < nlandmarks; l += kBlock) dst[pl * out_plane_stride + l] = src[pl * in_plane_stride + l];
 }
 
 // index of the largest value, lowest index on ties (the heaviest particle); one workgroup
@@ -659,33 +737,28 @@ hipError_t launch_motion_sample(hipStream_t stream, const float* sx, const float
 hipError_t launch_ekf_update(hipStream_t stream, const EkfArgs& a, const EventPair* ev)
 {
     if (a.n <= 0) return hipSuccess;
-    const int nchunks = (a.nobs + EKF_OBS_CHUNK - 1) / EKF_OBS_CHUNK;
-    if (a.map_in != a.map_out && a.nunobs > 0) {
-        const int gy = a.nunobs < 1024 ? a.nunobs : 1024;
-        map_copy_through_kernel<<<dim3(blocks_for(a.n), gy), kBlock, 0, stream>>>(a);
-    }
-    if (nchunks == 0) {
-        if (!a.loglik) return hipGetLastError();
-        hipError_t err = hipMemsetAsync(a.loglik, 0, sizeof(float) * (size_t)a.n, stream);
-        return err != hipSuccess ? err : hipGetLastError();
-    }
+    const int blocks = (a.n + kEkfWaves - 1) / kEkfWaves;
+    const bool copy = a.map_in != a.map_out;   // in place: rows without an observation stay as they are
+    static const int nb_env = getenv("SLAM_EKF_NB") ? atoi(getenv("SLAM_EKF_NB")) : 0;   // tuning knob
+    const int nb = nb_env ? nb_env : (a.nlandmarks <= 128 ? 1 : 2);
     if (ev) (void)hipEventRecord(ev->start, stream);
-    ekf_update_kernel<<<dim3(blocks_for(a.n), nchunks), kBlock, 0, stream>>>(a);
+    if (!copy) ekf_update_kernel<1, false><<<blocks, kEkfWaves * 64, 0, stream>>>(a);
+    else if (nb == 1) ekf_update_kernel<1, true><<<blocks, kEkfWaves * 64, 0, stream>>>(a);
+    else if (nb == 2) ekf_update_kernel<2, true><<<blocks, kEkfWaves * 64, 0, stream>>>(a);
+    else ekf_update_kernel<4, true><<<blocks, kEkfWaves * 64, 0, stream>>>(a);
     if (ev) (void)hipEventRecord(ev->stop, stream);
-    if (nchunks > 1 && a.loglik)   // loglik == nullptr: the partials are consumed by launch_logweight instead
-        ekf_loglik_finalize_kernel<<<blocks_for(a.n), kBlock, 0, stream>>>(a.ll_part, nchunks, a.n, a.loglik);
     return hipGetLastError();
 }
 
 static int capped_blocks(int n) { const int b = blocks_for(n); return b < 2048 ? b : 2048; }
 int logweight_scratch_elems(int n) { return capped_blocks(n > 0 ? n : 1); }
 
-hipError_t launch_logweight(hipStream_t stream, const float* score, const float* loglik, const float* ll_part,
-                            int nchunks, float gain, int n, float* logw, float* block_max_scratch, float* d_max)
+hipError_t launch_logweight(hipStream_t stream, const float* score, const float* loglik, float gain, int n,
+                            float* logw, float* block_max_scratch, float* d_max)
 {
     if (n <= 0) return hipSuccess;
     const int nb = capped_blocks(n);
-    logweight_kernel<<<nb, kBlock, 0, stream>>>(score, loglik, ll_part, nchunks, gain, n, logw, block_max_scratch);
+    logweight_kernel<<<nb, kBlock, 0, stream>>>(score, loglik, gain, n, logw, block_max_scratch);
     if (d_max) max_finalize_kernel<<<1, kBlock, 0, stream>>>(block_max_scratch, nb, d_max);
     return hipGetLastError();
 }
@@ -768,24 +841,22 @@ hipError_t launch_ancestors_sharded(hipStream_t stream, const int32_t* first_all
 
 hipError_t launch_migrate_pack(hipStream_t stream, const int32_t* first_all, int64_t n_total, int n, int rank,
                                const MigratePlan& plan, const float* pose, int64_t pose_ld, const float* map,
-                               int64_t plane_stride, int ld, int nlandmarks, float* out)
+                               int64_t row_stride, int plane_stride, int nlandmarks, float* out)
 {
     const int total = plan.off[plan.world];
     if (total <= 0) return hipSuccess;
-    const int rows = 3 + 5 * nlandmarks;
-    migrate_pack_kernel<<<dim3(blocks_for(total), rows < 512 ? rows : 512), kBlock, 0, stream>>>(
-        first_all, n_total, n, rank, plan, pose, pose_ld, map, plane_stride, ld, nlandmarks, out);
+    migrate_pack_kernel<<<total, kBlock, 0, stream>>>(first_all, n_total, n, rank, plan, pose, pose_ld, map, row_stride,
+                                                     plane_stride, nlandmarks, out);
     return hipGetLastError();
 }
 
 hipError_t launch_migrate_unpack(hipStream_t stream, const float* in, const MigratePlan& plan, int n, float* pose,
-                                 int64_t pose_ld, float* map, int64_t plane_stride, int ld, int nlandmarks)
+                                 int64_t pose_ld, float* map, int64_t row_stride, int plane_stride, int nlandmarks)
 {
     const int total = plan.off[plan.world];
     if (total <= 0) return hipSuccess;
-    const int rows = 3 + 5 * nlandmarks;
-    migrate_unpack_kernel<<<dim3(blocks_for(total), rows < 512 ? rows : 512), kBlock, 0, stream>>>(
-        in, plan, n, pose, pose_ld, map, plane_stride, ld, nlandmarks);
+    migrate_unpack_kernel<<<total, kBlock, 0, stream>>>(in, total, n, pose, pose_ld, map, row_stride, plane_stride,
+                                                       nlandmarks);
     return hipGetLastError();
 }
 
@@ -803,13 +874,13 @@ hipError_t launch_gather_f32(hipStream_t stream, const float* src, const int32_t
     return hipGetLastError();
 }
 
-hipError_t launch_gather_map(hipStream_t stream, const float* in, float* out, int64_t in_stride, int64_t out_stride,
-                             int ld_in, int ld_out, int nlandmarks, const int32_t* idx, int n)
+hipError_t launch_gather_map(hipStream_t stream, const float* in, float* out, int64_t in_row_stride,
+                             int64_t out_row_stride, int in_plane_stride, int out_plane_stride, int nlandmarks,
+                             const int32_t* idx, int n)
 {
     if (n <= 0 || nlandmarks <= 0) return hipSuccess;
-    const int gy = nlandmarks < 1024 ? nlandmarks : 1024;
-    gather_map_kernel<<<dim3(blocks_for(n), gy), kBlock, 0, stream>>>(in, out, in_stride, out_stride, ld_in, ld_out,
-                                                                      nlandmarks, idx, n);
+    gather_map_kernel<<<n, kBlock, 0, stream>>>(in, out, in_row_stride, out_row_stride, in_plane_stride,
+                                                out_plane_stride, nlandmarks, idx, n);
     return hipGetLastError();
 }
 

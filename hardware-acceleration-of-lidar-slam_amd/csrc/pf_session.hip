@@ -17,7 +17,8 @@ struct slam_pf {
     slam_pf_config cfg{};
     int n = 0, L = 0;
     float* pose[2] = { nullptr, nullptr };     // [3][n] each
-    float* map[2] = { nullptr, nullptr };      // [5][L][n] each
+    float* map[2] = { nullptr, nullptr };      // [n][5][Lp] each: one row per particle, planes padded to Lp floats
+    int Lp = 0;                                // plane stride: L rounded up to 32 floats (128-byte rows)
     int32_t* anc[2] = { nullptr, nullptr };
     float *score = nullptr, *logw = nullptr;
     int32_t *count = nullptr, *first = nullptr, *best_idx = nullptr;
@@ -63,12 +64,13 @@ int slam_pf_create(slam_engine* e, const slam_pf_config* cfg, slam_pf** out)
     pf->cfg = *cfg;
     pf->n = cfg->n_particles;
     pf->L = cfg->n_landmarks;
-    const size_t n = (size_t)pf->n, L = (size_t)pf->L;
+    pf->Lp = (pf->L + 31) / 32 * 32;
+    const size_t n = (size_t)pf->n, L = (size_t)pf->L, Lp = (size_t)pf->Lp;
     bool ok = true;
     for (int b = 0; b < 2; ++b) {
         ok = ok && dev_alloc((void**)&pf->pose[b], 3 * n * 4) == hipSuccess;
         ok = ok && dev_alloc((void**)&pf->anc[b], n * 4) == hipSuccess;
-        if (L) ok = ok && dev_alloc((void**)&pf->map[b], 5 * L * n * 4) == hipSuccess;
+        if (L) ok = ok && dev_alloc((void**)&pf->map[b], 5 * Lp * n * 4) == hipSuccess;
     }
     ok = ok && dev_alloc((void**)&pf->score, n * 4) == hipSuccess && dev_alloc((void**)&pf->logw, n * 4) == hipSuccess &&
          dev_alloc((void**)&pf->count, n * 4) == hipSuccess && dev_alloc((void**)&pf->first, n * 4) == hipSuccess &&
@@ -112,8 +114,10 @@ int slam_pf_reset(slam_pf* pf, const float pose[3])
     if (int rc = slam_engine_sync(pf->e)) return rc;
     if (hipMemcpy(pf->pose[pf->cur], h.data(), 3 * n * 4, hipMemcpyHostToDevice) != hipSuccess) return SLAM_ERR_HIP;
     if (pf->L) {   // P_xx = -1: "not seen yet"
-        std::vector<float> m(5 * (size_t)pf->L * n, 0.0f);
-        for (size_t k = 2 * (size_t)pf->L * n; k < 3 * (size_t)pf->L * n; ++k) m[k] = -1.0f;
+        const size_t Lp = (size_t)pf->Lp;
+        std::vector<float> m(5 * Lp * n, 0.0f);
+        for (size_t i = 0; i < n; ++i)
+            for (size_t l = 0; l < Lp; ++l) m[(5 * i + 2) * Lp + l] = -1.0f;
         if (hipMemcpy(pf->map[pf->map_cur], m.data(), m.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
             return SLAM_ERR_HIP;
     }
@@ -136,12 +140,14 @@ int slam_pf_set_poses_host(slam_pf* pf, const float* x, const float* y, const fl
     return SLAM_OK;
 }
 
-int slam_pf_set_map_host(slam_pf* pf, const float* planes)
+int slam_pf_set_map_host(slam_pf* pf, const float* rows)
 {
-    if (!pf || !planes || !pf->L) return SLAM_ERR_INVALID_ARG;
+    if (!pf || !rows || !pf->L) return SLAM_ERR_INVALID_ARG;
     if (int rc = slam_engine_sync(pf->e)) return rc;
     if (pf->has_anc) return SLAM_ERR_NOT_READY;   // set poses / reset first: a gather is pending
-    if (hipMemcpy(pf->map[pf->map_cur], planes, 5 * (size_t)pf->L * pf->n * 4, hipMemcpyHostToDevice) != hipSuccess)
+    // host [n][5][L] -> device [n][5][Lp]: 5n planes of L floats each
+    if (hipMemcpy2D(pf->map[pf->map_cur], (size_t)pf->Lp * 4, rows, (size_t)pf->L * 4, (size_t)pf->L * 4,
+                    5 * (size_t)pf->n, hipMemcpyHostToDevice) != hipSuccess)
         return SLAM_ERR_HIP;
     return SLAM_OK;
 }
@@ -161,14 +167,15 @@ int slam_pf_step(slam_pf* pf, int slot, const float dp[3], int use_observations)
     const bool ekf = L > 0 && use_observations;
     const int mc = pf->map_cur, mn = 1 - mc;
     if (ekf) {
-        rc = slam_ekf_update_dev(e, pf->map[mc], pf->map[mn], (int64_t)L * n, n, L, dst, dst + sn, dst + 2 * sn, anc, n,
+        rc = slam_ekf_update_dev(e, pf->map[mc], pf->map[mn], 5 * (int64_t)pf->Lp, pf->Lp, L, dst, dst + sn, dst + 2 * sn, anc, n,
                                  pf->cfg.meas_var, nullptr);
         if (rc != SLAM_OK) return rc;
         pf->map_cur = mn;
         rc = slam_logweight_ekf_dev(e, pf->score, pf->cfg.score_gain, n, pf->logw, nullptr);
     } else {
         if (L > 0 && anc) {   // the maps follow their particles even without an observation
-            rc = slam_gather_map_dev(e, pf->map[mc], pf->map[mn], (int64_t)L * n, (int64_t)L * n, n, n, L, anc, n);
+            rc = slam_gather_map_dev(e, pf->map[mc], pf->map[mn], 5 * (int64_t)pf->Lp, 5 * (int64_t)pf->Lp, pf->Lp, pf->Lp, L,
+                                     anc, n);
             if (rc != SLAM_OK) return rc;
             pf->map_cur = mn;
         }
@@ -217,19 +224,19 @@ int slam_pf_get_poses_host(slam_pf* pf, float* x, float* y, float* theta)
     return SLAM_OK;
 }
 
-int slam_pf_get_map_host(slam_pf* pf, float* planes)
+int slam_pf_get_map_host(slam_pf* pf, float* rows)
 {
-    if (!pf || !planes || !pf->L) return SLAM_ERR_INVALID_ARG;
-    const size_t n = (size_t)pf->n, L = (size_t)pf->L;
+    if (!pf || !rows || !pf->L) return SLAM_ERR_INVALID_ARG;
+    const size_t n = (size_t)pf->n, L = (size_t)pf->L, Lp = (size_t)pf->Lp;
     const float* src = pf->map[pf->map_cur];
     if (pf->has_anc) {
-        int rc = slam_gather_map_dev(pf->e, pf->map[pf->map_cur], pf->map[1 - pf->map_cur], (int64_t)(L * n),
-                                     (int64_t)(L * n), pf->n, pf->n, pf->L, pf->anc[pf->cur], pf->n);
+        int rc = slam_gather_map_dev(pf->e, pf->map[pf->map_cur], pf->map[1 - pf->map_cur], 5 * (int64_t)Lp,
+                                     5 * (int64_t)Lp, pf->Lp, pf->Lp, pf->L, pf->anc[pf->cur], pf->n);
         if (rc != SLAM_OK) return rc;
         src = pf->map[1 - pf->map_cur];
     }
     if (int rc = slam_engine_sync(pf->e)) return rc;
-    return hipMemcpy(planes, src, 5 * L * n * 4, hipMemcpyDeviceToHost) == hipSuccess ? SLAM_OK : SLAM_ERR_HIP;
+    return hipMemcpy2D(rows, L * 4, src, Lp * 4, L * 4, 5 * n, hipMemcpyDeviceToHost) == hipSuccess ? SLAM_OK : SLAM_ERR_HIP;
 }
 
 }  // extern "C"

@@ -45,8 +45,8 @@ class HipOps:
     def motion_score(self, slot, src, anc, dst, n, first_id, dp, sigma, seed, frame, score, count):
         self.e.motion_score_dev(slot, src, anc, dst, n, first_id, dp, sigma, seed, frame, score, count)
 
-    def obs_set_dev(self, d_ids, d_zx, d_zy, nobs, d_unobs, nunobs, nlandmarks):
-        self.e.obs_set_dev(d_ids, d_zx, d_zy, nobs, d_unobs, nunobs, nlandmarks)
+    def obs_set_dev(self, d_zx_by_landmark, d_zy_by_landmark, nlandmarks):
+        self.e.obs_set_dev(d_zx_by_landmark, d_zy_by_landmark, nlandmarks)
 
     def logweight_ekf(self, score, gain, n, logw, d_max):
         self.e.logweight_ekf_dev(score, gain, n, logw, d_max)
@@ -54,8 +54,8 @@ class HipOps:
     def obs_upload(self, ids, zx, zy, nlandmarks):
         self.e.obs_upload(ids, zx, zy, nlandmarks)
 
-    def ekf(self, map_in, map_out, plane_stride, ld, nlandmarks, x, y, th, anc, n, meas_var, loglik):
-        self.e.ekf_update_dev(map_in, map_out, plane_stride, ld, nlandmarks, x, y, th, anc, n, meas_var, loglik)
+    def ekf(self, map_in, map_out, row_stride, plane_stride, nlandmarks, x, y, th, anc, n, meas_var, loglik):
+        self.e.ekf_update_dev(map_in, map_out, row_stride, plane_stride, nlandmarks, x, y, th, anc, n, meas_var, loglik)
 
     def logweight(self, score, loglik, gain, n, logw, d_max):
         self.e.logweight_dev(score, loglik, gain, n, logw, d_max)
@@ -84,19 +84,20 @@ class HipOps:
     def ancestors_sharded(self, first_all, n_total, n_local, rank, world, src):
         self.e.ancestors_sharded_dev(first_all, n_total, n_local, rank, world, src)
 
-    def migrate_pack(self, first_all, n_total, n_local, rank, world, send_lo, send_cnt, pose, pose_ld, mp, plane_stride,
-                     ld, nlandmarks, out):
+    def migrate_pack(self, first_all, n_total, n_local, rank, world, send_lo, send_cnt, pose, pose_ld, mp, row_stride,
+                     plane_stride, nlandmarks, out):
         self.e.migrate_pack_dev(first_all, n_total, n_local, rank, world, send_lo, send_cnt, pose, pose_ld, mp,
-                                plane_stride, ld, nlandmarks, out)
+                                row_stride, plane_stride, nlandmarks, out)
 
-    def migrate_unpack(self, inp, world, recv_cnt, n_local, pose, pose_ld, mp, plane_stride, ld, nlandmarks):
-        self.e.migrate_unpack_dev(inp, world, recv_cnt, n_local, pose, pose_ld, mp, plane_stride, ld, nlandmarks)
+    def migrate_unpack(self, inp, world, recv_cnt, n_local, pose, pose_ld, mp, row_stride, plane_stride, nlandmarks):
+        self.e.migrate_unpack_dev(inp, world, recv_cnt, n_local, pose, pose_ld, mp, row_stride, plane_stride, nlandmarks)
 
     def gather_f32(self, src, idx, n, dst):
         self.e.gather_f32_dev(src, idx, n, dst)
 
-    def gather_map(self, m_in, m_out, in_stride, out_stride, ld_in, ld_out, nlandmarks, idx, n):
-        self.e.gather_map_dev(m_in, m_out, in_stride, out_stride, ld_in, ld_out, nlandmarks, idx, n)
+    def gather_map(self, m_in, m_out, in_row_stride, out_row_stride, in_plane_stride, out_plane_stride, nlandmarks, idx, n):
+        self.e.gather_map_dev(m_in, m_out, in_row_stride, out_row_stride, in_plane_stride, out_plane_stride, nlandmarks,
+                              idx, n)
 
 
 class ParticleFilter:
@@ -121,7 +122,10 @@ class ParticleFilter:
         dv = self.device
         f32, i32, i64 = torch.float32, torch.int32, torch.int64
         self.pose = torch.zeros((2, 3, self.cap), dtype=f32, device=dv)         # [buffer][x,y,theta][particle]
-        self.map = torch.zeros((2, 5, self.L, self.cap), dtype=f32, device=dv) if self.L else None
+        # landmark maps: one row per particle, [buffer][particle][plane][Lp]; planes padded to 32 floats so that
+        # every row starts on a 128-byte boundary (include/slam_hip.h, slam_ekf_update_dev)
+        self.Lp = (self.L + 31) // 32 * 32
+        self.map = torch.zeros((2, self.cap, 5, self.Lp), dtype=f32, device=dv) if self.L else None
         self.cur = 0
         self.src_idx = None            # local gather indices left by the previous resample (None = identity)
         self.score = torch.zeros(self.n, dtype=f32, device=dv)
@@ -174,9 +178,9 @@ class ParticleFilter:
             self.pose[self.cur, k, : self.n] = torch.as_tensor(a, dtype=torch.float32).to(self.device)
         self.src_idx = None
 
-    def set_map(self, planes):
-        """planes: float32 [5][L][n_local]"""
-        self.map[self.cur, :, :, : self.n] = torch.as_tensor(planes, dtype=torch.float32).to(self.device)
+    def set_map(self, rows):
+        """rows: float32 [n_local][5][L] (mu_x, mu_y, P_xx, P_xy, P_yy per landmark)"""
+        self.map[self.cur, : self.n, :, : self.L] = torch.as_tensor(rows, dtype=torch.float32).to(self.device)
         self.src_idx = None
 
     def poses(self):
@@ -185,14 +189,16 @@ class ParticleFilter:
         return p[:, : self.n] if self.src_idx is None else p[:, self.src_idx.long()]
 
     def maps(self):
-        m = self.map[self.cur]
-        return m[:, :, : self.n] if self.src_idx is None else m[:, :, self.src_idx.long()]
+        """Current maps [n_local][5][L] with any pending resample gather applied."""
+        m = self.map[self.cur][:, :, : self.L]
+        return m[: self.n] if self.src_idx is None else m[self.src_idx.long()]
 
     # ------------------------------------------------------------------ one frame
     def step(self, dp, obs=None, obs_dev=None):
         """dp: odometry increment (3 floats).  Observations of this frame, either
         obs = (landmark ids, zx, zy) host arrays (uploaded here), or
-        obs_dev = (d_ids, d_zx, d_zy, nobs, d_unobserved_ids, nunobserved) already resident on the device."""
+        obs_dev = (d_zx_by_landmark, d_zy_by_landmark): the table form already resident on the device — entry l is
+        the observation of landmark l, NaN in zx = not observed this frame."""
         o, n, cur, nxt = self.ops, self.n, self.cur, 1 - self.cur
         src, dst = self.pose[cur], self.pose[nxt]
         # 1+2. motion (+ fused gather of the previous resample) and scan-match score, one launch
@@ -205,12 +211,11 @@ class ParticleFilter:
                 o.obs_set_dev(*obs_dev, self.L)
             else:
                 o.obs_upload(obs[0], obs[1], obs[2], self.L)
-            o.ekf(self.map[cur], self.map[nxt], self.L * self.cap, self.cap, self.L, dst[0], dst[1], dst[2],
+            o.ekf(self.map[cur], self.map[nxt], 5 * self.Lp, self.Lp, self.L, dst[0], dst[1], dst[2],
                   self.src_idx, n, self.meas_var, None)
         elif self.L > 0:   # no observation this frame: the maps still have to follow their particles
             idx = self.src_idx if self.src_idx is not None else torch.arange(n, dtype=torch.int32, device=self.device)
-            o.gather_map(self.map[cur], self.map[nxt], self.L * self.cap, self.L * self.cap, self.cap, self.cap,
-                         self.L, idx, n)
+            o.gather_map(self.map[cur], self.map[nxt], 5 * self.Lp, 5 * self.Lp, self.Lp, self.Lp, self.L, idx, n)
         # 4. weights (fused form: the fixed-point weights are scanned as they are produced, never stored)
         multi = self.multi
         if use_ll:
@@ -275,9 +280,9 @@ class ParticleFilter:
         pose = self.pose[self.cur]
         mp = self.map[self.cur] if L else None
         o.migrate_pack(self.first_all, self.n_total, n, r, G, [lo for lo, _ in send], scnt, pose, self.cap, mp,
-                       L * self.cap, self.cap, L, sbuf)
+                       5 * self.Lp, self.Lp, L, sbuf)
         self._all_to_all(rbuf, sbuf, [rows * c for c in rcnt], [rows * c for c in scnt])
-        o.migrate_unpack(rbuf, G, rcnt, n, pose, self.cap, mp, L * self.cap, self.cap, L)
+        o.migrate_unpack(rbuf, G, rcnt, n, pose, self.cap, mp, 5 * self.Lp, self.Lp, L)
 
     # ------------------------------------------------------------------ estimate
     def best_particle(self):

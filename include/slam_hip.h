@@ -175,26 +175,35 @@ int slam_motion_score_dev(slam_engine *e, int slot, const float *d_src_x, const 
 
 /* A10: per-particle x per-landmark 2x2 EKF correction (FastSLAM 1.0, known correspondences,
  * cartesian sensor-frame observations z = H (m - t), H = [[ct,-st],[st,ct]]).
- * The observation list of the current frame is sensor data like the scan: upload it once per frame
- * with slam_obs_upload_host (landmark ids must be unique and < nlandmarks; nobs <= SLAM_MAX_OBS).
- * The map is 5 planes [L][ld_map] (mu_x, mu_y, P_xx, P_xy, P_yy), particle index fastest, plane p
- * at d_map + p * plane_stride.  For every observed landmark: read the 5 values of
- * (landmark, src(i)), update, write them to (landmark, i) of the output planes; the observation
- * log-likelihoods are summed per chunk of 32 observations and then over chunks into loglik[i]
- * (overwritten).  With d_anc != NULL the resample gather is fused in (src(i) = anc[i], a local
- * index; requires d_map_in != d_map_out); landmarks without an observation are copied through when
- * the update is out of place.  P_xx < 0 marks a landmark not seen yet: it is initialised from the
- * observation and contributes no likelihood. */
+ * The observations of the current frame are sensor data like the scan: hand them over once per frame,
+ * either as a list from the host (slam_obs_upload_host: landmark ids unique and < nlandmarks, no NaN
+ * measurements, nlandmarks <= SLAM_MAX_OBS) or as a table that is already on the device
+ * (slam_obs_set_dev).  Inside the engine they are a table indexed by landmark either way.
+ * The map is ONE ROW PER PARTICLE: value (plane p, landmark l) of particle i lives at
+ * d_map[i * row_stride + p * plane_stride + l], planes mu_x, mu_y, P_xx, P_xy, P_yy, strides in floats
+ * (plane_stride >= nlandmarks, row_stride >= 5 * plane_stride; plane_stride a multiple of 32 keeps every
+ * row 128-byte aligned and is what the engine's own session uses).  For every observed landmark: read
+ * the 5 values of row src(i), update, write them to row i of the output map.  With d_anc != NULL the
+ * resample gather is fused in (src(i) = anc[i], a local index; requires d_map_in != d_map_out);
+ * landmarks without an observation are copied through when the update is out of place.  P_xx < 0 marks
+ * a landmark not seen yet: it is initialised from the observation and contributes no likelihood.
+ * The padding columns [nlandmarks, plane_stride) of an output row are unspecified after an out-of-place
+ * update (whole 128-landmark batches that fit into the row are processed without predication, padding
+ * included, so a plane_stride that is a multiple of 128 is the fastest).
+ * loglik[i] (overwritten) is the sum of the observation log-likelihoods in a fixed order: landmark l adds
+ * its term to accumulator l mod 128 in order of l (nothing for a landmark without an observation),
+ * accumulators j and j+64 are added, and the 64 sums are reduced by a 6-level xor butterfly
+ * (t[j] += t[j ^ s], s = 1..32).  The order of the observation list does not matter. */
 enum { SLAM_MAX_OBS = 8192 };
 int slam_obs_upload_host(slam_engine *e, const int32_t *landmark_id, const float *zx, const float *zy, int nobs,
                          int nlandmarks);
-/* Same, for an observation list that is already on the device (nothing is copied or checked: ids must be
- * unique, d_unobserved_id must list the nlandmarks - nobs landmarks without an observation). */
-int slam_obs_set_dev(slam_engine *e, const int32_t *d_landmark_id, const float *d_zx, const float *d_zy, int nobs,
-                     const int32_t *d_unobserved_id, int nunobserved, int nlandmarks);
-/* d_loglik may be NULL: the per-chunk partial sums then stay inside the engine and are added up, in the
- * specified order, by slam_logweight_ekf_dev (one launch less per frame). */
-int slam_ekf_update_dev(slam_engine *e, const float *d_map_in, float *d_map_out, int64_t plane_stride, int ld_map,
+/* Observations already on the device, as the table the engine works on: entry l of the two arrays is the
+ * observation of landmark l, NaN in d_zx_by_landmark[l] = landmark l was not observed this frame.  Nothing is
+ * copied: the arrays must stay valid until the EKF call that uses them has run. */
+int slam_obs_set_dev(slam_engine *e, const float *d_zx_by_landmark, const float *d_zy_by_landmark, int nlandmarks);
+/* d_loglik may be NULL: the log-likelihoods always stay inside the engine as well, where
+ * slam_logweight_ekf_dev picks them up. */
+int slam_ekf_update_dev(slam_engine *e, const float *d_map_in, float *d_map_out, int64_t row_stride, int plane_stride,
                         int nlandmarks, const float *d_x, const float *d_y, const float *d_th, const int32_t *d_anc,
                         int n, float meas_var, float *d_loglik);
 
@@ -254,18 +263,19 @@ uint64_t slam_comb_offset(uint64_t seed, uint32_t frame, uint64_t total);
  *    contiguous slot run because `first` is sorted).  Needs nothing from the host.
  *  - slam_migrate_pack_dev: one launch packs, for every destination q, the send_cnt[q] consecutive slots
  *    starting at global slot send_lo[q] (host arrays of `world` entries, 0 for this rank itself) whose
- *    ancestors are this rank's particles, as block q = [3 + 5*nlandmarks][send_cnt[q]] floats (x, y, theta,
- *    then the five map planes landmark by landmark) — the layout of one all-to-all send buffer.
- *  - slam_migrate_unpack_dev: the received blocks (recv_cnt[q] particles from rank q, same block layout)
- *    into the staging tail of the pose arrays (leading dimension pose_ld, rows x|y|theta) and map planes. */
+ *    ancestors are this rank's particles, as block q = send_cnt[q] records of 3 + 5*nlandmarks floats (x, y,
+ *    theta, then the five map planes of nlandmarks values each) — the layout of one all-to-all send buffer.
+ *  - slam_migrate_unpack_dev: the received blocks (recv_cnt[q] records from rank q, same layout) into the
+ *    staging tail of the pose arrays (rows x|y|theta, leading dimension pose_ld = particle capacity, which
+ *    the map must have as rows too) and of the map. */
 int slam_ancestors_sharded_dev(slam_engine *e, const int32_t *d_first_all, int64_t n_total, int n_local, int rank,
                                int world, int32_t *d_src);
 int slam_migrate_pack_dev(slam_engine *e, const int32_t *d_first_all, int64_t n_total, int n_local, int rank,
                           int world, const int64_t *send_lo, const int32_t *send_cnt, const float *d_pose,
-                          int64_t pose_ld, const float *d_map, int64_t plane_stride, int ld_map, int nlandmarks,
+                          int64_t pose_ld, const float *d_map, int64_t row_stride, int plane_stride, int nlandmarks,
                           float *d_out);
 int slam_migrate_unpack_dev(slam_engine *e, const float *d_in, int world, const int32_t *recv_cnt, int n_local,
-                            float *d_pose, int64_t pose_ld, float *d_map, int64_t plane_stride, int ld_map,
+                            float *d_pose, int64_t pose_ld, float *d_map, int64_t row_stride, int plane_stride,
                             int nlandmarks);
 
 /* Index (lowest on ties) and value of the largest element: the heaviest particle. */
@@ -274,8 +284,10 @@ int slam_argmax_dev(slam_engine *e, const float *d_values, int n, int32_t *d_ind
 /* Plain gather of particle attributes through an index (used when the gather is not fused into the
  * next stage, and to pack rows for migration between GPUs). */
 int slam_gather_f32_dev(slam_engine *e, const float *d_src, const int32_t *d_idx, int n, float *d_dst);
-int slam_gather_map_dev(slam_engine *e, const float *d_map_in, float *d_map_out, int64_t in_plane_stride,
-                        int64_t out_plane_stride, int ld_in, int ld_out, int nlandmarks, const int32_t *d_idx, int n);
+/* map rows: out row i = in row d_idx[i] (strides as in slam_ekf_update_dev) */
+int slam_gather_map_dev(slam_engine *e, const float *d_map_in, float *d_map_out, int64_t in_row_stride,
+                        int64_t out_row_stride, int in_plane_stride, int out_plane_stride, int nlandmarks,
+                        const int32_t *d_idx, int n);
 
 /* ------------------------------------------------------------------ particle-filter session
  * Convenience object for hosts that do not manage device memory themselves (a plain C program): it owns
@@ -300,14 +312,14 @@ int slam_pf_destroy(slam_pf *pf);
 /* all particles at `pose`; maps (if any) marked "not seen yet" */
 int slam_pf_reset(slam_pf *pf, const float pose[3]);
 int slam_pf_set_poses_host(slam_pf *pf, const float *x, const float *y, const float *theta);
-int slam_pf_set_map_host(slam_pf *pf, const float *planes /* [5][n_landmarks][n_particles] */);
+int slam_pf_set_map_host(slam_pf *pf, const float *rows /* [n_particles][5][n_landmarks] */);
 /* one frame against grid `slot`; asynchronous */
 int slam_pf_step(slam_pf *pf, int slot, const float dp[3], int use_observations);
 /* heaviest particle of the last frame (lowest index on ties): its pose, log-weight and index; synchronises */
 int slam_pf_best(slam_pf *pf, float pose[3], float *logw, int32_t *index);
 /* current particles with the pending resample gather applied; synchronises */
 int slam_pf_get_poses_host(slam_pf *pf, float *x, float *y, float *theta);
-int slam_pf_get_map_host(slam_pf *pf, float *planes);
+int slam_pf_get_map_host(slam_pf *pf, float *rows /* [n_particles][5][n_landmarks] */);
 
 /* ------------------------------------------------------------------ mapper: the reference's frame loop in one call
  * (SURVEY.md §8f rows N1 + N2).  One slam_mapper_next_frame = one iteration of the reference's loop

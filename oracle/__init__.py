@@ -262,14 +262,16 @@ def motion_sample(src_x, src_y, src_th, anc, n, first_id, dp, sigma, seed, frame
 
 
 def ekf_update(map_in, x, y, th, anc, obs_id, obs_zx, obs_zy, meas_var, n=None):
-    """map_in: float32 [5][L][ld].  Returns (map_out [5][L][ld], loglik[n]); out of place."""
+    """map_in: float32 [rows][5][L] (one row per particle).  Returns (map_out, loglik[n]); out of place."""
     map_in = _f32(map_in)
-    _, L_, ld = map_in.shape
+    rows, five, L_ = map_in.shape
     n = len(x) if n is None else n
+    if five != 5 or rows < n or (len(obs_id) and (np.min(obs_id) < 0 or np.max(obs_id) >= L_)):
+        raise ValueError("ekf_update: map must be [rows >= n][5][L] and landmark ids < L")
     out = map_in.copy()
     ll = np.empty(n, np.float32)
     keep, ancp = _opt_i32(anc)
-    lib().orc_ekf_update(map_in, out, L_ * ld, ld, L_, _f32(x), _f32(y), _f32(th), ancp, n,
+    lib().orc_ekf_update(map_in, out, 5 * L_, L_, L_, _f32(x), _f32(y), _f32(th), ancp, n,
                          np.ascontiguousarray(obs_id, np.int32), _f32(obs_zx), _f32(obs_zy), len(obs_id), meas_var, ll)
     return out, ll
 

@@ -201,78 +201,83 @@ void orc_motion_sample(const float *src_x, const float *src_y, const float *src_
 
 /* ------------------------------------------------------------------ A10 */
 
-void orc_ekf_update(const float *map_in, float *map_out, int64_t plane_stride, int ld, int nlandmarks,
+void orc_ekf_update(const float *map_in, float *map_out, int64_t row_stride, int plane_stride, int nlandmarks,
                     const float *x, const float *y, const float *th, const int32_t *anc, int n,
                     const int32_t *obs_id, const float *obs_zx, const float *obs_zy, int nobs, float meas_var,
                     float *loglik)
 {
-    const float *in[5];
-    float *out[5];
-    for (int p = 0; p < 5; ++p) {
-        in[p] = map_in + p * plane_stride;
-        out[p] = map_out + p * plane_stride;
-    }
-    /* landmarks without an observation this frame: gathered copy when the update is out of place */
-    if (map_in != map_out) {
-        char *seen = (char *)calloc((size_t)(nlandmarks > 0 ? nlandmarks : 1), 1);
-        for (int k = 0; k < nobs; ++k) seen[obs_id[k]] = 1;
-        for (int l = 0; l < nlandmarks; ++l) {
-            if (seen[l]) continue;
-            for (int p = 0; p < 5; ++p)
-                for (int i = 0; i < n; ++i)
-                    out[p][(size_t)l * ld + i] = in[p][(size_t)l * ld + (anc ? anc[i] : i)];
-        }
-        free(seen);
-    }
     const float q = meas_var;
+    /* observation of landmark l, if any (ids are unique) */
+    int *obs_of = (int *)malloc(sizeof(int) * (size_t)(nlandmarks > 0 ? nlandmarks : 1));
+    for (int l = 0; l < nlandmarks; ++l) obs_of[l] = -1;
+    for (int k = 0; k < nobs; ++k) obs_of[obs_id[k]] = k;
+    /* landmark slots are padded to whole groups of 128; a padded or unobserved slot contributes +0.0f */
+    const int nslots = (nlandmarks + ORC_EKF_LANES - 1) / ORC_EKF_LANES * ORC_EKF_LANES;
+    const size_t ps = (size_t)plane_stride;
     for (int i = 0; i < n; ++i) {
+        const int src = anc ? anc[i] : i;
+        const float *in = map_in + (size_t)src * row_stride;
+        float *out = map_out + (size_t)i * row_stride;
         float st, ct;
         orc_det_sincosf(th[i], &st, &ct);
         const float px = x[i], py = y[i];
-        const int src = anc ? anc[i] : i;
-        float total = 0.0f;
-        for (int k0 = 0; k0 < nobs; k0 += ORC_EKF_OBS_CHUNK) {
-            float part = 0.0f;
-            const int k1 = k0 + ORC_EKF_OBS_CHUNK < nobs ? k0 + ORC_EKF_OBS_CHUNK : nobs;
-            for (int k = k0; k < k1; ++k) {
-                const size_t ri = (size_t)obs_id[k] * ld + src, wi = (size_t)obs_id[k] * ld + i;
-                const float mx = in[0][ri], my = in[1][ri], pxx = in[2][ri], pxy = in[3][ri], pyy = in[4][ri];
+        float lane[ORC_EKF_LANES];
+        for (int j = 0; j < ORC_EKF_LANES; ++j) lane[j] = 0.0f;
+        for (int l = 0; l < nslots; ++l) {
+            float ll = 0.0f;
+            const int k = l < nlandmarks ? obs_of[l] : -1;
+            if (l < nlandmarks && k < 0) {
+                /* no observation this frame: gathered copy when the update is out of place */
+                if (map_in != map_out)
+                    for (int p = 0; p < 5; ++p) out[p * ps + l] = in[p * ps + l];
+            } else if (k >= 0) {
+                const float mx = in[l], my = in[ps + l], pxx = in[2 * ps + l], pxy = in[3 * ps + l], pyy = in[4 * ps + l];
                 const float zx = obs_zx[k], zy = obs_zy[k];
                 if (pxx < 0.0f) {
-                    /* first sighting: place the landmark at the observed point, P = R */
-                    out[0][wi] = px + (ct * zx + st * zy);
-                    out[1][wi] = py + (ct * zy - st * zx);
-                    out[2][wi] = q;
-                    out[3][wi] = 0.0f;
-                    out[4][wi] = q;
-                    continue;
+                    /* first sighting: place the landmark at the observed point, P = R; no likelihood term */
+                    out[l] = px + (ct * zx + st * zy);
+                    out[ps + l] = py + (ct * zy - st * zx);
+                    out[2 * ps + l] = q;
+                    out[3 * ps + l] = 0.0f;
+                    out[4 * ps + l] = q;
+                } else {
+                    /* h(mu) = H (mu - t), H = [[ct,-st],[st,ct]] (inverse of the reference's R^T, main.c:115-116) */
+                    const float dx = mx - px, dy = my - py;
+                    const float vx = zx - (ct * dx - st * dy);
+                    const float vy = zy - (st * dx + ct * dy);
+                    const float a00 = ct * pxx - st * pxy, a01 = ct * pxy - st * pyy;   /* A = H P */
+                    const float a10 = st * pxx + ct * pxy, a11 = st * pxy + ct * pyy;
+                    const float s00 = (a00 * ct - a01 * st) + q;                         /* S = A H^T + R */
+                    const float s01 = a00 * st + a01 * ct;
+                    const float s11 = (a10 * st + a11 * ct) + q;
+                    const float det = s00 * s11 - s01 * s01;
+                    const float idet = 1.0f / det;
+                    const float i00 = s11 * idet, i01 = -s01 * idet, i11 = s00 * idet;
+                    const float k00 = a00 * i00 + a10 * i01, k01 = a00 * i01 + a10 * i11;   /* K = A^T S^-1 */
+                    const float k10 = a01 * i00 + a11 * i01, k11 = a01 * i01 + a11 * i11;
+                    out[l] = mx + (k00 * vx + k01 * vy);
+                    out[ps + l] = my + (k10 * vx + k11 * vy);
+                    out[2 * ps + l] = pxx - (k00 * a00 + k01 * a10);                      /* P - K A */
+                    out[3 * ps + l] = pxy - (k00 * a01 + k01 * a11);
+                    out[4 * ps + l] = pyy - (k10 * a01 + k11 * a11);
+                    const float maha = vx * (i00 * vx + i01 * vy) + vy * (i01 * vx + i11 * vy);
+                    ll = ((0.0f - 0.5f * maha) - 0.5f * orc_det_logf(det)) - 1.8378770664f;
                 }
-                /* h(mu) = H (mu - t), H = [[ct,-st],[st,ct]] (inverse of the reference's R^T, main.c:115-116) */
-                const float dx = mx - px, dy = my - py;
-                const float vx = zx - (ct * dx - st * dy);
-                const float vy = zy - (st * dx + ct * dy);
-                const float a00 = ct * pxx - st * pxy, a01 = ct * pxy - st * pyy;   /* A = H P */
-                const float a10 = st * pxx + ct * pxy, a11 = st * pxy + ct * pyy;
-                const float s00 = (a00 * ct - a01 * st) + q;                         /* S = A H^T + R */
-                const float s01 = a00 * st + a01 * ct;
-                const float s11 = (a10 * st + a11 * ct) + q;
-                const float det = s00 * s11 - s01 * s01;
-                const float idet = 1.0f / det;
-                const float i00 = s11 * idet, i01 = -s01 * idet, i11 = s00 * idet;
-                const float k00 = a00 * i00 + a10 * i01, k01 = a00 * i01 + a10 * i11;   /* K = A^T S^-1 */
-                const float k10 = a01 * i00 + a11 * i01, k11 = a01 * i01 + a11 * i11;
-                out[0][wi] = mx + (k00 * vx + k01 * vy);
-                out[1][wi] = my + (k10 * vx + k11 * vy);
-                out[2][wi] = pxx - (k00 * a00 + k01 * a10);                          /* P - K A */
-                out[3][wi] = pxy - (k00 * a01 + k01 * a11);
-                out[4][wi] = pyy - (k10 * a01 + k11 * a11);
-                const float maha = vx * (i00 * vx + i01 * vy) + vy * (i01 * vx + i11 * vy);
-                part = ((part - 0.5f * maha) - 0.5f * orc_det_logf(det)) - 1.8378770664f;
             }
-            total = total + part;
+            /* summation order (the specification): landmark l goes to accumulator l mod 128, in order of l ... */
+            lane[l % ORC_EKF_LANES] = lane[l % ORC_EKF_LANES] + ll;
         }
-        loglik[i] = total;
+        /* ... then accumulators j and j+64 are added, then a 6-level xor butterfly over the 64 sums */
+        float t[64];
+        for (int j = 0; j < 64; ++j) t[j] = lane[j] + lane[j + 64];
+        for (int s = 1; s < 64; s <<= 1) {
+            float u[64];
+            for (int j = 0; j < 64; ++j) u[j] = t[j] + t[j ^ s];
+            for (int j = 0; j < 64; ++j) t[j] = u[j];
+        }
+        loglik[i] = t[0];
     }
+    free(obs_of);
 }
 
 /* ------------------------------------------------------------------ A11 */

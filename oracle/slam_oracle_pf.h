@@ -45,9 +45,15 @@ void orc_motion_sample(const float *src_x, const float *src_y, const float *src_
                        float *y, float *th, int n, int64_t first_id, const float dp[3], const float sigma[3],
                        uint64_t seed, uint32_t frame);
 
-/* ---- A10 per-particle x per-landmark 2x2 EKF (map = 5 planes [L][ld]: mu_x mu_y P_xx P_xy P_yy) */
-enum { ORC_EKF_OBS_CHUNK = 32 };   /* log-likelihood is summed per chunk of observations, then over chunks */
-void orc_ekf_update(const float *map_in, float *map_out, int64_t plane_stride, int ld, int nlandmarks,
+/* ---- A10 per-particle x per-landmark 2x2 EKF.  The map is one row per particle: value (plane p, landmark l) of
+ * particle i at map[i * row_stride + p * plane_stride + l], planes mu_x mu_y P_xx P_xy P_yy.
+ * Log-likelihood summation order (part of the specification): the landmarks are walked by index; landmark l
+ * adds its term to accumulator l mod 128 (+0.0f when it has no observation, on a first sighting, and for the
+ * slots that pad the count to a multiple of 128); accumulators j and j+64 are added; the 64 sums are reduced
+ * by a 6-level xor butterfly t[j] = t[j] + t[j ^ s], s = 1, 2, 4, 8, 16, 32.  The order of the observation
+ * list does not matter (landmark ids in it are unique). */
+enum { ORC_EKF_LANES = 128 };
+void orc_ekf_update(const float *map_in, float *map_out, int64_t row_stride, int plane_stride, int nlandmarks,
                     const float *x, const float *y, const float *th, const int32_t *anc, int n,
                     const int32_t *obs_id, const float *obs_zx, const float *obs_zy, int nobs, float meas_var,
                     float *loglik);

@@ -32,8 +32,10 @@ class OracleOps:
         self.motion_sample(src, anc, dst, n, first_id, dp, sigma, seed, frame)
         self.score(slot, dst[0], dst[1], dst[2], n, score, count)
 
-    def obs_set_dev(self, d_ids, d_zx, d_zy, nobs, d_unobs, nunobs, nlandmarks):
-        self.obs = (_np(d_ids)[:nobs].copy(), _np(d_zx)[:nobs].copy(), _np(d_zy)[:nobs].copy())
+    def obs_set_dev(self, d_zx_by_landmark, d_zy_by_landmark, nlandmarks):
+        zx, zy = _np(d_zx_by_landmark)[:nlandmarks], _np(d_zy_by_landmark)[:nlandmarks]
+        ids = np.flatnonzero(~np.isnan(zx)).astype(np.int32)
+        self.obs = (ids, zx[ids].copy(), zy[ids].copy())
 
     def logweight_ekf(self, score, gain, n, logw, d_max):
         self.logweight(score, torch.from_numpy(self._ll), gain, n, logw, d_max)
@@ -41,11 +43,11 @@ class OracleOps:
     def obs_upload(self, ids, zx, zy, nlandmarks):
         self.obs = (np.asarray(ids, np.int32), np.asarray(zx, np.float32), np.asarray(zy, np.float32))
 
-    def ekf(self, map_in, map_out, plane_stride, ld, nlandmarks, x, y, th, anc, n, meas_var, loglik):
+    def ekf(self, map_in, map_out, row_stride, plane_stride, nlandmarks, x, y, th, anc, n, meas_var, loglik):
         L = oracle.lib()
         ll = np.empty(n, np.float32)
         a = _np(anc)
-        L.orc_ekf_update(_np(map_in).reshape(5, nlandmarks, ld), _np(map_out).reshape(5, nlandmarks, ld), plane_stride, ld,
+        L.orc_ekf_update(_np(map_in), _np(map_out), row_stride, plane_stride,
                          nlandmarks, _np(x), _np(y), _np(th), a.ctypes.data_as(C.c_void_p) if a is not None else None, n,
                          self.obs[0], self.obs[1], self.obs[2], len(self.obs[0]), meas_var, ll)
         self._ll = ll
@@ -110,36 +112,31 @@ class OracleOps:
         out = np.where(owner == rank, g - lo_me, n_local + np.array(off)[owner] + (j - np.array(lo)[owner]))
         src[:n_local] = torch.from_numpy(out.astype(np.int32))
 
-    def migrate_pack(self, first_all, n_total, n_local, rank, world, send_lo, send_cnt, pose, pose_ld, mp, plane_stride,
-                     ld, nlandmarks, out):
-        rows, off = 3 + 5 * nlandmarks, 0
+    def migrate_pack(self, first_all, n_total, n_local, rank, world, send_lo, send_cnt, pose, pose_ld, mp, row_stride,
+                     plane_stride, nlandmarks, out):
+        rec, off = 3 + 5 * nlandmarks, 0
         for d in range(world):
             c = send_cnt[d]
             if not c:
                 continue
             loc = torch.from_numpy((oracle.ancestors(_np(first_all)[:n_total], send_lo[d], c) - rank * n_local).astype(np.int64))
-            blk = out[rows * off: rows * (off + c)].view(rows, c)
-            blk[:3] = pose[:, loc]
+            blk = out[rec * off: rec * (off + c)].view(c, rec)
+            blk[:, :3] = pose[:, loc].T
             if nlandmarks:
-                blk[3:] = mp[:, :, loc].reshape(5 * nlandmarks, c)
+                blk[:, 3:] = mp[loc][:, :, :nlandmarks].reshape(c, 5 * nlandmarks)
             off += c
 
-    def migrate_unpack(self, inp, world, recv_cnt, n_local, pose, pose_ld, mp, plane_stride, ld, nlandmarks):
-        rows, off = 3 + 5 * nlandmarks, 0
-        for s in range(world):
-            c = recv_cnt[s]
-            if not c:
-                continue
-            blk = inp[rows * off: rows * (off + c)].view(rows, c)
-            pose[:, n_local + off: n_local + off + c] = blk[:3]
-            if nlandmarks:
-                mp[:, :, n_local + off: n_local + off + c] = blk[3:].view(5, nlandmarks, c)
-            off += c
+    def migrate_unpack(self, inp, world, recv_cnt, n_local, pose, pose_ld, mp, row_stride, plane_stride, nlandmarks):
+        rec, tot = 3 + 5 * nlandmarks, int(sum(recv_cnt))
+        if not tot:
+            return
+        blk = inp[: rec * tot].view(tot, rec)
+        pose[:, n_local: n_local + tot] = blk[:, :3].T
+        if nlandmarks:
+            mp[n_local: n_local + tot, :, :nlandmarks] = blk[:, 3:].view(tot, 5, nlandmarks)
 
     def gather_f32(self, src, idx, n, dst):
         dst[:n] = src[idx[:n].long()]
 
-    def gather_map(self, m_in, m_out, in_stride, out_stride, ld_in, ld_out, nlandmarks, idx, n):
-        src = torch.as_strided(m_in, (5, nlandmarks, ld_in), (in_stride, ld_in, 1), m_in.storage_offset())
-        out = torch.as_strided(m_out, (5, nlandmarks, ld_out), (out_stride, ld_out, 1), m_out.storage_offset())
-        out[:, :, :n] = src[:, :, idx[:n].long()]
+    def gather_map(self, m_in, m_out, in_row_stride, out_row_stride, in_plane_stride, out_plane_stride, nlandmarks, idx, n):
+        m_out[:n, :, :nlandmarks] = m_in[idx[:n].long()][:, :, :nlandmarks]

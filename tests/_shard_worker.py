@@ -44,7 +44,7 @@ def init_state(n_total, L, lm, seed=5):
     mp[2] = 0.05; mp[4] = 0.05
     if L:
         mp[2, L - 1] = -1.0   # one landmark not seen yet
-    return x, y, th, mp
+    return x, y, th, np.ascontiguousarray(mp.transpose(2, 0, 1))   # one row per particle: [n][5][L]
 
 
 def observations(lm, frame):
@@ -71,7 +71,7 @@ def run_filter(rank, world, n_total, L, frames, group=None):
     sl = slice(rank * n, (rank + 1) * n)
     pf.set_poses(x[sl], y[sl], th[sl])
     if L:
-        pf.set_map(mp[:, :, sl])
+        pf.set_map(mp[sl])
     migrated = []
     for f in range(frames):
         pf.step([0.01, -0.005, 0.002], observations(lm, f) if L else None)
@@ -122,7 +122,7 @@ def worker_gpu(rank, world, port, n_total, L, frames, outdir):
         sl = slice(rank * n, (rank + 1) * n)
         pf.set_poses(x[sl], y[sl], th[sl])
         if L:
-            pf.set_map(mp[:, :, sl])
+            pf.set_map(mp[sl])
         migrated = []
         for f in range(frames):
             pf.step([0.01, -0.005, 0.002], observations(lm, f) if L else None)

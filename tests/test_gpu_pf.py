@@ -65,44 +65,49 @@ def test_motion_sample(eng, orc, n, first_id, with_anc):
     assert np.array_equal(bits(host(th)), bits(wt))
 
 
-def _rand_map(rng, L, ld, n):
-    mp = np.zeros((5, L, ld), np.float32)
-    mp[0:2] = rng.normal(0, 3, (2, L, ld))
-    A = rng.normal(0, 0.3, (L, ld, 2, 2))
+def _rand_map(rng, L, rows, Lp=None):
+    """Random maps in the engine's layout, one row per particle: [rows][5][Lp]; columns >= L are padding (-555)."""
+    Lp = L if Lp is None else Lp
+    mp = np.full((rows, 5, Lp), -555.0, np.float32)
+    mp[:, 0:2, :L] = rng.normal(0, 3, (rows, 2, L))
+    A = rng.normal(0, 0.3, (rows, L, 2, 2))
     P = A @ np.swapaxes(A, -1, -2) + 0.02 * np.eye(2)
-    mp[2], mp[3], mp[4] = P[..., 0, 0], P[..., 0, 1], P[..., 1, 1]
-    mp[2, rng.integers(0, L, max(L // 10, 1))] = -1.0   # a few landmarks not seen yet
+    mp[:, 2, :L], mp[:, 3, :L], mp[:, 4, :L] = P[..., 0, 0], P[..., 0, 1], P[..., 1, 1]
+    mp[:, 2, rng.integers(0, L, max(L // 10, 1))] = -1.0   # a few landmarks not seen yet
     return mp
 
 
-@pytest.mark.parametrize("n,L,nobs,with_anc", [
-    (5000, 40, 40, False),      # everything observed, 2 chunks
-    (5000, 40, 7, True),        # subset observed + fused gather: copy-through of the other 33
-    (300, 500, 500, True),      # BASELINE config 2 landmark count, 16 chunks
-    (1, 3, 3, False), (4097, 33, 33, True), (256, 10, 0, True),
+@pytest.mark.parametrize("n,L,Lp,nobs,with_anc", [
+    (5000, 40, 64, 40, False),       # everything observed, one partly filled batch
+    (5000, 40, 43, 7, True),         # subset observed + fused gather: copy-through of the other 33; rows not 128-B aligned
+    (300, 500, 512, 500, True),      # BASELINE config 2 landmark count: 4 batches of 128, the last one partial
+    (300, 700, 704, 641, True),      # accumulators reused across batches, partial last batch, 59 copied through
+    (1, 3, 3, 3, False), (4097, 33, 64, 33, True), (256, 10, 32, 0, True), (130, 128, 128, 128, False),
+    (77, 129, 160, 129, True), (64, 300, 320, 1, True), (50, 257, 257, 200, True), (9, 1, 1, 1, False),
 ])
-def test_ekf_update(eng, orc, n, L, nobs, with_anc):
+def test_ekf_update(eng, orc, n, L, Lp, nobs, with_anc):
+    import ctypes as C
     rng = np.random.default_rng(n * 31 + L)
-    ld = n + 37 if with_anc else n
-    mp = _rand_map(rng, L, ld, n)
+    rows = n + 37 if with_anc else n
+    mp = _rand_map(rng, L, rows, Lp)
     x, y, th = (rng.normal(0, 1, n).astype(np.float32) for _ in range(3))
-    anc = np.sort(rng.integers(0, ld, n)).astype(np.int32) if with_anc else None
+    anc = np.sort(rng.integers(0, rows, n)).astype(np.int32) if with_anc else None
     ids = rng.permutation(L)[:nobs].astype(np.int32)
     zx, zy = rng.normal(0, 2, nobs).astype(np.float32), rng.normal(0, 2, nobs).astype(np.float32)
     d_in = dev(mp)
-    d_out = torch.full((5, L, ld), -777.0, device=DEV)
+    d_out = torch.full((rows, 5, Lp), -777.0, device=DEV)
     ll = torch.empty(n, device=DEV)
     eng.obs_upload(ids, zx, zy, L)
-    eng.ekf_update_dev(d_in, d_out, L * ld, ld, L, dev(x), dev(y), dev(th), dev(anc) if with_anc else None, n, 0.015, ll)
-    # oracle works in place on a copy; its columns >= n are untouched copies of the input
-    want = np.full((5, L, ld), -777.0, np.float32)
+    eng.ekf_update_dev(d_in, d_out, 5 * Lp, Lp, L, dev(x), dev(y), dev(th), dev(anc) if with_anc else None, n, 0.015, ll)
+    want = np.full((rows, 5, Lp), -777.0, np.float32)
     wl = np.empty(n, np.float32)
-    import ctypes as C
-    orc.lib().orc_ekf_update(mp, want, L * ld, ld, L, x, y, th, anc.ctypes.data_as(C.c_void_p) if with_anc else None, n,
+    orc.lib().orc_ekf_update(mp, want, 5 * Lp, Lp, L, x, y, th, anc.ctypes.data_as(C.c_void_p) if with_anc else None, n,
                              ids, zx, zy, nobs, 0.015, wl)
     got = host(d_out)
-    assert np.array_equal(bits(got[:, :, :n]), bits(want[:, :, :n]))
-    assert np.all(got[:, :, n:] == -777.0)              # nothing written beyond the n particles
+    assert np.array_equal(bits(got[:, :, :L]), bits(want[:, :, :L]))
+    assert np.all(got[n:] == -777.0)                      # nothing written to rows >= n
+    pad = got[:n, :, L:]                                  # row padding: left alone, or carried over from the source row
+    assert np.all((pad == -777.0) | (pad == -555.0))
     assert np.array_equal(bits(host(ll)), bits(wl))
 
 
@@ -110,24 +115,37 @@ def test_ekf_in_place_and_argument_checks(eng, orc):
     pkg = load_package()
     rng = np.random.default_rng(2)
     n, L = 1000, 12
-    mp = _rand_map(rng, L, n, n)
+    mp = _rand_map(rng, L, n)
     x, y, th = (rng.normal(0, 1, n).astype(np.float32) for _ in range(3))
     ids = np.arange(L, dtype=np.int32)
     zx, zy = rng.normal(0, 2, L).astype(np.float32), rng.normal(0, 2, L).astype(np.float32)
     d = dev(mp)
     ll = torch.empty(n, device=DEV)
     eng.obs_upload(ids, zx, zy, L)
-    eng.ekf_update_dev(d, d, L * n, n, L, dev(x), dev(y), dev(th), None, n, 0.02, ll)   # in place, no gather
+    eng.ekf_update_dev(d, d, 5 * L, L, L, dev(x), dev(y), dev(th), None, n, 0.02, ll)   # in place, no gather
     want, wl = orc.ekf_update(mp, x, y, th, None, ids, zx, zy, 0.02)
     assert np.array_equal(bits(host(d)), bits(want)) and np.array_equal(bits(host(ll)), bits(wl))
+    # in place with only some landmarks observed: the others stay as they are
+    eng.obs_upload(ids[:5], zx[:5], zy[:5], L)
+    before = host(d).copy()
+    eng.ekf_update_dev(d, d, 5 * L, L, L, dev(x), dev(y), dev(th), None, n, 0.02, ll)
+    want2, wl2 = orc.ekf_update(before, x, y, th, None, ids[:5], zx[:5], zy[:5], 0.02)
+    assert np.array_equal(bits(host(d)), bits(want2)) and np.array_equal(bits(host(ll)), bits(wl2))
+    eng.obs_upload(ids, zx, zy, L)
     with pytest.raises(pkg.SlamError):   # gather in place is a race: rejected
-        eng.ekf_update_dev(d, d, L * n, n, L, dev(x), dev(y), dev(th), dev(np.zeros(n, np.int32)), n, 0.02, ll)
+        eng.ekf_update_dev(d, d, 5 * L, L, L, dev(x), dev(y), dev(th), dev(np.zeros(n, np.int32)), n, 0.02, ll)
+    with pytest.raises(pkg.SlamError):   # planes overlapping: plane_stride < nlandmarks
+        eng.ekf_update_dev(d, d, 5 * L, L - 2, L, dev(x), dev(y), dev(th), None, n, 0.02, ll)
+    with pytest.raises(pkg.SlamError):   # rows overlapping: row_stride < 5 * plane_stride
+        eng.ekf_update_dev(d, d, 5 * L - 2, L, L, dev(x), dev(y), dev(th), None, n, 0.02, ll)
+    with pytest.raises(pkg.SlamError):   # a NaN measurement in the list
+        eng.obs_upload(ids[:2], np.array([np.nan, 1.0], np.float32), zy[:2], L)
     with pytest.raises(pkg.SlamError):   # duplicate landmark ids
         eng.obs_upload(np.array([1, 1], np.int32), zx[:2], zy[:2], L)
     with pytest.raises(pkg.SlamError):   # id out of range
         eng.obs_upload(np.array([L], np.int32), zx[:1], zy[:1], L)
     with pytest.raises(pkg.SlamError) as ei:   # observation list made for another landmark count
-        eng.ekf_update_dev(d, d, (L + 1) * n, n, L + 1, dev(x), dev(y), dev(th), None, n, 0.02, ll)
+        eng.ekf_update_dev(d, d, 5 * (L + 2), L + 2, L + 1, dev(x), dev(y), dev(th), None, n, 0.02, ll)
     assert ei.value.status == -4
 
 
@@ -264,30 +282,37 @@ def test_fused_entries_equal_staged_ones(eng, orc):
         eng.motion_score_dev(2, src, anc, b, n, 7, dp, sig, 99, 4, sb, cb)
         for u, v in zip(a + [sa, ca], b + [sb, cb]):
             assert torch.equal(u, v)
-        # EKF: 70 observations = 3 chunks
-        mp = _rand_map(rng, L, m, n)
+        # EKF: 70 observations (one batch of two groups), rows padded to 96 floats
+        Lp = 96
+        mp = _rand_map(rng, L, m, Lp)
         ids = rng.permutation(L).astype(np.int32)
         zx, zy = rng.normal(0, 2, L).astype(np.float32), rng.normal(0, 2, L).astype(np.float32)
         d_in = dev(mp)
-        o1, o2 = torch.zeros((5, L, m), device=DEV), torch.zeros((5, L, m), device=DEV)
+        o1, o2 = torch.zeros((m, 5, Lp), device=DEV), torch.zeros((m, 5, Lp), device=DEV)
         ll = torch.empty(n, device=DEV)
         lw1, lw2 = torch.empty(n, device=DEV), torch.empty(n, device=DEV)
         m1, m2 = torch.empty(1, device=DEV), torch.empty(1, device=DEV)
+        def table(ids_, zx_, zy_):
+            t = np.full((2, L), np.nan, np.float32)
+            t[0, ids_], t[1, ids_] = zx_, zy_
+            return dev(t)
+
         eng.obs_upload(ids, zx, zy, L)
-        eng.ekf_update_dev(d_in, o1, L * m, m, L, a[0], a[1], a[2], anc, n, 0.02, ll)
+        eng.ekf_update_dev(d_in, o1, 5 * Lp, Lp, L, a[0], a[1], a[2], anc, n, 0.02, ll)
         eng.logweight_dev(sa, ll, 0.3, n, lw1, m1)
-        eng.obs_set_dev(dev(ids), dev(zx), dev(zy), L, None, 0, L)
-        eng.ekf_update_dev(d_in, o2, L * m, m, L, a[0], a[1], a[2], anc, n, 0.02, None)
+        tab = table(ids, zx, zy)
+        eng.obs_set_dev(tab[0], tab[1], L)
+        eng.ekf_update_dev(d_in, o2, 5 * Lp, Lp, L, a[0], a[1], a[2], anc, n, 0.02, None)
         eng.logweight_ekf_dev(sa, 0.3, n, lw2, m2)
         assert torch.equal(o1, o2) and torch.equal(lw1, lw2) and torch.equal(m1, m2)
-        # a single chunk, and a partial observation list given on the device with its complement
+        # a partial observation list, as a list from the host and as a table on the device
         few = ids[:9].copy()
-        unobs = np.setdiff1d(np.arange(L, dtype=np.int32), few).astype(np.int32)
         eng.obs_upload(few, zx[:9], zy[:9], L)
-        eng.ekf_update_dev(d_in, o1, L * m, m, L, a[0], a[1], a[2], anc, n, 0.02, ll)
+        eng.ekf_update_dev(d_in, o1, 5 * Lp, Lp, L, a[0], a[1], a[2], anc, n, 0.02, ll)
         eng.logweight_dev(sa, ll, 0.3, n, lw1, m1)
-        eng.obs_set_dev(dev(few), dev(zx[:9]), dev(zy[:9]), 9, dev(unobs), len(unobs), L)
-        eng.ekf_update_dev(d_in, o2, L * m, m, L, a[0], a[1], a[2], anc, n, 0.02, None)
+        tab = table(few, zx[:9], zy[:9])
+        eng.obs_set_dev(tab[0], tab[1], L)
+        eng.ekf_update_dev(d_in, o2, 5 * Lp, Lp, L, a[0], a[1], a[2], anc, n, 0.02, None)
         eng.logweight_ekf_dev(sa, 0.3, n, lw2, m2)
         assert torch.equal(o1, o2) and torch.equal(lw1, lw2) and torch.equal(m1, m2)
     with pytest.raises(pkg.SlamError) as ei:
@@ -303,11 +328,11 @@ def test_gathers(eng):
     dst = torch.empty(n, device=DEV)
     eng.gather_f32_dev(dev(src), dev(idx), n, dst)
     assert np.array_equal(host(dst), src[idx])
-    mp = rng.standard_normal((5, L, m)).astype(np.float32)
-    out = torch.zeros((5, L, n + 3), device=DEV)
-    eng.gather_map_dev(dev(mp), out, L * m, L * (n + 3), m, n + 3, L, dev(idx), n)
+    mp = rng.standard_normal((m, 5, L + 2)).astype(np.float32)    # source rows: plane stride L + 2
+    out = torch.zeros((n + 3, 5, 32), device=DEV)                 # destination rows: plane stride 32
+    eng.gather_map_dev(dev(mp), out, 5 * (L + 2), 5 * 32, L + 2, 32, L, dev(idx), n)
     got = host(out)
-    assert np.array_equal(got[:, :, :n], mp[:, :, idx]) and not got[:, :, n:].any()
+    assert np.array_equal(got[:n, :, :L], mp[idx][:, :, :L]) and not got[n:].any() and not got[:, :, L:].any()
 
 
 def test_full_filter_matches_oracle_over_frames(eng, orc):
@@ -365,7 +390,7 @@ def test_ranks_on_one_card_equal_unsharded_oracle(orc, tmp_path, L, world):
     assert np.array_equal(bits(np.concatenate([p["pose"] for p in parts], axis=1)), bits(ref["pose"]))
     assert np.array_equal(bits(np.concatenate([p["logw"] for p in parts])), bits(ref["logw"]))
     if L:
-        assert np.array_equal(bits(np.concatenate([p["map"] for p in parts], axis=2)), bits(ref["map"]))
+        assert np.array_equal(bits(np.concatenate([p["map"] for p in parts], axis=0)), bits(ref["map"]))
     assert parts[-1]["migrated"].max() > 200
     for p in parts:
         assert tuple(p["best"]) == tuple(np.array(ref["best"]))
@@ -417,28 +442,29 @@ def test_full_size_ekf_config2_vs_oracle(eng, orc):
     """BASELINE config 2 at full size — 65 536 particles x 500 landmarks, every landmark observed, resample
     gather fused in: the whole 2 x 655 MB update against the CPU specification, bit for bit."""
     import ctypes as C
-    n, L = 65536, 500
+    n, L, Lp = 65536, 500, 512
     rng = np.random.default_rng(65536)
-    mp = _rand_map(rng, L, n, n)
+    mp = _rand_map(rng, L, n, Lp)
     x, y, th = (rng.normal(0, 1, n).astype(np.float32) for _ in range(3))
     u = rng.random(n) ** 3
     anc = np.sort(rng.choice(n, n, p=u / u.sum())).astype(np.int32)    # resample-like: sorted, with repeats and gaps
     ids = rng.permutation(L).astype(np.int32)
     zx, zy = rng.normal(0, 2, L).astype(np.float32), rng.normal(0, 2, L).astype(np.float32)
-    d_out = torch.empty((5, L, n), device=DEV)
+    d_out = torch.full((n, 5, Lp), -555.0, device=DEV)
     ll = torch.empty(n, device=DEV)
     eng.obs_upload(ids, zx, zy, L)
-    eng.ekf_update_dev(dev(mp), d_out, L * n, n, L, dev(x), dev(y), dev(th), dev(anc), n, 0.0016, ll)
-    want = np.empty((5, L, n), np.float32)
+    eng.ekf_update_dev(dev(mp), d_out, 5 * Lp, Lp, L, dev(x), dev(y), dev(th), dev(anc), n, 0.0016, ll)
+    want = np.full((n, 5, Lp), -555.0, np.float32)
     wl = np.empty(n, np.float32)
-    orc.lib().orc_ekf_update(mp, want, L * n, n, L, x, y, th, anc.ctypes.data_as(C.c_void_p), n, ids, zx, zy, L, 0.0016, wl)
+    orc.lib().orc_ekf_update(mp, want, 5 * Lp, Lp, L, x, y, th, anc.ctypes.data_as(C.c_void_p), n, ids, zx, zy, L, 0.0016, wl)
     got = host(d_out)
     assert np.array_equal(bits(got), bits(want))
     assert np.array_equal(bits(host(ll)), bits(wl))
     # size-independent properties: covariances stay symmetric positive definite and never grow
-    seen = mp[2][:, anc] >= 0
-    det = got[2] * got[4] - got[3] * got[3]
-    assert (got[2][seen] > 0).all() and (det[seen] > 0).all() and (got[2][seen] <= mp[2][:, anc][seen] * (1 + 1e-5)).all()
+    got, prior = got[:, :, :L], mp[anc][:, :, :L]
+    seen = prior[:, 2] >= 0
+    det = got[:, 2] * got[:, 4] - got[:, 3] * got[:, 3]
+    assert (got[:, 2][seen] > 0).all() and (det[seen] > 0).all() and (got[:, 2][seen] <= prior[:, 2][seen] * (1 + 1e-5)).all()
 
 
 def test_full_size_resample_8m_vs_oracle(eng, orc):

@@ -81,6 +81,15 @@ def _ekf_f64(mu, P, pose, z, q):
     return mu + K @ v, (np.eye(2) - K @ H) @ P, ll
 
 
+def _rows(planes):
+    """[5][L][n] (convenient to fill) -> the engine's layout, one row per particle: [n][5][L]"""
+    return np.ascontiguousarray(np.asarray(planes, np.float32).transpose(2, 0, 1))
+
+
+def _planes(rows):
+    return np.asarray(rows).transpose(1, 2, 0)
+
+
 def test_ekf_single_landmark_against_float64(orc):
     rng = np.random.default_rng(3)
     n, L = 64, 7
@@ -93,7 +102,8 @@ def test_ekf_single_landmark_against_float64(orc):
     obs_id = np.array([4, 1], np.int32)
     z = rng.normal(0, 2, (2, 2)).astype(np.float32)
     q = 0.01
-    out, ll = orc.ekf_update(mp, pose[:, 0], pose[:, 1], pose[:, 2], None, obs_id, z[:, 0], z[:, 1], q)
+    out, ll = orc.ekf_update(_rows(mp), pose[:, 0], pose[:, 1], pose[:, 2], None, obs_id, z[:, 0], z[:, 1], q)
+    out = _planes(out)
     for i in range(n):
         tot = 0.0
         for k, l in enumerate(obs_id):
@@ -110,7 +120,7 @@ def test_ekf_single_landmark_against_float64(orc):
     assert (out[2, 4] < mp[2, 4]).all() and (out[4, 1] < mp[4, 1]).all()
 
 
-def test_ekf_first_sighting_gather_and_chunked_loglik(orc):
+def test_ekf_first_sighting_gather_and_loglik_summation_order(orc):
     n, L = 5, 70
     rng = np.random.default_rng(4)
     mp = np.zeros((5, L, n), np.float32)
@@ -118,29 +128,49 @@ def test_ekf_first_sighting_gather_and_chunked_loglik(orc):
     mp[2, 9] = -1.0                                   # landmark 9 never seen
     x = rng.normal(0, 1, n).astype(np.float32); y = rng.normal(0, 1, n).astype(np.float32)
     th = rng.normal(0, 1, n).astype(np.float32)
-    ids = np.arange(L, dtype=np.int32)[::-1].copy()   # 70 observations = 3 chunks of 32
+    ids = np.arange(L, dtype=np.int32)[::-1].copy()
     zx = rng.normal(0, 1, L).astype(np.float32); zy = rng.normal(0, 1, L).astype(np.float32)
-    out, ll = orc.ekf_update(mp, x, y, th, None, ids, zx, zy, 0.02)
+    out, ll = orc.ekf_update(_rows(mp), x, y, th, None, ids, zx, zy, 0.02)
+    out = _planes(out)
     # first sighting: world point = R^T-convention inverse of the observation, P = R
     s, c = orc.det_sincos(th)
     k9 = int(np.where(ids == 9)[0][0])
     assert np.allclose(out[0, 9], x + (c * zx[k9] + s * zy[k9]), atol=1e-6)
     assert np.allclose(out[1, 9], y + (c * zy[k9] - s * zx[k9]), atol=1e-6)
     assert (out[2, 9] == np.float32(0.02)).all() and (out[3, 9] == 0).all() and (out[4, 9] == np.float32(0.02)).all()
-    # chunked summation order: per-chunk partial sums, then the partials in order
-    parts = []
-    for k0 in range(0, L, 32):
-        sel = ids[k0:k0 + 32]
-        _, llp = orc.ekf_update(mp, x, y, th, None, sel, zx[k0:k0 + 32], zy[k0:k0 + 32], 0.02)
-        parts.append(llp)
-    tot = np.zeros(n, np.float32)
-    for p in parts:
-        tot = (tot + p).astype(np.float32)
-    assert np.array_equal(tot, ll)
+    # the specified summation order, restated independently: the term of landmark l (what a one-observation
+    # call returns; 0 when l has no observation) goes to accumulator l mod 128 in order of l; accumulators j and
+    # j+64 are added; then a 6-level xor butterfly over the 64 sums
+    def tree(terms, ids_, nl):                         # terms: [nobs][n] float32, one per observation
+        lane = np.zeros((128, terms.shape[1]), np.float32)
+        by_landmark = {int(l): terms[k] for k, l in enumerate(ids_)}
+        for l in range(nl):
+            if l in by_landmark:
+                lane[l % 128] = lane[l % 128] + by_landmark[l]
+        t = lane[:64] + lane[64:]
+        for sft in (1, 2, 4, 8, 16, 32):
+            t = t + t[np.arange(64) ^ sft]
+        return t[0]
+
+    def terms_of(mp_, ids_, zx_, zy_):
+        return np.stack([orc.ekf_update(_rows(mp_), x, y, th, None, ids_[k:k + 1], zx_[k:k + 1], zy_[k:k + 1], 0.02)[1]
+                         for k in range(len(ids_))])
+
+    assert np.array_equal(tree(terms_of(mp, ids, zx, zy), ids, L), ll)
+    _, ll_shuffled = orc.ekf_update(_rows(mp), x, y, th, None, ids[::-1].copy(), zx[::-1].copy(), zy[::-1].copy(), 0.02)
+    assert np.array_equal(ll_shuffled, ll)             # the order of the observation list is irrelevant
+    # more than 128 landmarks: accumulators are reused in order (l and l+128 share one)
+    L2 = 300
+    mp2 = np.zeros((5, L2, n), np.float32)
+    mp2[0:2] = rng.normal(0, 1, (2, L2, n)); mp2[2] = 0.2; mp2[4] = 0.3; mp2[3] = -0.02
+    ids2 = rng.permutation(L2).astype(np.int32)[:290]
+    zx2 = rng.normal(0, 1, 290).astype(np.float32); zy2 = rng.normal(0, 1, 290).astype(np.float32)
+    _, ll2 = orc.ekf_update(_rows(mp2), x, y, th, None, ids2, zx2, zy2, 0.02)
+    assert np.array_equal(tree(terms_of(mp2, ids2, zx2, zy2), ids2, L2), ll2)
     # fused gather: particle i continues from ancestor anc[i]'s map
     anc = np.array([2, 2, 0, 4, 4], np.int32)
-    out_g, ll_g = orc.ekf_update(mp, x, y, th, anc, ids[:10], zx[:10], zy[:10], 0.02)
-    out_ref, ll_ref = orc.ekf_update(mp[:, :, anc], x, y, th, None, ids[:10], zx[:10], zy[:10], 0.02)
+    out_g, ll_g = orc.ekf_update(_rows(mp), x, y, th, anc, ids[:10], zx[:10], zy[:10], 0.02)
+    out_ref, ll_ref = orc.ekf_update(_rows(mp[:, :, anc]), x, y, th, None, ids[:10], zx[:10], zy[:10], 0.02)
     assert np.array_equal(out_g, out_ref) and np.array_equal(ll_g, ll_ref)
 
 

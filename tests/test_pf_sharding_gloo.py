@@ -32,7 +32,7 @@ def test_sharded_equals_unsharded(orc, tmp_path, L, world):
     logw = np.concatenate([p["logw"] for p in parts])
     assert np.array_equal(logw.view(np.uint32), ref["logw"].view(np.uint32))
     if L:
-        mapc = np.concatenate([p["map"] for p in parts], axis=2)
+        mapc = np.concatenate([p["map"] for p in parts], axis=0)   # rows = particles
         assert np.array_equal(mapc.view(np.uint32), ref["map"].view(np.uint32))
     # the scenario really exercised the exchange: the upper half of the population collapses and is refilled
     # from the lower half, i.e. from other ranks (several sources per receiver when world > 2)
