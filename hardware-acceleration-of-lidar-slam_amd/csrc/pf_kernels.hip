@@ -95,11 +95,20 @@ __device__ __forceinline__ float wave_xor_tree_sum(float v)   // t[j] = t[j] + t
 
 constexpr int kEkfWaves = 4;   // particles per workgroup
 
+// global-address-space pointers: "scalar base + 32-bit lane offset" is an addressing mode of global_load/store only
+typedef __attribute__((address_space(1))) char gchar;
+typedef __attribute__((address_space(1))) float gfloat;
+__device__ __forceinline__ gchar* uniform_gptr(const void* p)   // tell the compiler the pointer is wave-uniform
+{
+    const uint64_t v = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return (gchar*)(((uint64_t)hi << 32) | lo);
+}
+
 struct EkfLane {   // per-wavefront constants of one particle
-    const char* rin;
-    char* rout;
-    int64_t pl;   // plane stride in bytes
-    const char *ozx, *ozy;
+    const gchar* rin[5];   // plane bases of the source row and of the destination row: wave-uniform, kept in SGPRs so
+    gchar* rout[5];        // that every access is "scalar base + 32-bit lane offset" with no 64-bit vector arithmetic
+    const gchar *ozx, *ozy;
     unsigned L;
     v2f s, c, px, py, q;
 };
@@ -125,7 +134,7 @@ __device__ __forceinline__ void ekf_batches(const EkfLane& w, unsigned lb, unsig
             const bool in = l < w.L;
             off[g][t] = ((FULL || in) ? l : 0u) * 4u;
             const unsigned zo = (in ? l : 0u) * 4u;   // clamped index + select instead of a predicated load
-            const float vx = *reinterpret_cast<const float*>(w.ozx + zo), vy = *reinterpret_cast<const float*>(w.ozy + zo);
+            const float vx = *(const gfloat*)(w.ozx + zo), vy = *(const gfloat*)(w.ozy + zo);
             zx[g][t] = in ? vx : nan;
             zy[g][t] = in ? vy : nan;
             // NaN = no observation (also what lanes beyond L were given).  Testing zy as well keeps its load up here
@@ -139,7 +148,7 @@ __device__ __forceinline__ void ekf_batches(const EkfLane& w, unsigned lb, unsig
         for (int t = 0; t < 2; ++t)
             if (FULL || use[g][t]) {
 #pragma unroll
-                for (int p = 0; p < 5; ++p) m[g][p][t] = *reinterpret_cast<const float*>(w.rin + p * w.pl + off[g][t]);
+                for (int p = 0; p < 5; ++p) m[g][p][t] = *(const gfloat*)(w.rin[p] + off[g][t]);
             }
 #pragma unroll
     for (int g = 0; g < NB; ++g) {
@@ -150,7 +159,7 @@ __device__ __forceinline__ void ekf_batches(const EkfLane& w, unsigned lb, unsig
             for (int t = 0; t < 2; ++t)
                 if (FULL || use[g][t]) {
 #pragma unroll
-                    for (int p = 0; p < 5; ++p) *reinterpret_cast<float*>(w.rout + p * w.pl + off[g][t]) = m[g][p][t];
+                    for (int p = 0; p < 5; ++p) *(gfloat*)(w.rout[p] + off[g][t]) = m[g][p][t];
                 }
             continue;
         }
@@ -188,12 +197,11 @@ __device__ __forceinline__ void ekf_batches(const EkfLane& w, unsigned lb, unsig
             o4[t] = !ob ? pyy[t] : first ? q[t] : o4[t];
             ll[t] = (!ob || first) ? 0.0f : ll[t];
             if (FULL || use[g][t]) {
-                char* wp = w.rout + off[g][t];
-                *reinterpret_cast<float*>(wp) = o0[t];
-                *reinterpret_cast<float*>(wp + w.pl) = o1[t];
-                *reinterpret_cast<float*>(wp + 2 * w.pl) = o2[t];
-                *reinterpret_cast<float*>(wp + 3 * w.pl) = o3[t];
-                *reinterpret_cast<float*>(wp + 4 * w.pl) = o4[t];
+                *(gfloat*)(w.rout[0] + off[g][t]) = o0[t];
+                *(gfloat*)(w.rout[1] + off[g][t]) = o1[t];
+                *(gfloat*)(w.rout[2] + off[g][t]) = o2[t];
+                *(gfloat*)(w.rout[3] + off[g][t]) = o3[t];
+                *(gfloat*)(w.rout[4] + off[g][t]) = o4[t];
             }
         }
         acc = acc + ll;
@@ -212,11 +220,13 @@ __global__ __launch_bounds__(kEkfWaves * 64) void ekf_update_kernel(EkfArgs a)
     float st_, ct_;
     det_sincosf(a.th[i], st_, ct_);
     EkfLane w;
-    w.rin = reinterpret_cast<const char*>(a.map_in + (int64_t)src * a.row_stride);
-    w.rout = reinterpret_cast<char*>(a.map_out + (int64_t)i * a.row_stride);
-    w.pl = (int64_t)a.plane_stride * 4;
-    w.ozx = reinterpret_cast<const char*>(a.obs_zx);
-    w.ozy = reinterpret_cast<const char*>(a.obs_zy);
+#pragma unroll
+    for (int p = 0; p < 5; ++p) {
+        w.rin[p] = uniform_gptr(a.map_in + (int64_t)src * a.row_stride + (int64_t)p * a.plane_stride);
+        w.rout[p] = uniform_gptr(a.map_out + (int64_t)i * a.row_stride + (int64_t)p * a.plane_stride);
+    }
+    w.ozx = uniform_gptr(a.obs_zx);
+    w.ozy = uniform_gptr(a.obs_zy);
     w.L = (unsigned)a.nlandmarks;
     w.s = bc2(st_); w.c = bc2(ct_); w.px = bc2(a.x[i]); w.py = bc2(a.y[i]); w.q = bc2(a.meas_var);
 
