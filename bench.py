@@ -357,6 +357,9 @@ def main():
                    "rows_received_per_frame_max_rank": migrated if world > 1 else 0},
         "roofline": {"bound": "hbm", "kernel": kern, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": alg,
+                     # the EKF re-reads the rows of repeated ancestors from L2, so its HBM traffic (PMC) is BELOW the
+                     # algorithmic 40 B per (particle, landmark); this is the rate at which HBM itself was driven
+                     "hbm_traffic_rate_gbs": (traffic / (dur_ms * 1e-3) / 1e9) if traffic and dur_ms > 0 else None,
                      "avg_launch_ms": dur_ms, "avg_event_bracket_ms": raw_ms,
                      "event_bracket_overhead_ms": bracket_overhead_ms,
                      "launches": int(ekf_n if kern.startswith("ekf") else score_n),

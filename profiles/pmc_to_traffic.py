@@ -8,8 +8,8 @@
 
 Corrections, as MI355X_MICROARCH.md §HBM prescribes: counters are in KiB; on gfx950 FETCH_SIZE reports
 half the bytes of a coalesced streaming read (128-B requests tallied at 64 B) -> doubled; WRITE_SIZE is
-exact.  The factor 2 is re-checked on the `ekf` sweep (no gather, 20 B read per particle x landmark,
-buffers far larger than the Infinity Cache, so HBM read bytes = algorithmic read bytes).
+exact.  The factor 2 is re-checked on the `ekf` sweep (no gather, every row read once — 20 B per particle x
+padded landmark — buffers far larger than the Infinity Cache, so HBM read bytes are known a priori).
 """
 import csv
 import glob
@@ -31,9 +31,10 @@ def counter(mode, name):
 
 
 n, L = 65536, 500
-alg_side = 20 * n * L
+Lp = (L + 31) // 32 * 32          # rows are padded to 32 floats per plane and whole 128-landmark batches are moved,
+alg_side = 20 * n * L             # padding included: the sweep really reads and writes 20 B x n x Lp
 cal, _ = counter("ekf", "FETCH_SIZE")
-factor = alg_side / (sum(cal[2:]) / len(cal[2:]))
+factor = 20 * n * Lp / (sum(cal[2:]) / len(cal[2:]))
 fetch, _ = counter("pf", "FETCH_SIZE")
 write, _ = counter("pf", "WRITE_SIZE")
 steady = slice(4, None)   # skip the frames before the particle cloud has settled
@@ -49,10 +50,12 @@ for mode in ("ekf", "pf"):
     for name in ("FETCH_SIZE", "WRITE_SIZE"):
         v, _ = counter(mode, name)
         md.append(f"| bench.py --mode {mode} | {name} | " + ", ".join(f"{x / 1e6:.1f} MB" for x in v[:10]) + " |")
-md += ["", f"Calibration on the `ekf` sweep (known 20 B x {n} x {L} = {alg_side / 1e6:.1f} MB read per launch): "
-       f"algorithmic / FETCH_SIZE = {factor:.3f} (the guide's factor 2).",
+md += ["", f"Calibration on the `ekf` sweep (known 20 B x {n} x {Lp} = {20 * n * Lp / 1e6:.1f} MB read per launch, row "
+       f"padding included): known / FETCH_SIZE = {factor:.3f} (the guide's factor 2).",
        f"`pf` mode, steady frames: read = 2 x FETCH_SIZE = {rd / 1e6:.1f} MB, write = {wr / 1e6:.1f} MB, total "
        f"{(rd + wr) / 1e6:.1f} MB per launch vs {2 * alg_side / 1e6:.1f} MB algorithmic "
-       f"(+{100 * ((rd + wr) / (2 * alg_side) - 1):.1f} %: line over-fetch of the fused resample gather)."]
+       f"({100 * ((rd + wr) / (2 * alg_side) - 1):+.1f} %): the writes are the 20 B x n x {Lp} of the padded rows; the "
+       f"reads are only the rows of the DISTINCT ancestors — the offspring of one ancestor are neighbouring "
+       f"particles and re-read its row from L2."]
 (here / f"{tag}_pmc_ekf.md").write_text("\n".join(md) + "\n")
 print("\n".join(md[-2:]))
