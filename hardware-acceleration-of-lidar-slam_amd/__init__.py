@@ -86,8 +86,8 @@ SIGNATURES = {
     "slam_offspring_offsets_dev": (_i, [_vp, _vp, _i, _vp, _vp, _u64, _u32, _i64, _vp]),
     "slam_ancestors_dev": (_i, [_vp, _vp, _i64, _i64, _i, _vp]),
     "slam_comb_offset": (_u64, [_u64, _u32, _u64]),
-    "slam_ancestors_sharded_dev": (_i, [_vp, _vp, _i64, _i, _i, _i, _vp]),
-    "slam_migrate_pack_dev": (_i, [_vp, _vp, _i64, _i, _i, _i, _vp, _vp, _vp, _i64, _vp, _i64, _i, _i, _vp]),
+    "slam_ancestors_sharded_dev": (_i, [_vp, _vp, _i64, _i, _i, _i, _vp, _vp]),
+    "slam_migrate_pack_dev": (_i, [_vp, _i, _i, _i, _vp, _vp, _i64, _vp, _i64, _i, _i, _vp]),
     "slam_migrate_unpack_dev": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i64, _vp, _i64, _i, _i]),
     "slam_argmax_dev": (_i, [_vp, _vp, _i, _vp, _vp]),
     "slam_gather_f32_dev": (_i, [_vp, _vp, _vp, _i, _vp]),
@@ -344,16 +344,17 @@ class Engine:
         self._ck(self.lib.slam_ancestors_dev(self.h, _ptr(d_first_all), n_total, slot0, nslots, _ptr(d_anc)),
                  "ancestors_dev")
 
-    def ancestors_sharded_dev(self, d_first_all, n_total, n_local, rank, world, d_src):
+    def ancestors_sharded_dev(self, d_first_all, n_total, n_local, rank, world, d_src, d_plan):
+        """d_plan: int32[plan_words(world)] on the device: [0] anything moves, send_cnt[world], recv_cnt[world], ..."""
         self._ck(self.lib.slam_ancestors_sharded_dev(self.h, _ptr(d_first_all), n_total, n_local, rank, world,
-                                                     _ptr(d_src)), "ancestors_sharded_dev")
+                                                     _ptr(d_src), _ptr(d_plan)), "ancestors_sharded_dev")
 
-    def migrate_pack_dev(self, d_first_all, n_total, n_local, rank, world, send_lo, send_cnt, d_pose, pose_ld, d_map,
-                         row_stride, plane_stride, nlandmarks, d_out):
-        lo, cnt = _np(send_lo, np.int64), _np(send_cnt, np.int32)
-        self._ck(self.lib.slam_migrate_pack_dev(self.h, _ptr(d_first_all), n_total, n_local, rank, world, _ptr(lo),
-                                                _ptr(cnt), _ptr(d_pose), pose_ld, _ptr(d_map), row_stride, plane_stride,
-                                                nlandmarks, _ptr(d_out)), "migrate_pack_dev")
+    def migrate_pack_dev(self, n_local, rank, world, plan, d_pose, pose_ld, d_map, row_stride, plane_stride, nlandmarks,
+                         d_out):
+        plan = _np(plan, np.int32)
+        self._ck(self.lib.slam_migrate_pack_dev(self.h, n_local, rank, world, _ptr(plan), _ptr(d_pose), pose_ld,
+                                                _ptr(d_map), row_stride, plane_stride, nlandmarks, _ptr(d_out)),
+                 "migrate_pack_dev")
 
     def migrate_unpack_dev(self, d_in, world, recv_cnt, n_local, d_pose, pose_ld, d_map, row_stride, plane_stride,
                            nlandmarks):
@@ -425,6 +426,11 @@ class PfSession:
         m = np.empty((self.n, 5, self.L), np.float32)
         self.e._ck(self.e.lib.slam_pf_get_map_host(self.h, _ptr(m)), "pf_get_map")
         return m
+
+
+def plan_words(world: int) -> int:
+    """int32 words of the exchange plan slam_ancestors_sharded_dev writes (SLAM_PLAN_WORDS in slam_hip.h)."""
+    return 1 + 3 * world
 
 
 def comb_offset(seed: int, frame: int, total: int) -> int:

@@ -155,6 +155,7 @@ int slam_engine_destroy(slam_engine* e)
     e->bmax_buf.release();
     e->scan_state.release();
     e->ll_buf.release();
+    e->shard_buf.release();
     if (e->h_stage) (void)hipHostFree(e->h_stage);
     for (auto& ev : e->stage_ev)
         if (ev) (void)hipEventDestroy(ev);
@@ -764,29 +765,35 @@ static bool make_plan(MigratePlan& plan, const int64_t* lo, const int32_t* cnt, 
 }
 
 int slam_ancestors_sharded_dev(slam_engine* e, const int32_t* d_first_all, int64_t n_total, int n_local, int rank,
-                               int world, int32_t* d_src)
+                               int world, int32_t* d_src, int32_t* d_plan)
 {
     ENTER(e);
     if (n_local <= 0 || world < 1 || world > kMaxRanks || rank < 0 || rank >= world ||
-        n_total != (int64_t)n_local * world || !d_first_all || !d_src)
+        n_total != (int64_t)n_local * world || !d_first_all || !d_src || !d_plan)
         return SLAM_ERR_INVALID_ARG;
-    HIP_TRY(launch_ancestors_sharded(e->stream, d_first_all, n_total, n_local, rank, world, d_src));
+    HIP_TRY(e->shard_buf.ensure(sizeof(int32_t) * (size_t)shard_scan_words(n_local)));
+    HIP_TRY(launch_ancestors_sharded(e->stream, d_first_all, n_total, n_local, rank, world, e->shard_buf.as<int32_t>(),
+                                     d_plan, d_src));
+    e->shard_n = n_local;   // what slam_migrate_pack_dev will read
     return SLAM_OK;
 }
 
-int slam_migrate_pack_dev(slam_engine* e, const int32_t* d_first_all, int64_t n_total, int n_local, int rank, int world,
-                          const int64_t* send_lo, const int32_t* send_cnt, const float* d_pose, int64_t pose_ld,
-                          const float* d_map, int64_t row_stride, int plane_stride, int nlandmarks, float* d_out)
+int slam_migrate_pack_dev(slam_engine* e, int n_local, int rank, int world, const int32_t* plan, const float* d_pose,
+                          int64_t pose_ld, const float* d_map, int64_t row_stride, int plane_stride, int nlandmarks,
+                          float* d_out)
 {
     ENTER(e);
-    MigratePlan plan;
-    if (!make_plan(plan, send_lo, send_cnt, world) || n_local <= 0 || rank < 0 || rank >= world || nlandmarks < 0 ||
-        n_total != (int64_t)n_local * world || !d_first_all || !d_pose ||
-        (nlandmarks > 0 && (!d_map || plane_stride < nlandmarks || row_stride < 5 * (int64_t)plane_stride)))
+    if (n_local <= 0 || world < 1 || world > kMaxRanks || rank < 0 || rank >= world || !plan || nlandmarks < 0 ||
+        !d_pose || (nlandmarks > 0 && (!d_map || plane_stride < nlandmarks || row_stride < 5 * (int64_t)plane_stride)))
         return SLAM_ERR_INVALID_ARG;
-    if (plan.off[world] > 0 && !d_out) return SLAM_ERR_INVALID_ARG;
-    HIP_TRY(launch_migrate_pack(e->stream, d_first_all, n_total, n_local, rank, plan, d_pose, pose_ld, d_map,
-                                row_stride, plane_stride, nlandmarks, d_out));
+    if (e->shard_n != n_local) return SLAM_ERR_NOT_READY;   // needs slam_ancestors_sharded_dev(n_local) of this frame
+    MigratePlan mp;
+    int64_t base[kMaxRanks];
+    for (int q = 0; q < world; ++q) base[q] = plan[1 + 2 * world + q];
+    if (!make_plan(mp, base, plan + 1, world) || plan[1 + rank] != 0) return SLAM_ERR_INVALID_ARG;
+    if (mp.off[world] > 0 && !d_out) return SLAM_ERR_INVALID_ARG;
+    HIP_TRY(launch_migrate_pack(e->stream, e->shard_buf.as<int32_t>(), n_local, mp, d_pose, pose_ld, d_map, row_stride,
+                                plane_stride, nlandmarks, d_out));
     return SLAM_OK;
 }
 

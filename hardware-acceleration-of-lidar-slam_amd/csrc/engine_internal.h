@@ -82,6 +82,8 @@ struct slam_engine {
     int bmax_count = 0, bmax_n = -1;
     DevBuf scan_state;         // tile-local CDF u64[n] + tile totals, left by slam_quantise_scan_dev
     int scan_n = -1;
+    DevBuf shard_buf;          // flag scans of the last slam_ancestors_sharded_dev call (read by slam_migrate_pack_dev)
+    int shard_n = -1;
     DevBuf ll_buf;             // log-likelihood [n] of the last EKF call
     int ll_n = -1;
     // pinned staging ring for the per-frame sensor uploads: one host-to-device copy per upload, and the

@@ -112,15 +112,16 @@ hipError_t launch_ancestors(hipStream_t stream, const int32_t* first_all, int64_
 // multi-GPU resample (see pf_kernels.hip): per-peer slot runs, offsets in the packed exchange buffers
 enum { kMaxRanks = 16 };
 struct MigratePlan {
-    int64_t lo[kMaxRanks];       // first global slot of the run exchanged with peer q
+    int64_t lo[kMaxRanks];       // pack: prefix count at the first particle sent to peer q (send_base); unpack: unused
     int32_t off[kMaxRanks + 1];  // running particle offset of peer q's run in the buffer (off[world] = total)
     int32_t world;
 };
+int shard_scan_words(int n);   // int32 words of scratch the two launchers below share
 hipError_t launch_ancestors_sharded(hipStream_t stream, const int32_t* first_all, int64_t n_total, int n, int rank,
-                                    int world, int32_t* src);
-hipError_t launch_migrate_pack(hipStream_t stream, const int32_t* first_all, int64_t n_total, int n, int rank,
-                               const MigratePlan& plan, const float* pose, int64_t pose_ld, const float* map,
-                               int64_t row_stride, int plane_stride, int nlandmarks, float* out);
+                                    int world, int32_t* scratch, int32_t* plan, int32_t* src);
+hipError_t launch_migrate_pack(hipStream_t stream, const int32_t* scratch, int n, const MigratePlan& plan,
+                               const float* pose, int64_t pose_ld, const float* map, int64_t row_stride,
+                               int plane_stride, int nlandmarks, float* out);
 hipError_t launch_migrate_unpack(hipStream_t stream, const float* in, const MigratePlan& plan, int n, float* pose,
                                  int64_t pose_ld, float* map, int64_t row_stride, int plane_stride, int nlandmarks);
 hipError_t launch_argmax(hipStream_t stream, const float* v, int n, int32_t* idx_out, float* val_out);

@@ -613,50 +613,172 @@ __device__ __forceinline__ int64_t last_with_first_le(const int32_t* __restrict_
     return lo - 1;
 }
 
-// src[jl]: where slot r*n + jl finds its ancestor — a local particle index, or n + (position in the staging
-// tail, which holds the runs received from ranks 0..world-1 in rank order, each run in slot order).
-__global__ __launch_bounds__(kBlock) void ancestors_sharded_kernel(const int32_t* __restrict__ first_all,
-                                                                   int64_t n_total, int n, int rank, int world,
-                                                                   int32_t* __restrict__ src)
+// ---- exchange with duplicates removed.  After a resample many slots share one ancestor; a remote ancestor's row
+// is sent ONCE per destination rank, however many of that rank's slots descend from it.  Both sides derive the
+// same order from first_all alone:
+//   receiver r: D(j) = number of "heads" among its slots up to j (a slot is a head when it is the first of r's
+//               slots with that ancestor); the rows received from rank s land in the staging tail in ancestor
+//               order, and slot j finds its row at  n + roff[s] + D(j) - D(first slot served by s);
+//   sender  s:  P(a) = number of its particles up to a that have any offspring; the rows for rank d are the
+//               particles with offspring in d's slot range, in order: the q-th is the first a with
+//               P(a) = P(first ancestor of the run) + q.
+// Both counts are prefix sums over n elements (two-level: 2048-element tiles, then the tile totals).
+constexpr int kShardTile = 2048;                       // elements per workgroup in the flag scan
+constexpr int kShardItems = kShardTile / kBlock;       // per thread
+
+// y = 0: head flags of my slots (also stores each slot's global ancestor);  y = 1: "has offspring" flags of my particles
+__global__ __launch_bounds__(kBlock) void shard_flag_scan_kernel(const int32_t* __restrict__ first_all, int64_t n_total,
+                                                                 int n, int rank, int32_t* __restrict__ gsrc,
+                                                                 int32_t* __restrict__ pfx, int32_t* __restrict__ btot,
+                                                                 int ntiles)
 {
-    __shared__ int64_t s_lo[kMaxRanks];    // first of my slots served by rank s
-    __shared__ int32_t s_off[kMaxRanks];   // staging offset of rank s's run
-    if (threadIdx.x == 0) {
-        const int64_t my_lo = (int64_t)rank * n, my_hi = my_lo + n;
-        int32_t off = 0;
-        for (int q = 0; q < world; ++q) {
-            const int64_t a = first_or_total(first_all, (int64_t)q * n, n_total);
-            const int64_t b = first_or_total(first_all, (int64_t)(q + 1) * n, n_total);
-            const int64_t lo = a > my_lo ? a : my_lo, hi = b < my_hi ? b : my_hi;
-            s_lo[q] = lo;
-            s_off[q] = off;
-            if (q != rank && hi > lo) off += (int32_t)(hi - lo);
+    __shared__ int32_t s_wave[kBlock / 64];
+    const int y = blockIdx.y;
+    const int64_t my_lo = (int64_t)rank * n;
+    const int base = blockIdx.x * kShardTile + threadIdx.x * kShardItems;
+    int32_t f[kShardItems];
+    int32_t run = 0;
+#pragma unroll
+    for (int k = 0; k < kShardItems; ++k) {
+        const int idx = base + k;
+        int32_t flag = 0;
+        if (idx < n) {
+            const int64_t j = my_lo + idx;
+            if (y == 0) {
+                const int64_t g = last_with_first_le(first_all, n_total, j);
+                gsrc[idx] = (int32_t)g;
+                flag = (idx == 0 || (int64_t)first_all[g] == j) ? 1 : 0;
+            } else {
+                flag = first_or_total(first_all, j + 1, n_total) > (int64_t)first_all[j] ? 1 : 0;
+            }
         }
+        run += flag;
+        f[k] = run;   // inclusive within the thread
     }
+    // exclusive offset of this thread inside the tile: wave scan + wave totals through LDS
+    int32_t incl = run;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int32_t v = __shfl_up(incl, o, 64);
+        if ((int)(threadIdx.x & 63) >= o) incl += v;
+    }
+    if ((threadIdx.x & 63) == 63) s_wave[threadIdx.x >> 6] = incl;
     __syncthreads();
-    const int jl = blockIdx.x * kBlock + threadIdx.x;
-    if (jl >= n) return;
-    const int64_t j = (int64_t)rank * n + jl;
-    const int64_t g = last_with_first_le(first_all, n_total, j);
-    const int owner = (int)(g / n);
-    src[jl] = owner == rank ? (int32_t)(g - (int64_t)rank * n) : n + s_off[owner] + (int32_t)(j - s_lo[owner]);
+    int32_t woff = 0;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) woff += s_wave[w];
+    const int32_t excl = woff + incl - run;
+#pragma unroll
+    for (int k = 0; k < kShardItems; ++k)
+        if (base + k < n) pfx[(int64_t)y * n + base + k] = excl + f[k];
+    if (threadIdx.x == kBlock - 1) btot[y * ntiles + blockIdx.x] = woff + incl;
 }
 
-// Pack what the other ranks need from me into one buffer: block d (for rank d) is cnt_d records of 3 + 5L
-// floats — x, y, theta, then the five map planes (L values each) — one record per consecutive slot starting at
-// lo_d whose ancestor is one of my particles.  One workgroup per record, one launch for every destination.
-__global__ __launch_bounds__(kBlock) void migrate_pack_kernel(const int32_t* __restrict__ first_all, int64_t n_total,
-                                                              int n, int rank, MigratePlan plan,
-                                                              const float* __restrict__ pose, int64_t pose_ld,
-                                                              const float* __restrict__ map, int64_t row_stride,
-                                                              int plane_stride, int nlandmarks,
+__device__ __forceinline__ int32_t shard_prefix(const int32_t* __restrict__ pfx, const int32_t* __restrict__ boff, int y,
+                                                int n, int ntiles, int idx)   // inclusive count up to idx
+{
+    return pfx[(int64_t)y * n + idx] + boff[y * ntiles + idx / kShardTile];
+}
+
+// One workgroup: tile totals -> exclusive tile offsets (in place), then the per-peer plan.
+// plan (int32, device, visible to the host): [0] anything moves (same on every rank) | send_cnt[world] |
+// recv_cnt[world] | send_base[world];   rplan (device only): roff[world] | rbase[world]
+__global__ __launch_bounds__(kBlock) void shard_plan_kernel(const int32_t* __restrict__ first_all, int64_t n_total, int n,
+                                                            int rank, int world, const int32_t* __restrict__ pfx,
+                                                            int32_t* __restrict__ boff, int ntiles,
+                                                            int32_t* __restrict__ plan, int32_t* __restrict__ rplan)
+{
+    __shared__ int32_t s_part[kBlock];
+    for (int y = 0; y < 2; ++y) {   // exclusive scan of the tile totals, kBlock-sized chunks with a running carry
+        int32_t carry = 0;
+        for (int c0 = 0; c0 < ntiles; c0 += kBlock) {
+            const int t = c0 + threadIdx.x;
+            const int32_t v = t < ntiles ? boff[y * ntiles + t] : 0;
+            s_part[threadIdx.x] = v;
+            __syncthreads();
+            for (int o = 1; o < kBlock; o <<= 1) {
+                const int32_t add = (int)threadIdx.x >= o ? s_part[threadIdx.x - o] : 0;
+                __syncthreads();
+                s_part[threadIdx.x] += add;
+                __syncthreads();
+            }
+            if (t < ntiles) boff[y * ntiles + t] = carry + s_part[threadIdx.x] - v;
+            carry += s_part[kBlock - 1];
+            __syncthreads();
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    const int64_t my_lo = (int64_t)rank * n, my_hi = my_lo + n;
+    const int64_t a_me = first_or_total(first_all, my_lo, n_total), b_me = first_or_total(first_all, my_hi, n_total);
+    int32_t anything = 0, roff = 0;
+    for (int q = 0; q < world; ++q) {
+        const int64_t aq = first_or_total(first_all, (int64_t)q * n, n_total);
+        const int64_t bq = first_or_total(first_all, (int64_t)(q + 1) * n, n_total);
+        if (q > 0 && aq != (int64_t)q * n) anything = 1;   // a run boundary off a rank boundary: somebody exchanges
+        // what I receive from q: my slots [lo, hi) descend from q's particles
+        int64_t lo = aq > my_lo ? aq : my_lo, hi = bq < my_hi ? bq : my_hi;
+        int32_t rcnt = 0, rbase = 0;
+        if (q != rank && hi > lo) {
+            rbase = shard_prefix(pfx, boff, 0, n, ntiles, (int)(lo - my_lo));
+            rcnt = shard_prefix(pfx, boff, 0, n, ntiles, (int)(hi - 1 - my_lo)) - rbase + 1;
+        }
+        rplan[q] = roff;
+        rplan[world + q] = rbase;
+        roff += rcnt;
+        // what I send to q: q's slots [lo, hi) descend from my particles
+        const int64_t q_lo = (int64_t)q * n, q_hi = q_lo + n;
+        lo = a_me > q_lo ? a_me : q_lo;
+        hi = b_me < q_hi ? b_me : q_hi;
+        int32_t scnt = 0, sbase = 0;
+        if (q != rank && hi > lo) {
+            const int a_lo = (int)(last_with_first_le(first_all, n_total, lo) - my_lo);
+            const int a_hi = (int)(last_with_first_le(first_all, n_total, hi - 1) - my_lo);
+            sbase = shard_prefix(pfx, boff, 1, n, ntiles, a_lo);
+            scnt = shard_prefix(pfx, boff, 1, n, ntiles, a_hi) - sbase + 1;
+        }
+        plan[1 + q] = scnt;
+        plan[1 + world + q] = rcnt;
+        plan[1 + 2 * world + q] = sbase;
+    }
+    plan[0] = anything;
+}
+
+// src[jl]: where slot r*n + jl finds its ancestor — a local particle index, or n + its row in the staging tail
+__global__ __launch_bounds__(kBlock) void ancestors_sharded_kernel(const int32_t* __restrict__ gsrc,
+                                                                   const int32_t* __restrict__ pfx,
+                                                                   const int32_t* __restrict__ boff, int ntiles,
+                                                                   const int32_t* __restrict__ rplan, int n, int rank,
+                                                                   int world, int32_t* __restrict__ src)
+{
+    const int jl = blockIdx.x * kBlock + threadIdx.x;
+    if (jl >= n) return;
+    const int32_t g = gsrc[jl];
+    const int owner = g / n;
+    src[jl] = owner == rank ? g - rank * n
+                            : n + rplan[owner] + (shard_prefix(pfx, boff, 0, n, ntiles, jl) - rplan[world + owner]);
+}
+
+// Pack what the other ranks need from me into one buffer: block d (for rank d) is cnt_d records of 3 + 5L floats
+// — x, y, theta, then the five map planes (L values each) — one record per DISTINCT particle of mine with
+// offspring among d's slots, in particle order.  One workgroup per record, one launch for every destination.
+__global__ __launch_bounds__(kBlock) void migrate_pack_kernel(const int32_t* __restrict__ pfx,
+                                                              const int32_t* __restrict__ boff, int ntiles, int n,
+                                                              MigratePlan plan, const float* __restrict__ pose,
+                                                              int64_t pose_ld, const float* __restrict__ map,
+                                                              int64_t row_stride, int plane_stride, int nlandmarks,
                                                               float* __restrict__ out)
 {
     const int p = blockIdx.x;
     int d = 0;
     while (p >= plan.off[d + 1]) ++d;
-    const int64_t j = plan.lo[d] + (p - plan.off[d]);
-    const int loc = (int)(last_with_first_le(first_all, n_total, j) - (int64_t)rank * n);
+    const int32_t target = (int32_t)plan.lo[d] + (p - plan.off[d]);   // P value of the wanted particle
+    int lo = 0, hi = n - 1;                                            // first a with P(a) >= target
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (shard_prefix(pfx, boff, 1, n, ntiles, mid) >= target) hi = mid; else lo = mid + 1;
+    }
+    const int loc = lo;
     float* __restrict__ rec = out + (int64_t)(3 + 5 * nlandmarks) * p;
     if (threadIdx.x < 3) rec[threadIdx.x] = pose[threadIdx.x * pose_ld + loc];
     const float* __restrict__ row = map + (int64_t)loc * row_stride;
@@ -841,21 +963,35 @@ hipError_t launch_ancestors(hipStream_t stream, const int32_t* first_all, int64_
     return hipGetLastError();
 }
 
+int shard_scan_words(int n) { const int t = (n + kShardTile - 1) / kShardTile; return 3 * n + 2 * t + 2 * kMaxRanks; }
+
+// scratch (int32 words, shard_scan_words(n)): gsrc[n] | pfx[2][n] | boff[2][ntiles] | rplan[2*kMaxRanks]
 hipError_t launch_ancestors_sharded(hipStream_t stream, const int32_t* first_all, int64_t n_total, int n, int rank,
-                                    int world, int32_t* src)
+                                    int world, int32_t* scratch, int32_t* plan, int32_t* src)
 {
     if (n <= 0) return hipSuccess;
-    ancestors_sharded_kernel<<<blocks_for(n), kBlock, 0, stream>>>(first_all, n_total, n, rank, world, src);
+    const int ntiles = (n + kShardTile - 1) / kShardTile;
+    int32_t* gsrc = scratch;
+    int32_t* pfx = gsrc + n;
+    int32_t* boff = pfx + 2 * (int64_t)n;
+    int32_t* rplan = boff + 2 * ntiles;
+    shard_flag_scan_kernel<<<dim3(ntiles, 2), kBlock, 0, stream>>>(first_all, n_total, n, rank, gsrc, pfx, boff, ntiles);
+    shard_plan_kernel<<<1, kBlock, 0, stream>>>(first_all, n_total, n, rank, world, pfx, boff, ntiles, plan, rplan);
+    ancestors_sharded_kernel<<<blocks_for(n), kBlock, 0, stream>>>(gsrc, pfx, boff, ntiles, rplan, n, rank, world, src);
     return hipGetLastError();
 }
 
-hipError_t launch_migrate_pack(hipStream_t stream, const int32_t* first_all, int64_t n_total, int n, int rank,
-                               const MigratePlan& plan, const float* pose, int64_t pose_ld, const float* map,
-                               int64_t row_stride, int plane_stride, int nlandmarks, float* out)
+// plan.lo[d] = send_base[d] (the P value of the first particle sent to d), plan.off = running record offsets
+hipError_t launch_migrate_pack(hipStream_t stream, const int32_t* scratch, int n, const MigratePlan& plan,
+                               const float* pose, int64_t pose_ld, const float* map, int64_t row_stride,
+                               int plane_stride, int nlandmarks, float* out)
 {
     const int total = plan.off[plan.world];
     if (total <= 0) return hipSuccess;
-    migrate_pack_kernel<<<total, kBlock, 0, stream>>>(first_all, n_total, n, rank, plan, pose, pose_ld, map, row_stride,
+    const int ntiles = (n + kShardTile - 1) / kShardTile;
+    const int32_t* pfx = scratch + n;
+    const int32_t* boff = pfx + 2 * (int64_t)n;
+    migrate_pack_kernel<<<total, kBlock, 0, stream>>>(pfx, boff, ntiles, n, plan, pose, pose_ld, map, row_stride,
                                                      plane_stride, nlandmarks, out);
     return hipGetLastError();
 }

@@ -81,13 +81,11 @@ class HipOps:
     def ancestors(self, first_all, n_total, slot0, nslots, anc):
         self.e.ancestors_dev(first_all, n_total, slot0, nslots, anc)
 
-    def ancestors_sharded(self, first_all, n_total, n_local, rank, world, src):
-        self.e.ancestors_sharded_dev(first_all, n_total, n_local, rank, world, src)
+    def ancestors_sharded(self, first_all, n_total, n_local, rank, world, src, plan):
+        self.e.ancestors_sharded_dev(first_all, n_total, n_local, rank, world, src, plan)
 
-    def migrate_pack(self, first_all, n_total, n_local, rank, world, send_lo, send_cnt, pose, pose_ld, mp, row_stride,
-                     plane_stride, nlandmarks, out):
-        self.e.migrate_pack_dev(first_all, n_total, n_local, rank, world, send_lo, send_cnt, pose, pose_ld, mp,
-                                row_stride, plane_stride, nlandmarks, out)
+    def migrate_pack(self, n_local, rank, world, plan, pose, pose_ld, mp, row_stride, plane_stride, nlandmarks, out):
+        self.e.migrate_pack_dev(n_local, rank, world, plan, pose, pose_ld, mp, row_stride, plane_stride, nlandmarks, out)
 
     def migrate_unpack(self, inp, world, recv_cnt, n_local, pose, pose_ld, mp, row_stride, plane_stride, nlandmarks):
         self.e.migrate_unpack_dev(inp, world, recv_cnt, n_local, pose, pose_ld, mp, row_stride, plane_stride, nlandmarks)
@@ -138,7 +136,7 @@ class ParticleFilter:
         self.d_max = torch.zeros(1, dtype=f32, device=dv)                         # of frame t+1 read frame t's indices
         self.d_sum = torch.zeros(1, dtype=i64, device=dv)
         self.totals = torch.zeros(world, dtype=i64, device=dv)
-        self._bound_sel = (torch.arange(world, device=dv) * self.n).long()   # first_all[q*n]: start of rank q's slot run
+        self.plan = torch.zeros(1 + 3 * world, dtype=i32, device=dv)         # exchange plan of the frame (slam_hip.h)
         self.frame = 0
         self.migrated_last = 0
         # gloo cannot move GPU tensors for every collective used here: stage them through the host then
@@ -238,38 +236,25 @@ class ParticleFilter:
             o.ancestors(self.first, self.n_total, 0, n, anc)
             self.migrated_last = 0
         else:
-            # 6. particles whose ancestor lives on another GPU.  The gather index needs nothing from the host;
-            # only the split sizes of the all-to-all do (world+1 boundary values: one tiny device->host read).
+            # 6. particles whose ancestor lives on another GPU.  The gather index and the exchange plan are made on
+            # the device; the host reads the plan once (3 * world + 1 words) for the all-to-all's split sizes.
             self._all_gather(self.first_all, self.first)
-            o.ancestors_sharded(self.first_all, self.n_total, n, self.rank, self.world, anc)
+            o.ancestors_sharded(self.first_all, self.n_total, n, self.rank, self.world, anc, self.plan)
             self._migrate()
         self.src_idx = anc
         self.frame += 1
 
     # ------------------------------------------------------------------ multi-GPU exchange
-    def _plan(self):
-        """Slot ranges [A_s, B_s) filled by the particles of rank s: A_s = first_all[s*n]."""
-        n, G = self.n, self.world
-        bounds = self.first_all[self._bound_sel].cpu().tolist() + [self.n_total]   # the one device->host sync of a frame
-        r = self.rank
-        send = [(max(bounds[r], d * n), min(bounds[r + 1], (d + 1) * n)) for d in range(G)]
-        recv = [(max(bounds[s], r * n), min(bounds[s + 1], (r + 1) * n)) for s in range(G)]
-        send = [(lo, hi) if hi > lo and d != r else (0, 0) for d, (lo, hi) in enumerate(send)]
-        recv = [(lo, hi) if hi > lo and s != r else (0, 0) for s, (lo, hi) in enumerate(recv)]
-        # every rank sees the same boundaries, so all ranks agree on whether anything moves at all
-        anything = any(bounds[s] != s * n for s in range(1, G))
-        return send, recv, anything
-
     def _migrate(self):
         """pack (one launch) -> one all-to-all carrying poses and map rows -> unpack (one launch) into the
-        staging tail of the current buffers, where the next frame's fused gathers pick them up."""
+        staging tail of the current buffers, where the next frame's fused gathers pick them up.  A remote ancestor
+        travels once per destination rank, however many slots there descend from it."""
         o, n, r, G, dv, L = self.ops, self.n, self.rank, self.world, self.device, self.L
-        send, recv, anything = self._plan()
+        plan = self.plan.cpu().tolist()   # the one device->host sync of a frame
+        anything, scnt, rcnt = plan[0], plan[1:1 + G], plan[1 + G:1 + 2 * G]
         if not anything and self.world > 1:   # every run boundary coincides with a rank boundary: all ranks skip
             self.migrated_last = 0
             return
-        scnt = [hi - lo for lo, hi in send]
-        rcnt = [hi - lo for lo, hi in recv]
         stot, rtot = sum(scnt), sum(rcnt)
         if rtot > self.recv_cap:
             raise RuntimeError(f"rank {r}: {rtot} particles to receive exceed recv_capacity {self.recv_cap}")
@@ -279,8 +264,7 @@ class ParticleFilter:
         rbuf = torch.empty(rows * rtot, dtype=torch.float32, device=dv)
         pose = self.pose[self.cur]
         mp = self.map[self.cur] if L else None
-        o.migrate_pack(self.first_all, self.n_total, n, r, G, [lo for lo, _ in send], scnt, pose, self.cap, mp,
-                       5 * self.Lp, self.Lp, L, sbuf)
+        o.migrate_pack(n, r, G, plan, pose, self.cap, mp, 5 * self.Lp, self.Lp, L, sbuf)
         self._all_to_all(rbuf, sbuf, [rows * c for c in rcnt], [rows * c for c in scnt])
         o.migrate_unpack(rbuf, G, rcnt, n, pose, self.cap, mp, 5 * self.Lp, self.Lp, L)
 

@@ -258,20 +258,25 @@ uint64_t slam_comb_offset(uint64_t seed, uint32_t frame, uint64_t total);
 /* Several GPUs (one engine per rank; n_total = world * n_local particles; world <= 16).  After the `first`
  * arrays of all ranks were all-gathered into d_first_all:
  *  - slam_ancestors_sharded_dev: the gather index of this rank's n_local slots — a local particle index when
- *    the ancestor is local, else n_local + its position in the staging tail behind the local particles,
- *    which holds the runs received from ranks 0..world-1 in rank order (the particles of rank s fill one
- *    contiguous slot run because `first` is sorted).  Needs nothing from the host.
- *  - slam_migrate_pack_dev: one launch packs, for every destination q, the send_cnt[q] consecutive slots
- *    starting at global slot send_lo[q] (host arrays of `world` entries, 0 for this rank itself) whose
- *    ancestors are this rank's particles, as block q = send_cnt[q] records of 3 + 5*nlandmarks floats (x, y,
- *    theta, then the five map planes of nlandmarks values each) — the layout of one all-to-all send buffer.
- *  - slam_migrate_unpack_dev: the received blocks (recv_cnt[q] records from rank q, same layout) into the
- *    staging tail of the pose arrays (rows x|y|theta, leading dimension pose_ld = particle capacity, which
- *    the map must have as rows too) and of the map. */
+ *    the ancestor is local, else n_local + its row in the staging tail behind the local particles.  A remote
+ *    ancestor is received ONCE, however many of this rank's slots descend from it: the tail holds, in rank
+ *    order and inside a rank in particle order, the distinct remote ancestors of this rank's slots.  Also writes
+ *    the exchange plan of the frame to d_plan (SLAM_PLAN_WORDS(world) int32 words, device memory):
+ *      [0] nonzero when any rank exchanges anything this frame (the same value on every rank),
+ *      [1 .. world] send_cnt[q]: rows this rank sends to rank q,  [1+world .. 2*world] recv_cnt[q],
+ *      [1+2*world .. 3*world] internal to the pack step.
+ *    Needs nothing from the host; the host reads the plan once for the all-to-all's split sizes.
+ *  - slam_migrate_pack_dev: one launch packs, for every destination q, its send_cnt[q] rows as records of
+ *    3 + 5*nlandmarks floats (x, y, theta, then the five map planes of nlandmarks values each) — the layout of
+ *    one all-to-all send buffer.  `plan` is the host copy of d_plan; uses state left by the
+ *    slam_ancestors_sharded_dev call of the same frame on this engine.
+ *  - slam_migrate_unpack_dev: the received records (recv_cnt[q] from rank q, same layout) into the staging
+ *    tail of the pose arrays (rows x|y|theta, leading dimension pose_ld = particle capacity, which the map
+ *    must have as rows too) and of the map. */
+#define SLAM_PLAN_WORDS(world) (1 + 3 * (world))
 int slam_ancestors_sharded_dev(slam_engine *e, const int32_t *d_first_all, int64_t n_total, int n_local, int rank,
-                               int world, int32_t *d_src);
-int slam_migrate_pack_dev(slam_engine *e, const int32_t *d_first_all, int64_t n_total, int n_local, int rank,
-                          int world, const int64_t *send_lo, const int32_t *send_cnt, const float *d_pose,
+                               int world, int32_t *d_src, int32_t *d_plan);
+int slam_migrate_pack_dev(slam_engine *e, int n_local, int rank, int world, const int32_t *plan, const float *d_pose,
                           int64_t pose_ld, const float *d_map, int64_t row_stride, int plane_stride, int nlandmarks,
                           float *d_out);
 int slam_migrate_unpack_dev(slam_engine *e, const float *d_in, int world, const int32_t *recv_cnt, int n_local,

@@ -96,30 +96,49 @@ class OracleOps:
     def ancestors(self, first_all, n_total, slot0, nslots, anc):
         anc[:nslots] = torch.from_numpy(oracle.ancestors(_np(first_all)[:n_total], slot0, nslots))
 
-    def ancestors_sharded(self, first_all, n_total, n_local, rank, world, src):
-        fa = _np(first_all)[:n_total].astype(np.int64)
-        bounds = [int(fa[q * n_local]) for q in range(world)] + [n_total]
-        lo_me, hi_me = rank * n_local, (rank + 1) * n_local
-        lo, off, run = [], [], 0
-        for q in range(world):
-            a, b = max(bounds[q], lo_me), min(bounds[q + 1], hi_me)
-            lo.append(a); off.append(run)
-            if q != rank and b > a:
-                run += b - a
-        g = oracle.ancestors(_np(first_all)[:n_total], lo_me, n_local).astype(np.int64)
-        owner = g // n_local
-        j = np.arange(lo_me, hi_me, dtype=np.int64)
-        out = np.where(owner == rank, g - lo_me, n_local + np.array(off)[owner] + (j - np.array(lo)[owner]))
-        src[:n_local] = torch.from_numpy(out.astype(np.int32))
+    def ancestors_sharded(self, first_all, n_total, n_local, rank, world, src, plan):
+        """Independent restatement with numpy set operations: rank s sends rank r the DISTINCT ancestors (its own
+        particles) of r's slots, in particle order; r stages them in rank order behind its n_local particles."""
+        fa = _np(first_all)[:n_total]
+        n = n_local
+        g_all = oracle.ancestors(fa, 0, n_total).astype(np.int64)            # ancestor of every slot of every rank
+        owner_all = g_all // n
+        bounds = [int(fa[q * n]) for q in range(world)] + [n_total]
+        out_plan = np.zeros(1 + 3 * world, np.int32)
+        out_plan[0] = int(any(bounds[q] != q * n for q in range(1, world)))
+        mine = g_all[rank * n:(rank + 1) * n]
+        out = np.empty(n, np.int64)
+        off = 0
+        for s_ in range(world):
+            sel = owner_all[rank * n:(rank + 1) * n] == s_
+            if s_ == rank:
+                out[sel] = mine[sel] - rank * n
+                continue
+            uniq, inv = np.unique(mine[sel], return_inverse=True)
+            out[sel] = n + off + inv
+            out_plan[1 + world + s_] = len(uniq)
+            off += len(uniq)
+        self._send_rows = []
+        for d in range(world):
+            slots = g_all[d * n:(d + 1) * n]
+            uniq = np.unique(slots[(owner_all[d * n:(d + 1) * n] == rank)]) if d != rank else np.empty(0, np.int64)
+            self._send_rows.append((uniq - rank * n).astype(np.int64))
+            out_plan[1 + d] = len(uniq)
+            # send_base: 1-based rank of the first sent particle among this rank's particles that have offspring
+            if len(uniq):
+                cnt = np.diff(np.append(fa[rank * n:(rank + 1) * n], fa[(rank + 1) * n] if (rank + 1) * n < n_total else n_total))
+                out_plan[1 + 2 * world + d] = int(np.count_nonzero(cnt[: int(uniq[0] - rank * n) + 1] > 0))
+        src[:n] = torch.from_numpy(out.astype(np.int32))
+        plan[:] = torch.from_numpy(out_plan)
 
-    def migrate_pack(self, first_all, n_total, n_local, rank, world, send_lo, send_cnt, pose, pose_ld, mp, row_stride,
-                     plane_stride, nlandmarks, out):
+    def migrate_pack(self, n_local, rank, world, plan, pose, pose_ld, mp, row_stride, plane_stride, nlandmarks, out):
         rec, off = 3 + 5 * nlandmarks, 0
         for d in range(world):
-            c = send_cnt[d]
+            loc = torch.from_numpy(self._send_rows[d])
+            c = len(loc)
+            assert c == plan[1 + d]
             if not c:
                 continue
-            loc = torch.from_numpy((oracle.ancestors(_np(first_all)[:n_total], send_lo[d], c) - rank * n_local).astype(np.int64))
             blk = out[rec * off: rec * (off + c)].view(c, rec)
             blk[:, :3] = pose[:, loc].T
             if nlandmarks:

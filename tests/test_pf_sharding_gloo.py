@@ -36,7 +36,7 @@ def test_sharded_equals_unsharded(orc, tmp_path, L, world):
         assert np.array_equal(mapc.view(np.uint32), ref["map"].view(np.uint32))
     # the scenario really exercised the exchange: the upper half of the population collapses and is refilled
     # from the lower half, i.e. from other ranks (several sources per receiver when world > 2)
-    assert parts[-1]["migrated"].max() > 50
+    assert parts[-1]["migrated"].max() > 10   # rows, i.e. distinct ancestors (each travels once per destination)
     # every rank agrees on the heaviest particle, and it is the unsharded answer
     for p in parts:
         assert tuple(p["best"]) == tuple(np.array(ref["best"]))
