@@ -86,6 +86,7 @@ struct EkfArgs {
     float meas_var;
     float* loglik;        // [n], always written
     float* loglik_user;   // optional second copy for the caller
+    int xcd_chunk;        // set by the launcher: workgroups per XCD when the grid is renumbered XCD-contiguously, else 0
 };
 hipError_t launch_ekf_update(hipStream_t stream, const EkfArgs& a, const EventPair* ev = nullptr);
 

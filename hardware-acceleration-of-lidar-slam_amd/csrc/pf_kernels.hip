@@ -98,6 +98,14 @@ constexpr int kEkfWaves = 4;   // particles per workgroup
 // global-address-space pointers: "scalar base + 32-bit lane offset" is an addressing mode of global_load/store only
 typedef __attribute__((address_space(1))) char gchar;
 typedef __attribute__((address_space(1))) float gfloat;
+__device__ __forceinline__ float row_load(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff)
+{
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, soff, 0));
+}
+__device__ __forceinline__ void row_store(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff, float v)
+{
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, (int)voff, soff, 0);
+}
 __device__ __forceinline__ gchar* uniform_gptr(const void* p)   // tell the compiler the pointer is wave-uniform
 {
     const uint64_t v = reinterpret_cast<uint64_t>(p);
@@ -106,8 +114,10 @@ __device__ __forceinline__ gchar* uniform_gptr(const void* p)   // tell the comp
 }
 
 struct EkfLane {   // per-wavefront constants of one particle
-    const gchar* rin[5];   // plane bases of the source row and of the destination row: wave-uniform, kept in SGPRs so
-    gchar* rout[5];        // that every access is "scalar base + 32-bit lane offset" with no 64-bit vector arithmetic
+    // source row and destination row as buffer resources (wave-uniform descriptors in SGPRs): an access is
+    // "descriptor + 32-bit lane offset + scalar plane offset", no 64-bit vector arithmetic for loads or stores
+    __amdgpu_buffer_rsrc_t rin, rout;
+    int pl;   // plane stride in bytes
     const gchar *ozx, *ozy;
     unsigned L;
     v2f s, c, px, py, q;
@@ -148,7 +158,7 @@ __device__ __forceinline__ void ekf_batches(const EkfLane& w, unsigned lb, unsig
         for (int t = 0; t < 2; ++t)
             if (FULL || use[g][t]) {
 #pragma unroll
-                for (int p = 0; p < 5; ++p) m[g][p][t] = *(const gfloat*)(w.rin[p] + off[g][t]);
+                for (int p = 0; p < 5; ++p) m[g][p][t] = row_load(w.rin, off[g][t], p * w.pl);
             }
 #pragma unroll
     for (int g = 0; g < NB; ++g) {
@@ -159,7 +169,7 @@ __device__ __forceinline__ void ekf_batches(const EkfLane& w, unsigned lb, unsig
             for (int t = 0; t < 2; ++t)
                 if (FULL || use[g][t]) {
 #pragma unroll
-                    for (int p = 0; p < 5; ++p) *(gfloat*)(w.rout[p] + off[g][t]) = m[g][p][t];
+                    for (int p = 0; p < 5; ++p) row_store(w.rout, off[g][t], p * w.pl, m[g][p][t]);
                 }
             continue;
         }
@@ -190,18 +200,21 @@ __device__ __forceinline__ void ekf_batches(const EkfLane& w, unsigned lb, unsig
         for (int t = 0; t < 2; ++t) {
             const bool ob = obs[g][t];
             const bool first = pxx[t] < 0.0f;
-            o0[t] = !ob ? mx[t] : first ? f0[t] : o0[t];
-            o1[t] = !ob ? my[t] : first ? f1[t] : o1[t];
-            o2[t] = !ob ? pxx[t] : first ? q[t] : o2[t];
-            o3[t] = !ob ? pxy[t] : first ? 0.0f : o3[t];
-            o4[t] = !ob ? pyy[t] : first ? q[t] : o4[t];
-            ll[t] = (!ob || first) ? 0.0f : ll[t];
+            // two plain selects per value (nested ternaries came out as exec-mask branches)
+            float r0 = first ? f0[t] : o0[t], r1 = first ? f1[t] : o1[t], r2 = first ? q[t] : o2[t];
+            float r3 = first ? 0.0f : o3[t], r4 = first ? q[t] : o4[t], rl = first ? 0.0f : ll[t];
+            r0 = ob ? r0 : mx[t];
+            r1 = ob ? r1 : my[t];
+            r2 = ob ? r2 : pxx[t];
+            r3 = ob ? r3 : pxy[t];
+            r4 = ob ? r4 : pyy[t];
+            ll[t] = ob ? rl : 0.0f;
             if (FULL || use[g][t]) {
-                *(gfloat*)(w.rout[0] + off[g][t]) = o0[t];
-                *(gfloat*)(w.rout[1] + off[g][t]) = o1[t];
-                *(gfloat*)(w.rout[2] + off[g][t]) = o2[t];
-                *(gfloat*)(w.rout[3] + off[g][t]) = o3[t];
-                *(gfloat*)(w.rout[4] + off[g][t]) = o4[t];
+                row_store(w.rout, off[g][t], 0 * w.pl, r0);
+                row_store(w.rout, off[g][t], 1 * w.pl, r1);
+                row_store(w.rout, off[g][t], 2 * w.pl, r2);
+                row_store(w.rout, off[g][t], 3 * w.pl, r3);
+                row_store(w.rout, off[g][t], 4 * w.pl, r4);
             }
         }
         acc = acc + ll;
@@ -214,17 +227,23 @@ __global__ __launch_bounds__(kEkfWaves * 64) void ekf_update_kernel(EkfArgs a)
 {
     const unsigned lane = threadIdx.x & 63u;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int i = blockIdx.x * kEkfWaves + wave;
+    // Workgroups are dealt to the 8 XCDs round-robin.  Renumber them so that each XCD (one L2) works on one
+    // contiguous eighth of the particles: the offspring of an ancestor then share ONE L2 instead of up to eight.
+    int bid = blockIdx.x;
+    if (a.xcd_chunk > 0) {
+        const int per = a.xcd_chunk;   // workgroups per XCD, gridDim.x == 8 * per
+        bid = (bid & 7) * per + (bid >> 3);
+    }
+    const int i = bid * kEkfWaves + wave;
     if (i >= a.n) return;
     const int src = a.anc ? a.anc[i] : i;
     float st_, ct_;
     det_sincosf(a.th[i], st_, ct_);
     EkfLane w;
-#pragma unroll
-    for (int p = 0; p < 5; ++p) {
-        w.rin[p] = uniform_gptr(a.map_in + (int64_t)src * a.row_stride + (int64_t)p * a.plane_stride);
-        w.rout[p] = uniform_gptr(a.map_out + (int64_t)i * a.row_stride + (int64_t)p * a.plane_stride);
-    }
+    const int row_bytes = __builtin_amdgcn_readfirstlane(5 * a.plane_stride * 4);
+    w.rin = __builtin_amdgcn_make_buffer_rsrc((void*)uniform_gptr(a.map_in + (int64_t)src * a.row_stride), 0, row_bytes, 0x00020000);
+    w.rout = __builtin_amdgcn_make_buffer_rsrc((void*)uniform_gptr(a.map_out + (int64_t)i * a.row_stride), 0, row_bytes, 0x00020000);
+    w.pl = __builtin_amdgcn_readfirstlane(a.plane_stride * 4);
     w.ozx = uniform_gptr(a.obs_zx);
     w.ozy = uniform_gptr(a.obs_zy);
     w.L = (unsigned)a.nlandmarks;
@@ -866,10 +885,17 @@ hipError_t launch_motion_sample(hipStream_t stream, const float* sx, const float
     return hipGetLastError();
 }
 
-hipError_t launch_ekf_update(hipStream_t stream, const EkfArgs& a, const EventPair* ev)
+hipError_t launch_ekf_update(hipStream_t stream, const EkfArgs& a_in, const EventPair* ev)
 {
-    if (a.n <= 0) return hipSuccess;
-    const int blocks = (a.n + kEkfWaves - 1) / kEkfWaves;
+    if (a_in.n <= 0) return hipSuccess;
+    EkfArgs a = a_in;
+    int blocks = (a.n + kEkfWaves - 1) / kEkfWaves;
+    static const int xcd_env = getenv("SLAM_EKF_XCD") ? atoi(getenv("SLAM_EKF_XCD")) : 1;   // tuning knob
+    a.xcd_chunk = 0;
+    if (xcd_env && blocks >= 64) {   // pad the grid to a multiple of 8 (surplus workgroups exit at once)
+        a.xcd_chunk = (blocks + 7) / 8;
+        blocks = 8 * a.xcd_chunk;
+    }
     const bool copy = a.map_in != a.map_out;   // in place: rows without an observation stay as they are
     static const int nb_env = getenv("SLAM_EKF_NB") ? atoi(getenv("SLAM_EKF_NB")) : 0;   // tuning knob
     const int nb = nb_env ? nb_env : (a.nlandmarks <= 128 ? 1 : 2);
