@@ -96,7 +96,9 @@ def sensor_frame(points, pose):
     return np.stack([ct * d[:, 0] - st * d[:, 1], st * d[:, 0] + ct * d[:, 1]], 1)
 
 
-def make_frames(nframes, nbeams, landmarks, rng):
+def make_frames(nframes, nbeams, landmarks, rng, observed=0):
+    """observed = K > 0: only the K landmarks nearest to the sensor are seen in a frame (SURVEY §8d's end-to-end
+    variant); 0: every landmark is seen in every frame (the roofline sweep, the default workload)."""
     frames = []
     ang = -np.pi + 2 * np.pi * np.arange(nbeams) / nbeams
     prev = true_pose(0)
@@ -106,6 +108,9 @@ def make_frames(nframes, nbeams, landmarks, rng):
         bx, by = (r * np.cos(ang)).astype(np.float32), (r * np.sin(ang)).astype(np.float32)
         z = sensor_frame(landmarks, pose) + rng.normal(0, 0.02, landmarks.shape)
         ids = rng.permutation(len(landmarks)).astype(np.int32)
+        if 0 < observed < len(landmarks):
+            near = np.argsort(np.hypot(z[:, 0], z[:, 1]))[:observed]
+            ids = ids[np.isin(ids, near)]
         frames.append(dict(bx=bx, by=by, dp=(pose - prev).astype(np.float32), ids=ids,
                            zx=z[ids, 0].astype(np.float32), zy=z[ids, 1].astype(np.float32)))
         prev = pose
@@ -171,6 +176,8 @@ def main():
     ap.add_argument("--host-sensor", action="store_true", help="upload scan + observations from the host every frame")
     ap.add_argument("--events", choices=["dominant", "all", "none"], default="dominant",
                     help="kernels bracketed by HIP events inside the timed region (a pair costs a few us of stream time)")
+    ap.add_argument("--observed", type=int, default=0,
+                    help="landmarks seen per frame: 0 = all (default, the roofline workload), K = the K nearest")
     ap.add_argument("--stats", action="store_true",
                     help="diagnostics: print the number of distinct resample ancestors per frame (synchronises; not for timing)")
     args = ap.parse_args()
@@ -216,7 +223,7 @@ def main():
     min_x, min_y = np.float32(-4.24), np.float32(-10.24)
     occ = occupancy(args.grid, float(pixel), float(min_x), float(min_y))
     nframes = args.steps + args.warmup + 10   # + the short per-kernel timing pass after the timed region
-    frames = make_frames(nframes, args.beams, landmarks, rng)
+    frames = make_frames(nframes, args.beams, landmarks, rng, args.observed)
 
     d_occ = torch.from_numpy(occ).to(dev)
     d_edt = torch.empty((args.grid, args.grid), dtype=torch.float32, device=dev)
@@ -343,7 +350,7 @@ def main():
     tfile = ROOT / "profiles" / "traffic.json"   # HBM bytes per launch from rocprofv3 --pmc runs of this command
     if tfile.exists():
         rec = json.loads(tfile.read_text()).get(f"{args.mode}:{n}:{args.beams}:{L}:{args.grid}", {})
-        traffic = rec.get(kern)
+        traffic = rec.get(kern) if not (0 < args.observed < L) else None   # measured for the all-observed workload
     out = {
         "metric": "particle-updates/sec (N_particles x scans/s) on 360-beam lidar",
         "value": value, "unit": "particle-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -353,7 +360,8 @@ def main():
                                       "EKF over all landmarks, weights, resample)",
                                 "score": "scan-match score only", "ekf": "EKF sweep only"}[args.mode],
                    "mode": args.mode, "particles_per_gpu": n, "particles_total": n_total, "beams": args.beams,
-                   "landmarks": L, "edt_grid": f"{args.grid}x{args.grid}", "parallelism": f"particle-shard x{world}",
+                   "landmarks": L, "landmarks_observed_per_frame": (args.observed if 0 < args.observed < L else L),
+                   "edt_grid": f"{args.grid}x{args.grid}", "parallelism": f"particle-shard x{world}",
                    "rows_received_per_frame_max_rank": migrated if world > 1 else 0},
         "roofline": {"bound": "hbm", "kernel": kern, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": alg,
