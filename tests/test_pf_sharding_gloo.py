@@ -21,7 +21,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("L,world", [(6, 2), (0, 2), (6, 4), (0, 3)])
+@pytest.mark.parametrize("L,world", [(6, 2), (0, 2), (6, 4), (0, 3), (6, 8)])
 def test_sharded_equals_unsharded(orc, tmp_path, L, world):
     n_total, frames = 768, 6
     ref = W.run_filter(0, 1, n_total, L, frames)
