@@ -86,6 +86,7 @@ SIGNATURES = {
     "slam_offspring_offsets_dev": (_i, [_vp, _vp, _i, _vp, _vp, _u64, _u32, _i64, _vp]),
     "slam_ancestors_dev": (_i, [_vp, _vp, _i64, _i64, _i, _vp]),
     "slam_comb_offset": (_u64, [_u64, _u32, _u64]),
+    "slam_ancestors_from_scan_dev": (_i, [_vp, _i, _u64, C.c_uint32, _vp]),
     "slam_ancestors_sharded_dev": (_i, [_vp, _vp, _i64, _i, _i, _i, _vp, _vp]),
     "slam_migrate_pack_dev": (_i, [_vp, _i, _i, _i, _vp, _vp, _i64, _vp, _i64, _i, _i, _vp]),
     "slam_migrate_unpack_dev": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i64, _vp, _i64, _i, _i]),
@@ -343,6 +344,9 @@ class Engine:
     def ancestors_dev(self, d_first_all, n_total, slot0, nslots, d_anc):
         self._ck(self.lib.slam_ancestors_dev(self.h, _ptr(d_first_all), n_total, slot0, nslots, _ptr(d_anc)),
                  "ancestors_dev")
+
+    def ancestors_from_scan_dev(self, n, seed, frame, d_anc):
+        self._ck(self.lib.slam_ancestors_from_scan_dev(self.h, n, seed, frame, _ptr(d_anc)), "ancestors_from_scan_dev")
 
     def ancestors_sharded_dev(self, d_first_all, n_total, n_local, rank, world, d_src, d_plan):
         """d_plan: int32[plan_words(world)] on the device: [0] anything moves, send_cnt[world], recv_cnt[world], ..."""

@@ -156,6 +156,7 @@ int slam_engine_destroy(slam_engine* e)
     e->scan_state.release();
     e->ll_buf.release();
     e->shard_buf.release();
+    e->first_buf.release();
     if (e->h_stage) (void)hipHostFree(e->h_stage);
     for (auto& ev : e->stage_ev)
         if (ev) (void)hipEventDestroy(ev);
@@ -683,6 +684,24 @@ int slam_offspring_from_scan_dev(slam_engine* e, int n, const uint64_t* d_base, 
     const uint64_t* cdf = e->scan_state.as<uint64_t>();
     HIP_TRY(launch_offspring_from_scan(e->stream, cdf, cdf + n, n, d_base, d_total, nullptr, 0, 1, seed, frame, n_total,
                                        d_first));
+    return SLAM_OK;
+}
+
+int slam_ancestors_from_scan_dev(slam_engine* e, int n, uint64_t seed, uint32_t frame, int32_t* d_anc)
+{
+    ENTER(e);
+    if (n <= 0 || !d_anc) return SLAM_ERR_INVALID_ARG;
+    if (e->scan_n != n) return SLAM_ERR_NOT_READY;
+    const uint64_t* cdf = e->scan_state.as<uint64_t>();
+    if (ancestors_from_scan_fits(n)) {
+        HIP_TRY(launch_ancestors_from_scan(e->stream, cdf, cdf + n, n, seed, frame, d_anc));
+        return SLAM_OK;
+    }
+    // more tiles than the one-launch form keeps in LDS: the two-launch form through a scratch `first` array
+    HIP_TRY(e->first_buf.ensure(sizeof(int32_t) * (size_t)n));
+    int32_t* first = e->first_buf.as<int32_t>();
+    HIP_TRY(launch_offspring_from_scan(e->stream, cdf, cdf + n, n, nullptr, nullptr, nullptr, 0, 1, seed, frame, n, first));
+    HIP_TRY(launch_ancestors(e->stream, first, n, 0, n, d_anc));
     return SLAM_OK;
 }
 

@@ -84,6 +84,7 @@ struct slam_engine {
     int scan_n = -1;
     DevBuf shard_buf;          // flag scans of the last slam_ancestors_sharded_dev call (read by slam_migrate_pack_dev)
     int shard_n = -1;
+    DevBuf first_buf;          // scratch `first` array of slam_ancestors_from_scan_dev's large-n fallback
     DevBuf ll_buf;             // log-likelihood [n] of the last EKF call
     int ll_n = -1;
     // pinned staging ring for the per-frame sensor uploads: one host-to-device copy per upload, and the

@@ -110,6 +110,10 @@ hipError_t launch_offspring_offsets(hipStream_t stream, const uint64_t* cdf, int
                                     int32_t* first);
 hipError_t launch_ancestors(hipStream_t stream, const int32_t* first_all, int64_t n_total, int64_t slot0, int nslots,
                             int32_t* anc);
+// single GPU: offspring offsets + ancestors in one launch (n up to 8M; beyond that use the two launches above)
+bool ancestors_from_scan_fits(int n);
+hipError_t launch_ancestors_from_scan(hipStream_t stream, const uint64_t* cdf_local, const uint64_t* tile_total, int n,
+                                      uint64_t seed, uint32_t frame, int32_t* anc);
 // multi-GPU resample (see pf_kernels.hip): per-peer slot runs, offsets in the packed exchange buffers
 enum { kMaxRanks = 16 };
 struct MigratePlan {

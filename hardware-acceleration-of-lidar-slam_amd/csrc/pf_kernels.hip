@@ -604,6 +604,53 @@ __global__ __launch_bounds__(kBlock) void offspring_from_scan_kernel(const uint6
     first[i] = comb_first(c_excl, total, n_total, key0, key1, frame);
 }
 
+// Single GPU: the ancestor of every slot straight from the tile-local scan, without materialising `first`.
+// first[i] <= j  <=>  N*C_excl(i) <= j*S + u  (first[i] = ceil((N*C_excl(i) - u)/S), clamped at 0), so the ancestor
+// of slot j — the last i with first[i] <= j — is the number of k in [0, n-1) with N*C_incl(k) <= j*S + u.
+// Both sides are 96-bit quantities, compared as (hi, lo) pairs.  Tile offsets live in LDS: n <= kMaxLdsTiles*2048.
+constexpr int kMaxLdsTiles = 4096;
+template <int kPer>   // tiles per thread: 1 covers n <= 512k with 2 KB of LDS, 16 covers n <= 8M with 32 KB
+__global__ __launch_bounds__(kBlock) void ancestors_from_scan_kernel(const uint64_t* __restrict__ cdf_local,
+                                                                     const uint64_t* __restrict__ tile_total,
+                                                                     int ntiles, int n, uint32_t key0, uint32_t key1,
+                                                                     uint32_t frame, int32_t* __restrict__ anc)
+{
+    __shared__ uint64_t s_off[kPer * kBlock];
+    __shared__ uint64_t s_wave[kBlock / 64];
+    uint64_t v[kPer], run = 0;
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+        const int t = threadIdx.x * kPer + k;
+        v[k] = run;   // exclusive within the thread
+        run += t < ntiles ? tile_total[t] : 0ull;
+    }
+    uint64_t total;
+    const uint64_t excl = block_inclusive_scan(run, s_wave, total) - run;
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) s_off[threadIdx.x * kPer + k] = v[k] + excl;
+    __syncthreads();
+    const int j = blockIdx.x * kBlock + threadIdx.x;
+    if (j >= n) return;
+    if (total == 0 || (total >> 63)) {   // see offspring_offsets_kernel: every slot gets the last particle
+        anc[j] = n - 1;
+        return;
+    }
+    const u32x4 r = philox4x32_10(0u, 0u, frame, 1u /* resample stream */, key0, key1);
+    const uint64_t comb_u = __umul64hi((uint64_t)r.v[0] | ((uint64_t)r.v[1] << 32), total);
+    uint64_t t_lo = (uint64_t)j * total, t_hi = __umul64hi((uint64_t)j, total);
+    t_lo += comb_u;
+    t_hi += t_lo < comb_u ? 1ull : 0ull;
+    const uint64_t N = (uint64_t)n;
+    int lo = 0, hi = n - 1;   // number of k in [0, n-1) with N*C_incl(k) <= T
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        const uint64_t c = cdf_local[mid] + s_off[mid / kScanTile];
+        const uint64_t x_lo = c * N, x_hi = __umul64hi(c, N);
+        if (x_hi < t_hi || (x_hi == t_hi && x_lo <= t_lo)) lo = mid + 1; else hi = mid;
+    }
+    anc[j] = lo;
+}
+
 __global__ __launch_bounds__(kBlock) void ancestors_kernel(const int32_t* __restrict__ first_all, int64_t n_total,
                                                            int64_t slot0, int nslots, int32_t* __restrict__ anc)
 {
@@ -982,6 +1029,22 @@ hipError_t launch_offspring_offsets(hipStream_t stream, const uint64_t* cdf, int
     offspring_offsets_kernel<<<blocks_for(n), kBlock, 0, stream>>>(cdf, n, d_base, d_total, (uint32_t)seed,
                                                                    (uint32_t)(seed >> 32), frame, (uint64_t)n_total,
                                                                    first);
+    return hipGetLastError();
+}
+
+bool ancestors_from_scan_fits(int n) { return n > 0 && (n + kScanTile - 1) / kScanTile <= kMaxLdsTiles; }
+
+hipError_t launch_ancestors_from_scan(hipStream_t stream, const uint64_t* cdf_local, const uint64_t* tile_total, int n,
+                                      uint64_t seed, uint32_t frame, int32_t* anc)
+{
+    if (n <= 0) return hipSuccess;
+    const int ntiles = (n + kScanTile - 1) / kScanTile;
+    if (ntiles <= kBlock)
+        ancestors_from_scan_kernel<1><<<blocks_for(n), kBlock, 0, stream>>>(cdf_local, tile_total, ntiles, n, (uint32_t)seed,
+                                                                            (uint32_t)(seed >> 32), frame, anc);
+    else
+        ancestors_from_scan_kernel<kMaxLdsTiles / kBlock><<<blocks_for(n), kBlock, 0, stream>>>(
+            cdf_local, tile_total, ntiles, n, (uint32_t)seed, (uint32_t)(seed >> 32), frame, anc);
     return hipGetLastError();
 }
 

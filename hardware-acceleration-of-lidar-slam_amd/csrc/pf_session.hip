@@ -183,9 +183,7 @@ int slam_pf_step(slam_pf* pf, int slot, const float dp[3], int use_observations)
     }
     if (rc != SLAM_OK) return rc;
     if ((rc = slam_quantise_scan_dev(e, pf->logw, nullptr, n, nullptr)) != SLAM_OK) return rc;
-    if ((rc = slam_offspring_from_scan_dev(e, n, nullptr, nullptr, pf->cfg.seed, pf->frame, n, pf->first)) != SLAM_OK)
-        return rc;
-    if ((rc = slam_ancestors_dev(e, pf->first, n, 0, n, pf->anc[nxt])) != SLAM_OK) return rc;
+    if ((rc = slam_ancestors_from_scan_dev(e, n, pf->cfg.seed, pf->frame, pf->anc[nxt])) != SLAM_OK) return rc;
     pf->cur = nxt;
     pf->has_anc = true;
     pf->frame++;

@@ -81,6 +81,9 @@ class HipOps:
     def ancestors(self, first_all, n_total, slot0, nslots, anc):
         self.e.ancestors_dev(first_all, n_total, slot0, nslots, anc)
 
+    def ancestors_from_scan(self, n, seed, frame, anc):
+        self.e.ancestors_from_scan_dev(n, seed, frame, anc)
+
     def ancestors_sharded(self, first_all, n_total, n_local, rank, world, src, plan):
         self.e.ancestors_sharded_dev(first_all, n_total, n_local, rank, world, src, plan)
 
@@ -228,12 +231,10 @@ class ParticleFilter:
             self._all_gather(self.totals, self.d_sum)
             o.offspring_from_scan_sharded(n, self.totals, self.rank, self.world, self.seed, self.frame, self.n_total,
                                           self.first)
-        else:
-            o.offspring_from_scan(n, None, None, self.seed, self.frame, self.n_total, self.first)
         anc = self.anc[nxt]
         self.cur = nxt
         if not multi:
-            o.ancestors(self.first, self.n_total, 0, n, anc)
+            o.ancestors_from_scan(n, self.seed, self.frame, anc)   # offspring offsets + ancestors in one launch
             self.migrated_last = 0
         else:
             # 6. particles whose ancestor lives on another GPU.  The gather index and the exchange plan are made on

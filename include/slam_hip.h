@@ -251,6 +251,10 @@ int slam_offspring_offsets_dev(slam_engine *e, const uint64_t *d_cdf, int n, con
                                int32_t *d_first);
 int slam_ancestors_dev(slam_engine *e, const int32_t *d_first_all, int64_t n_total, int64_t slot0, int nslots,
                        int32_t *d_anc);
+/* Single GPU, frame-loop form: the ancestor of every one of the n slots straight from the scan left by
+ * slam_quantise_scan_dev(n) — the same result as slam_offspring_from_scan_dev followed by
+ * slam_ancestors_dev, in one launch and without the intermediate `first` array. */
+int slam_ancestors_from_scan_dev(slam_engine *e, int n, uint64_t seed, uint32_t frame, int32_t *d_anc);
 /* The comb offset of a frame: uniform integer in [0,total) from Philox4x32-10 keyed by seed,
  * counter (0,0,frame,1).  Pure host function (every rank computes the same value). */
 uint64_t slam_comb_offset(uint64_t seed, uint32_t frame, uint64_t total);

@@ -96,6 +96,11 @@ class OracleOps:
     def ancestors(self, first_all, n_total, slot0, nslots, anc):
         anc[:nslots] = torch.from_numpy(oracle.ancestors(_np(first_all)[:n_total], slot0, nslots))
 
+    def ancestors_from_scan(self, n, seed, frame, anc):
+        first = torch.zeros(n, dtype=torch.int32)
+        self.offspring_from_scan(n, None, None, seed, frame, n, first)
+        self.ancestors(first, n, 0, n, anc)
+
     def ancestors_sharded(self, first_all, n_total, n_local, rank, world, src, plan):
         """Independent restatement with numpy set operations: rank s sends rank r the DISTINCT ancestors (its own
         particles) of r's slots, in particle order; r stages them in rank order behind its n_local particles."""

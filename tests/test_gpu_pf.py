@@ -545,6 +545,43 @@ def test_full_size_resample_8m_vs_oracle(eng, orc):
     assert (np.abs(cnt - n * w.astype(np.float64) / total) < 1.0 + 1e-6).all()
 
 
+@pytest.mark.parametrize("n", [1, 2, 7, 2048, 2049, 100_000, 1_048_576 + 3, 8 * 1024 * 1024, 8 * 1024 * 1024 + 2049])
+def test_ancestors_from_scan_equals_the_two_launch_form(eng, orc, n):
+    """slam_ancestors_from_scan_dev (one launch, 96-bit comparisons against the scan) == slam_offspring_from_scan_dev
+    + slam_ancestors_dev, on weights with zeros, ties and a dominant particle; tile counts up to the 4096 the
+    one-launch form keeps in LDS and beyond (its fallback); small sizes also against the CPU specification."""
+    rng = np.random.default_rng(n)
+    logw = (rng.normal(0, 3, n) - 5).astype(np.float32)
+    logw[rng.integers(0, n, max(n // 10, 1))] = -200.0     # weight exactly 0 after quantisation
+    logw[rng.integers(0, n)] = 0.0                          # the maximum
+    if n > 4:
+        logw[n // 2] = logw[n // 2 - 1]
+    lw, d_max = dev(logw), torch.empty(1, device=DEV)
+    tmp = torch.empty(n, device=DEV)
+    eng.logweight_dev(None, lw, 0.0, n, tmp, d_max)         # leaves the block maxima the scan needs
+    seed, frame = 99, 3
+    eng.quantise_scan_dev(tmp, None, n, None)
+    first = torch.empty(n, dtype=torch.int32, device=DEV)
+    eng.offspring_from_scan_dev(n, None, None, seed, frame, n, first)
+    two = torch.empty(n, dtype=torch.int32, device=DEV)
+    eng.ancestors_dev(first, n, 0, n, two)
+    one = torch.full((n,), -1, dtype=torch.int32, device=DEV)
+    eng.ancestors_from_scan_dev(n, seed, frame, one)
+    assert torch.equal(one, two)
+    if n <= 200_000:
+        wq, total = orc.quantise_weights(logw, np.float32(logw.max()))
+        want = orc.resample(wq, seed, frame)
+        assert np.array_equal(host(one), want)
+    # all weights zero cannot happen with finite log-weights, but -inf everywhere must stay memory-safe
+    if n == 7:
+        eng.logweight_dev(None, dev(np.full(n, -np.inf, np.float32)), 0.0, n, tmp, d_max)
+        eng.quantise_scan_dev(tmp, None, n, None)
+        eng.ancestors_from_scan_dev(n, seed, frame, one)
+        eng.offspring_from_scan_dev(n, None, None, seed, frame, n, first)
+        eng.ancestors_dev(first, n, 0, n, two)
+        assert torch.equal(one, two)
+
+
 def test_rccl_collectives_single_rank(eng, orc, tmp_path):
     """The multi-GPU code path over the real RCCL backend, as far as one GPU allows: a world_size-1 `nccl` group,
     every collective of the frame loop issued for real (all-reduce MAX on float32, all-gather of int64 totals and of
