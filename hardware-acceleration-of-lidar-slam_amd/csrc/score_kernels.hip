@@ -96,10 +96,13 @@ __global__ __launch_bounds__(kScoreBlock) void score_poses_kernel(ScoreGrid g, c
     const float nst = -st;
     const float off_x = (pose_x - g.min_x) * g.ipix;
     const float off_y = (pose_y - g.min_y) * g.ipix;
-    // (int)roundf(v) + 1 > 1  <=>  roundf(v) > 0 ;  ... + 1 < n  <=>  roundf(v) < n - 1  (integers in float)
-    const float lim_x = (float)(g.cols - 1);
-    const float lim_y = (float)(g.rows - 1);
-    const float* __restrict__ edt = g.edt;
+    // The reference's test (int)roundf(v) + 1 > 1 && ... + 1 < n is 1 <= c <= n - 2 on the rounded cell c, i.e.
+    // (unsigned)(c - 1) < n - 2: one subtract and one unsigned compare per axis, no branches.  The conversion
+    // saturates and maps NaN to 0, so far-away and padding (NaN) beams fail the test like they fail the float one.
+    const unsigned lim_x = (unsigned)(g.cols > 2 ? g.cols - 2 : 0);
+    const unsigned lim_y = (unsigned)(g.rows > 2 ? g.rows - 2 : 0);
+    typedef __attribute__((address_space(1))) const char gbytes;   // scalar base + 32-bit lane offset addressing
+    gbytes* edt = (gbytes*)g.edt;
     const int ld = g.ld;
 
     float total = 0.0f;
@@ -108,11 +111,12 @@ __global__ __launch_bounds__(kScoreBlock) void score_poses_kernel(ScoreGrid g, c
         const float2 q = s_beam[b];
         const float rx = (q.x * ct) + (q.y * st);
         const float ry = (q.x * nst) + (q.y * ct);
-        const float fx = round_half_away(rx + off_x);
-        const float fy = round_half_away(ry + off_y);
-        const bool in = (fx > 0.0f) & (fy > 0.0f) & (fx < lim_x) & (fy < lim_y);
-        const int idx = in ? (int)fy * ld + (int)fx : 0;
-        const float h = edt[idx];
+        const int ix = __float2int_rz(round_half_away(rx + off_x));
+        const int iy = __float2int_rz(round_half_away(ry + off_y));
+        const bool in = (unsigned)(ix - 1) < lim_x && (unsigned)(iy - 1) < lim_y;
+        unsigned off = (unsigned)(iy * ld + ix) * 4u;
+        off = in ? off : 0u;
+        const float h = *(__attribute__((address_space(1))) const float*)(edt + off);
         n_in += in ? 1 : 0;
         return in ? h : 0.0f;   // adding +0 leaves the running sum's bits unchanged
     };
