@@ -368,6 +368,11 @@ def main():
                      # the EKF re-reads the rows of repeated ancestors from L2, so its HBM traffic (PMC) is BELOW the
                      # algorithmic 40 B per (particle, landmark); this is the rate at which HBM itself was driven
                      "hbm_traffic_rate_gbs": (traffic / (dur_ms * 1e-3) / 1e9) if traffic and dur_ms > 0 else None,
+                     "note": ("achieved = SURVEY 8(d) algorithmic bytes (40 B per particle and landmark, no reuse assumed) / "
+                              "launch time; rows of repeated resample ancestors are re-read from L2, so the HBM traffic "
+                              "(`traffic`, PMC) is lower and `frac` can exceed 1; --mode ekf is the sweep without sharing"
+                              if kern.startswith("ekf") else
+                              "EDT gathers are served by L2 / Infinity Cache: logical-byte rate, not HBM traffic"),
                      "avg_launch_ms": dur_ms, "avg_event_bracket_ms": raw_ms,
                      "event_bracket_overhead_ms": bracket_overhead_ms,
                      "launches": int(ekf_n if kern.startswith("ekf") else score_n),
