@@ -261,13 +261,22 @@ class ParticleFilter:
             raise RuntimeError(f"rank {r}: {rtot} particles to receive exceed recv_capacity {self.recv_cap}")
         self.migrated_last = rtot
         rows = 3 + 5 * L
-        sbuf = torch.empty(rows * stot, dtype=torch.float32, device=dv)
-        rbuf = torch.empty(rows * rtot, dtype=torch.float32, device=dv)
+        sbuf = self._exchange_buffer("_sbuf", rows * stot)
+        rbuf = self._exchange_buffer("_rbuf", rows * rtot)
         pose = self.pose[self.cur]
         mp = self.map[self.cur] if L else None
         o.migrate_pack(n, r, G, plan, pose, self.cap, mp, 5 * self.Lp, self.Lp, L, sbuf)
         self._all_to_all(rbuf, sbuf, [rows * c for c in rcnt], [rows * c for c in scnt])
         o.migrate_unpack(rbuf, G, rcnt, n, pose, self.cap, mp, 5 * self.Lp, self.Lp, L)
+
+    def _exchange_buffer(self, name, nfloats):
+        """Grow-only device buffer for the all-to-all (no allocator traffic in the frame loop)."""
+        buf = getattr(self, name, None)
+        if buf is None or buf.numel() < nfloats:
+            buf = torch.empty(max(nfloats, 2 * (buf.numel() if buf is not None else 0), 1), dtype=torch.float32,
+                              device=self.device)
+            setattr(self, name, buf)
+        return buf[:nfloats]
 
     # ------------------------------------------------------------------ estimate
     def best_particle(self):
