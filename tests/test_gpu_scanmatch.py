@@ -58,6 +58,9 @@ def test_edt_slam_state(eng, golden, which):
     (300, 517, 0.05, 3.5),          # non-integer cap
     (129, 65, 0.3, 1.0),
     (200, 333, 0.001, 16.0),
+    (150, 260, 0.0008, 31.0),       # widest window the bit-mask search takes (63 bits)
+    (150, 260, 0.0008, 32.0),       # one more: the byte-halo kernel
+    (90, 70, 0.1, 0.5),
     (1, 1, 1.0, 10.0), (1, 500, 0.01, 10.0), (500, 1, 0.01, 10.0),
     (64, 64, 0.0, 10.0),            # no occupied cell at all
 ])
