@@ -88,6 +88,7 @@ SIGNATURES = {
     "slam_comb_offset": (_u64, [_u64, _u32, _u64]),
     "slam_ancestors_from_scan_dev": (_i, [_vp, _i, _u64, C.c_uint32, _vp]),
     "slam_ancestors_sharded_dev": (_i, [_vp, _vp, _i64, _i, _i, _i, _vp, _vp]),
+    "slam_exchange_plan_host": (_i, [_vp, _i, _vp]),
     "slam_migrate_pack_dev": (_i, [_vp, _i, _i, _i, _vp, _vp, _i64, _vp, _i64, _i, _i, _vp]),
     "slam_migrate_unpack_dev": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i64, _vp, _i64, _i, _i]),
     "slam_argmax_dev": (_i, [_vp, _vp, _i, _vp, _vp]),
@@ -352,6 +353,12 @@ class Engine:
         """d_plan: int32[plan_words(world)] on the device: [0] anything moves, send_cnt[world], recv_cnt[world], ..."""
         self._ck(self.lib.slam_ancestors_sharded_dev(self.h, _ptr(d_first_all), n_total, n_local, rank, world,
                                                      _ptr(d_src), _ptr(d_plan)), "ancestors_sharded_dev")
+
+    def exchange_plan_host(self, world):
+        """The plan of the last ancestors_sharded_dev call, delivered through mapped host memory (no copy, no sync)."""
+        plan = np.zeros(plan_words(world), np.int32)
+        self._ck(self.lib.slam_exchange_plan_host(self.h, world, _ptr(plan)), "exchange_plan_host")
+        return plan.tolist()
 
     def migrate_pack_dev(self, n_local, rank, world, plan, d_pose, pose_ld, d_map, row_stride, plane_stride, nlandmarks,
                          d_out):

@@ -125,6 +125,8 @@ int slam_engine_create(int device, slam_engine** out)
         e->fm_work.ensure(sizeof(float) * kLattice * SLAM_MAX_BEAMS) != hipSuccess ||
         hipHostMalloc((void**)&e->h_fm, sizeof(float) * (kFmIn + kFmOut + 4), hipHostMallocMapped) != hipSuccess ||
         hipHostGetDevicePointer((void**)&e->d_hfm, e->h_fm, 0) != hipSuccess ||
+        hipHostMalloc((void**)&e->h_plan, sizeof(int32_t) * (SLAM_PLAN_WORDS(kMaxRanks) + 1), hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer((void**)&e->d_hplan, e->h_plan, 0) != hipSuccess ||
         e->scan_buf.ensure(sizeof(float) * 2 * SLAM_MAX_BEAMS) != hipSuccess ||
         hipHostMalloc((void**)&e->h_stage, sizeof(float) * kStageSlots * kStageFloats, hipHostMallocDefault) !=
             hipSuccess) {
@@ -133,6 +135,7 @@ int slam_engine_create(int device, slam_engine** out)
         return SLAM_ERR_NO_DEVICE;
     }
     memset(e->h_fm, 0, sizeof(float) * (kFmIn + kFmOut + 4));   // arrival flag starts at 0, sequence numbers at 1
+    memset(e->h_plan, 0, sizeof(int32_t) * (SLAM_PLAN_WORDS(kMaxRanks) + 1));
     e->stream = e->own_stream;
     *out = e;
     return SLAM_OK;
@@ -167,6 +170,7 @@ int slam_engine_destroy(slam_engine* e)
             (void)hipEventDestroy(p.stop);
         }
     if (e->h_fm) (void)hipHostFree(e->h_fm);
+    if (e->h_plan) (void)hipHostFree(e->h_plan);
     if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
     delete e;
     return SLAM_OK;
@@ -791,9 +795,31 @@ int slam_ancestors_sharded_dev(slam_engine* e, const int32_t* d_first_all, int64
         n_total != (int64_t)n_local * world || !d_first_all || !d_src || !d_plan)
         return SLAM_ERR_INVALID_ARG;
     HIP_TRY(e->shard_buf.ensure(sizeof(int32_t) * (size_t)shard_scan_words(n_local)));
+    const uint32_t seq = ++e->plan_seq;
     HIP_TRY(launch_ancestors_sharded(e->stream, d_first_all, n_total, n_local, rank, world, e->shard_buf.as<int32_t>(),
-                                     d_plan, d_src));
+                                     d_plan, d_src, e->d_hplan,
+                                     reinterpret_cast<uint32_t*>(e->d_hplan + SLAM_PLAN_WORDS(kMaxRanks)), seq));
     e->shard_n = n_local;   // what slam_migrate_pack_dev will read
+    e->plan_world = world;
+    return SLAM_OK;
+}
+
+int slam_exchange_plan_host(slam_engine* e, int world, int32_t* plan)
+{
+    ENTER(e);
+    if (!plan || world < 1 || world > kMaxRanks) return SLAM_ERR_INVALID_ARG;
+    if (e->plan_seq == 0 || e->plan_world != world) return SLAM_ERR_NOT_READY;
+    volatile uint32_t* h_flag = reinterpret_cast<volatile uint32_t*>(e->h_plan + SLAM_PLAN_WORDS(kMaxRanks));
+    const uint32_t seq = e->plan_seq;
+    bool arrived = false;
+    for (long spin = 0; spin < 400000000L; ++spin) {   // bounded: a few seconds at most
+        if (__atomic_load_n(h_flag, __ATOMIC_ACQUIRE) == seq) { arrived = true; break; }
+    }
+    if (!arrived) {   // the launch failed or the device is wedged: let the runtime tell us
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        if (__atomic_load_n(h_flag, __ATOMIC_ACQUIRE) != seq) return fail_hip(e, hipErrorUnknown, "exchange plan flag");
+    }
+    memcpy(plan, e->h_plan, sizeof(int32_t) * (size_t)SLAM_PLAN_WORDS(world));
     return SLAM_OK;
 }
 

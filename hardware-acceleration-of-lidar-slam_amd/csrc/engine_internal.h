@@ -77,6 +77,10 @@ struct slam_engine {
     float* h_fm = nullptr;     // pinned + mapped: lattice candidates in, results out, then one uint32 arrival flag
     float* d_hfm = nullptr;    // the same memory as the device sees it (zero-copy FastMatch I/O)
     uint32_t fm_seq = 0;
+    int32_t* h_plan = nullptr;   // pinned + mapped: exchange plan of the last slam_ancestors_sharded_dev, then one arrival flag
+    int32_t* d_hplan = nullptr;
+    uint32_t plan_seq = 0;
+    int plan_world = 0;
     DevBuf scratch;            // per-call temporaries of the *_dev stages
     DevBuf bmax_buf;           // block maxima left by slam_logweight_dev (read by slam_quantise_scan_dev)
     int bmax_count = 0, bmax_n = -1;

@@ -757,7 +757,9 @@ __device__ __forceinline__ int32_t shard_prefix(const int32_t* __restrict__ pfx,
 __global__ __launch_bounds__(kBlock) void shard_plan_kernel(const int32_t* __restrict__ first_all, int64_t n_total, int n,
                                                             int rank, int world, const int32_t* __restrict__ pfx,
                                                             int32_t* __restrict__ boff, int ntiles,
-                                                            int32_t* __restrict__ plan, int32_t* __restrict__ rplan)
+                                                            int32_t* __restrict__ plan, int32_t* __restrict__ rplan,
+                                                            int32_t* __restrict__ host_plan,
+                                                            uint32_t* __restrict__ host_flag, uint32_t seq)
 {
     __shared__ int32_t s_part[kBlock];
     for (int y = 0; y < 2; ++y) {   // exclusive scan of the tile totals, kBlock-sized chunks with a running carry
@@ -812,8 +814,18 @@ __global__ __launch_bounds__(kBlock) void shard_plan_kernel(const int32_t* __res
         plan[1 + q] = scnt;
         plan[1 + world + q] = rcnt;
         plan[1 + 2 * world + q] = sbase;
+        if (host_plan) {
+            host_plan[1 + q] = scnt;
+            host_plan[1 + world + q] = rcnt;
+            host_plan[1 + 2 * world + q] = sbase;
+        }
     }
     plan[0] = anything;
+    if (host_plan) {   // zero-copy delivery: the host polls the flag instead of a device-to-host copy + stream sync
+        host_plan[0] = anything;
+        __threadfence_system();
+        __hip_atomic_store(host_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 // src[jl]: where slot r*n + jl finds its ancestor — a local particle index, or n + its row in the staging tail
@@ -1060,7 +1072,8 @@ int shard_scan_words(int n) { const int t = (n + kShardTile - 1) / kShardTile; r
 
 // scratch (int32 words, shard_scan_words(n)): gsrc[n] | pfx[2][n] | boff[2][ntiles] | rplan[2*kMaxRanks]
 hipError_t launch_ancestors_sharded(hipStream_t stream, const int32_t* first_all, int64_t n_total, int n, int rank,
-                                    int world, int32_t* scratch, int32_t* plan, int32_t* src)
+                                    int world, int32_t* scratch, int32_t* plan, int32_t* src, int32_t* host_plan,
+                                    uint32_t* host_flag, uint32_t seq)
 {
     if (n <= 0) return hipSuccess;
     const int ntiles = (n + kShardTile - 1) / kShardTile;
@@ -1069,7 +1082,8 @@ hipError_t launch_ancestors_sharded(hipStream_t stream, const int32_t* first_all
     int32_t* boff = pfx + 2 * (int64_t)n;
     int32_t* rplan = boff + 2 * ntiles;
     shard_flag_scan_kernel<<<dim3(ntiles, 2), kBlock, 0, stream>>>(first_all, n_total, n, rank, gsrc, pfx, boff, ntiles);
-    shard_plan_kernel<<<1, kBlock, 0, stream>>>(first_all, n_total, n, rank, world, pfx, boff, ntiles, plan, rplan);
+    shard_plan_kernel<<<1, kBlock, 0, stream>>>(first_all, n_total, n, rank, world, pfx, boff, ntiles, plan, rplan,
+                                                host_plan, host_flag, seq);
     ancestors_sharded_kernel<<<blocks_for(n), kBlock, 0, stream>>>(gsrc, pfx, boff, ntiles, rplan, n, rank, world, src);
     return hipGetLastError();
 }

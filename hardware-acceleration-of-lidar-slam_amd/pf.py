@@ -87,6 +87,9 @@ class HipOps:
     def ancestors_sharded(self, first_all, n_total, n_local, rank, world, src, plan):
         self.e.ancestors_sharded_dev(first_all, n_total, n_local, rank, world, src, plan)
 
+    def read_plan(self, d_plan, world):
+        return self.e.exchange_plan_host(world)   # zero-copy: the plan kernel wrote it to mapped host memory
+
     def migrate_pack(self, n_local, rank, world, plan, pose, pose_ld, mp, row_stride, plane_stride, nlandmarks, out):
         self.e.migrate_pack_dev(n_local, rank, world, plan, pose, pose_ld, mp, row_stride, plane_stride, nlandmarks, out)
 
@@ -251,7 +254,7 @@ class ParticleFilter:
         staging tail of the current buffers, where the next frame's fused gathers pick them up.  A remote ancestor
         travels once per destination rank, however many slots there descend from it."""
         o, n, r, G, dv, L = self.ops, self.n, self.rank, self.world, self.device, self.L
-        plan = self.plan.cpu().tolist()   # the one device->host sync of a frame
+        plan = o.read_plan(self.plan, G)   # the one point of a frame where the host waits for the device
         anything, scnt, rcnt = plan[0], plan[1:1 + G], plan[1 + G:1 + 2 * G]
         if not anything and self.world > 1:   # every run boundary coincides with a rank boundary: all ranks skip
             self.migrated_last = 0

@@ -280,6 +280,10 @@ uint64_t slam_comb_offset(uint64_t seed, uint32_t frame, uint64_t total);
 #define SLAM_PLAN_WORDS(world) (1 + 3 * (world))
 int slam_ancestors_sharded_dev(slam_engine *e, const int32_t *d_first_all, int64_t n_total, int n_local, int rank,
                                int world, int32_t *d_src, int32_t *d_plan);
+/* The plan of the last slam_ancestors_sharded_dev call on this engine, on the host: the plan kernel also writes it to
+ * pinned host memory mapped into the device and releases an arrival flag; this call waits for that flag (no
+ * device-to-host copy, no stream synchronisation) and copies the SLAM_PLAN_WORDS(world) words out. */
+int slam_exchange_plan_host(slam_engine *e, int world, int32_t *plan);
 int slam_migrate_pack_dev(slam_engine *e, int n_local, int rank, int world, const int32_t *plan, const float *d_pose,
                           int64_t pose_ld, const float *d_map, int64_t row_stride, int plane_stride, int nlandmarks,
                           float *d_out);

@@ -136,6 +136,9 @@ class OracleOps:
         src[:n] = torch.from_numpy(out.astype(np.int32))
         plan[:] = torch.from_numpy(out_plan)
 
+    def read_plan(self, d_plan, world):
+        return d_plan.tolist()
+
     def migrate_pack(self, n_local, rank, world, plan, pose, pose_ld, mp, row_stride, plane_stride, nlandmarks, out):
         rec, off = 3 + 5 * nlandmarks, 0
         for d in range(world):

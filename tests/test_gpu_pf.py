@@ -364,6 +364,7 @@ def test_exchange_plan_index_and_pack_vs_numpy(eng, orc, n, world, skew):
         plan_g = torch.zeros(1 + 3 * world, dtype=torch.int32, device=DEV)
         gpu.ancestors_sharded(dev(first), n_total, n, rank, world, src_g, plan_g)
         assert np.array_equal(host(plan_g), plan_c.numpy())
+        assert gpu.read_plan(plan_g, world) == plan_c.tolist()     # the same plan through mapped host memory
         assert np.array_equal(host(src_g), src_c.numpy())
         plan = plan_c.tolist()
         stot = sum(plan[1:1 + world])
