@@ -178,6 +178,9 @@ def main():
                     help="kernels bracketed by HIP events inside the timed region (a pair costs a few us of stream time)")
     ap.add_argument("--observed", type=int, default=0,
                     help="landmarks seen per frame: 0 = all (default, the roofline workload), K = the K nearest")
+    ap.add_argument("--force-collectives", action="store_true",
+                    help="diagnostics, --gpus 1 only: run the multi-GPU code path (every RCCL collective, the sharded index "
+                         "kernels, the plan read-back) on a one-rank group to price its control overhead")
     ap.add_argument("--stats", action="store_true",
                     help="diagnostics: print the number of distinct resample ancestors per frame (synchronises; not for timing)")
     args = ap.parse_args()
@@ -204,6 +207,10 @@ def main():
     dev_index = local_rank if args.device_index is None else args.device_index
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    if world == 1 and args.force_collectives:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group(args.dist_backend, rank=0, world_size=1, **({"device_id": dev} if args.dist_backend == "nccl" else {}))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.dist_backend == "nccl":
@@ -233,7 +240,8 @@ def main():
 
     n = args.particles
     pf = ParticleFilter(ops, n, L, device=dev, rank=rank, world=world, seed=1234, sigma=args.sigma,
-                        meas_var=args.meas_var, score_gain=args.score_gain, grid_slot=0)
+                        meas_var=args.meas_var, score_gain=args.score_gain, grid_slot=0,
+                        force_collectives=args.force_collectives and world == 1)
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
     p0 = true_pose(0)
     pf.set_poses(p0[0] + 0.05 * torch.randn(n, generator=g), p0[1] + 0.05 * torch.randn(n, generator=g),
@@ -361,7 +369,7 @@ def main():
                                 "score": "scan-match score only", "ekf": "EKF sweep only"}[args.mode],
                    "mode": args.mode, "particles_per_gpu": n, "particles_total": n_total, "beams": args.beams,
                    "landmarks": L, "landmarks_observed_per_frame": (args.observed if 0 < args.observed < L else L),
-                   "edt_grid": f"{args.grid}x{args.grid}", "parallelism": f"particle-shard x{world}",
+                   "edt_grid": f"{args.grid}x{args.grid}", "parallelism": f"particle-shard x{world}" + (" (multi-GPU code path forced)" if args.force_collectives else ""),
                    "rows_received_per_frame_max_rank": migrated if world > 1 else 0},
         "roofline": {"bound": "hbm", "kernel": kern, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": alg,
@@ -385,7 +393,7 @@ def main():
         out["cpu_baseline"] = None
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or (world == 1 and args.force_collectives):
         dist.destroy_process_group()
     eng.close()
 

@@ -710,22 +710,47 @@ __global__ __launch_bounds__(kBlock) void shard_flag_scan_kernel(const int32_t* 
     const int base = blockIdx.x * kShardTile + threadIdx.x * kShardItems;
     int32_t f[kShardItems];
     int32_t run = 0;
+    if (y == 0) {
+        // the thread's kShardItems binary searches advance in lock step, so that their loads are in flight together
+        // (one search after the other is kShardItems x 17 dependent L2 round trips: 20 us for this kernel)
+        int64_t lo[kShardItems], hi[kShardItems];
 #pragma unroll
-    for (int k = 0; k < kShardItems; ++k) {
-        const int idx = base + k;
-        int32_t flag = 0;
-        if (idx < n) {
-            const int64_t j = my_lo + idx;
-            if (y == 0) {
-                const int64_t g = last_with_first_le(first_all, n_total, j);
+        for (int k = 0; k < kShardItems; ++k) { lo[k] = 0; hi[k] = base + k < n ? n_total : 0; }
+        for (int step = 0; step < 64; ++step) {
+            bool any = false;
+#pragma unroll
+            for (int k = 0; k < kShardItems; ++k)
+                if (lo[k] < hi[k]) {
+                    const int64_t mid = (lo[k] + hi[k]) >> 1;
+                    if ((int64_t)first_all[mid] <= my_lo + base + k) lo[k] = mid + 1; else hi[k] = mid;
+                    any = true;
+                }
+            if (!any) break;
+        }
+#pragma unroll
+        for (int k = 0; k < kShardItems; ++k) {
+            const int idx = base + k;
+            int32_t flag = 0;
+            if (idx < n) {
+                const int64_t g = lo[k] - 1;   // last index whose first slot is <= j
                 gsrc[idx] = (int32_t)g;
-                flag = (idx == 0 || (int64_t)first_all[g] == j) ? 1 : 0;
-            } else {
+                flag = (idx == 0 || (int64_t)first_all[g] == my_lo + idx) ? 1 : 0;
+            }
+            run += flag;
+            f[k] = run;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < kShardItems; ++k) {
+            const int idx = base + k;
+            int32_t flag = 0;
+            if (idx < n) {
+                const int64_t j = my_lo + idx;
                 flag = first_or_total(first_all, j + 1, n_total) > (int64_t)first_all[j] ? 1 : 0;
             }
+            run += flag;
+            f[k] = run;   // inclusive within the thread
         }
-        run += flag;
-        f[k] = run;   // inclusive within the thread
     }
     // exclusive offset of this thread inside the tile: wave scan + wave totals through LDS
     int32_t incl = run;
