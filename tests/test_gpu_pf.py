@@ -111,6 +111,46 @@ def test_ekf_update(eng, orc, n, L, Lp, nobs, with_anc):
     assert np.array_equal(bits(host(ll)), bits(wl))
 
 
+def test_ekf_update_randomised_shapes(eng, orc):
+    """40 seeded random cases of the EKF update against the CPU specification: particle counts around the workgroup
+    size, landmark counts around the 128-landmark batches, plane strides from tight to generous (so that the
+    unpredicated, the tail and the mixed paths all occur), observation fractions from none to all, unseen
+    landmarks, with and without the fused gather, in place and out of place."""
+    import ctypes as C
+    rng = np.random.default_rng(20261004)
+    for case in range(40):
+        n = int(rng.choice([1, 3, 4, 5, 63, 64, 65, 255, 257, 1000]))
+        L = int(rng.choice([1, 2, 63, 64, 65, 127, 128, 129, 255, 256, 257, 300, 511, 513]))
+        Lp = L + int(rng.choice([0, 1, 5, 31, 127, 200]))
+        in_place = bool(rng.random() < 0.25)
+        with_anc = (not in_place) and bool(rng.random() < 0.6)
+        rows = n + (int(rng.integers(0, 50)) if with_anc else 0)
+        mp = _rand_map(rng, L, rows, Lp)
+        x, y, th = (rng.normal(0, 1, n).astype(np.float32) for _ in range(3))
+        anc = np.sort(rng.integers(0, rows, n)).astype(np.int32) if with_anc else None
+        nobs = int(rng.choice([0, 1, L // 3, L]))
+        ids = rng.permutation(L)[:nobs].astype(np.int32)
+        zx, zy = rng.normal(0, 2, nobs).astype(np.float32), rng.normal(0, 2, nobs).astype(np.float32)
+        eng.obs_upload(ids, zx, zy, L)
+        d_in = dev(mp)
+        d_out = d_in if in_place else torch.full((rows, 5, Lp), -777.0, device=DEV)
+        ll = torch.empty(n, device=DEV)
+        eng.ekf_update_dev(d_in, d_out, 5 * Lp, Lp, L, dev(x), dev(y), dev(th), dev(anc) if with_anc else None, n, 0.015, ll)
+        want = mp.copy() if in_place else np.full((rows, 5, Lp), -777.0, np.float32)
+        wl = np.empty(n, np.float32)
+        src = want if in_place else mp
+        orc.lib().orc_ekf_update(src, want, 5 * Lp, Lp, L, x, y, th, anc.ctypes.data_as(C.c_void_p) if with_anc else None, n,
+                                 ids, zx, zy, nobs, 0.015, wl)
+        got = host(d_out)
+        tag = f"case {case}: n={n} L={L} Lp={Lp} nobs={nobs} anc={with_anc} in_place={in_place}"
+        assert np.array_equal(bits(got[:n, :, :L]), bits(want[:n, :, :L])), tag
+        assert np.array_equal(bits(host(ll)), bits(wl)), tag
+        if not in_place:
+            assert np.all(got[n:] == -777.0), tag
+        else:
+            assert np.array_equal(bits(got[:, :, L:]), bits(mp[:, :, L:])), tag    # in place never touches the padding
+
+
 def test_ekf_in_place_and_argument_checks(eng, orc):
     pkg = load_package()
     rng = np.random.default_rng(2)
