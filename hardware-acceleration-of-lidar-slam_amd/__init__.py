@@ -87,7 +87,7 @@ SIGNATURES = {
     "slam_ancestors_dev": (_i, [_vp, _vp, _i64, _i64, _i, _vp]),
     "slam_comb_offset": (_u64, [_u64, _u32, _u64]),
     "slam_ancestors_from_scan_dev": (_i, [_vp, _i, _u64, C.c_uint32, _vp]),
-    "slam_ancestors_sharded_dev": (_i, [_vp, _vp, _i64, _i, _i, _i, _vp, _vp]),
+    "slam_ancestors_sharded_dev": (_i, [_vp, _vp, _i64, _i, _i, _i, _vp, _vp, _vp]),
     "slam_exchange_plan_host": (_i, [_vp, _i, _vp]),
     "slam_migrate_pack_dev": (_i, [_vp, _i, _i, _i, _vp, _vp, _i64, _vp, _i64, _i, _i, _vp]),
     "slam_migrate_unpack_dev": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i64, _vp, _i64, _i, _i]),
@@ -349,10 +349,11 @@ class Engine:
     def ancestors_from_scan_dev(self, n, seed, frame, d_anc):
         self._ck(self.lib.slam_ancestors_from_scan_dev(self.h, n, seed, frame, _ptr(d_anc)), "ancestors_from_scan_dev")
 
-    def ancestors_sharded_dev(self, d_first_all, n_total, n_local, rank, world, d_src, d_plan):
-        """d_plan: int32[plan_words(world)] on the device: [0] anything moves, send_cnt[world], recv_cnt[world], ..."""
+    def ancestors_sharded_dev(self, d_first_all, n_total, n_local, rank, world, d_src, d_plan, d_pose_idx=None):
+        """d_plan: int32[plan_words(world)] on the device: [0] anything moves, send_cnt[world], recv_cnt[world], ...
+        d_pose_idx (optional): ancestor's position in an all-gather of the ranks' [x | y | theta] pose blocks."""
         self._ck(self.lib.slam_ancestors_sharded_dev(self.h, _ptr(d_first_all), n_total, n_local, rank, world,
-                                                     _ptr(d_src), _ptr(d_plan)), "ancestors_sharded_dev")
+                                                     _ptr(d_src), _ptr(d_plan), _ptr(d_pose_idx)), "ancestors_sharded_dev")
 
     def exchange_plan_host(self, world):
         """The plan of the last ancestors_sharded_dev call, delivered through mapped host memory (no copy, no sync)."""

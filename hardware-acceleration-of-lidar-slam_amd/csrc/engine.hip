@@ -788,16 +788,17 @@ static bool make_plan(MigratePlan& plan, const int64_t* lo, const int32_t* cnt, 
 }
 
 int slam_ancestors_sharded_dev(slam_engine* e, const int32_t* d_first_all, int64_t n_total, int n_local, int rank,
-                               int world, int32_t* d_src, int32_t* d_plan)
+                               int world, int32_t* d_src, int32_t* d_plan, int32_t* d_pose_idx)
 {
     ENTER(e);
     if (n_local <= 0 || world < 1 || world > kMaxRanks || rank < 0 || rank >= world ||
-        n_total != (int64_t)n_local * world || !d_first_all || !d_src || !d_plan)
+        n_total != (int64_t)n_local * world || !d_first_all || !d_src || !d_plan ||
+        (d_pose_idx && 3 * n_total > 0x7fffffff))
         return SLAM_ERR_INVALID_ARG;
     HIP_TRY(e->shard_buf.ensure(sizeof(int32_t) * (size_t)shard_scan_words(n_local)));
     const uint32_t seq = ++e->plan_seq;
     HIP_TRY(launch_ancestors_sharded(e->stream, d_first_all, n_total, n_local, rank, world, e->shard_buf.as<int32_t>(),
-                                     d_plan, d_src, e->d_hplan,
+                                     d_plan, d_src, d_pose_idx, e->d_hplan,
                                      reinterpret_cast<uint32_t*>(e->d_hplan + SLAM_PLAN_WORDS(kMaxRanks)), seq));
     e->shard_n = n_local;   // what slam_migrate_pack_dev will read
     e->plan_world = world;

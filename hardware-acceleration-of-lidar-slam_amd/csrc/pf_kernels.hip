@@ -698,9 +698,17 @@ __device__ __forceinline__ int64_t last_with_first_le(const int32_t* __restrict_
 constexpr int kShardTile = 2048;                       // elements per workgroup in the flag scan
 constexpr int kShardItems = kShardTile / kBlock;       // per thread
 
-// y = 0: head flags of my slots (also stores each slot's global ancestor);  y = 1: "has offspring" flags of my particles
+// global ancestor of each of my slots: one thread per slot
+__global__ __launch_bounds__(kBlock) void shard_search_kernel(const int32_t* __restrict__ first_all, int64_t n_total, int n,
+                                                              int rank, int32_t* __restrict__ gsrc)
+{
+    const int jl = blockIdx.x * kBlock + threadIdx.x;
+    if (jl < n) gsrc[jl] = (int32_t)last_with_first_le(first_all, n_total, (int64_t)rank * n + jl);
+}
+
+// y = 0: head flags of my slots;  y = 1: "has offspring" flags of my particles
 __global__ __launch_bounds__(kBlock) void shard_flag_scan_kernel(const int32_t* __restrict__ first_all, int64_t n_total,
-                                                                 int n, int rank, int32_t* __restrict__ gsrc,
+                                                                 int n, int rank, const int32_t* __restrict__ gsrc,
                                                                  int32_t* __restrict__ pfx, int32_t* __restrict__ btot,
                                                                  int ntiles)
 {
@@ -711,29 +719,14 @@ __global__ __launch_bounds__(kBlock) void shard_flag_scan_kernel(const int32_t* 
     int32_t f[kShardItems];
     int32_t run = 0;
     if (y == 0) {
-        // the thread's kShardItems binary searches advance in lock step, so that their loads are in flight together
-        // (one search after the other is kShardItems x 17 dependent L2 round trips: 20 us for this kernel)
-        int64_t lo[kShardItems], hi[kShardItems];
-#pragma unroll
-        for (int k = 0; k < kShardItems; ++k) { lo[k] = 0; hi[k] = base + k < n ? n_total : 0; }
-        for (int step = 0; step < 64; ++step) {
-            bool any = false;
-#pragma unroll
-            for (int k = 0; k < kShardItems; ++k)
-                if (lo[k] < hi[k]) {
-                    const int64_t mid = (lo[k] + hi[k]) >> 1;
-                    if ((int64_t)first_all[mid] <= my_lo + base + k) lo[k] = mid + 1; else hi[k] = mid;
-                    any = true;
-                }
-            if (!any) break;
-        }
+        // the ancestors were found by shard_search_kernel, one thread per slot (a thread doing its kShardItems
+        // searches itself is 136 dependent L2 round trips: 20 us for this kernel instead of 5 + 5)
 #pragma unroll
         for (int k = 0; k < kShardItems; ++k) {
             const int idx = base + k;
             int32_t flag = 0;
             if (idx < n) {
-                const int64_t g = lo[k] - 1;   // last index whose first slot is <= j
-                gsrc[idx] = (int32_t)g;
+                const int64_t g = gsrc[idx];
                 flag = (idx == 0 || (int64_t)first_all[g] == my_lo + idx) ? 1 : 0;
             }
             run += flag;
@@ -858,12 +851,15 @@ __global__ __launch_bounds__(kBlock) void ancestors_sharded_kernel(const int32_t
                                                                    const int32_t* __restrict__ pfx,
                                                                    const int32_t* __restrict__ boff, int ntiles,
                                                                    const int32_t* __restrict__ rplan, int n, int rank,
-                                                                   int world, int32_t* __restrict__ src)
+                                                                   int world, int32_t* __restrict__ src,
+                                                                   int32_t* __restrict__ pose_idx)
 {
     const int jl = blockIdx.x * kBlock + threadIdx.x;
     if (jl >= n) return;
     const int32_t g = gsrc[jl];
     const int owner = g / n;
+    // where the ancestor's pose sits in an all-gather of the ranks' [x | y | theta] blocks (3 n floats per rank)
+    if (pose_idx) pose_idx[jl] = owner * 3 * n + (g - owner * n);
     src[jl] = owner == rank ? g - rank * n
                             : n + rplan[owner] + (shard_prefix(pfx, boff, 0, n, ntiles, jl) - rplan[world + owner]);
 }
@@ -1097,8 +1093,8 @@ int shard_scan_words(int n) { const int t = (n + kShardTile - 1) / kShardTile; r
 
 // scratch (int32 words, shard_scan_words(n)): gsrc[n] | pfx[2][n] | boff[2][ntiles] | rplan[2*kMaxRanks]
 hipError_t launch_ancestors_sharded(hipStream_t stream, const int32_t* first_all, int64_t n_total, int n, int rank,
-                                    int world, int32_t* scratch, int32_t* plan, int32_t* src, int32_t* host_plan,
-                                    uint32_t* host_flag, uint32_t seq)
+                                    int world, int32_t* scratch, int32_t* plan, int32_t* src, int32_t* pose_idx,
+                                    int32_t* host_plan, uint32_t* host_flag, uint32_t seq)
 {
     if (n <= 0) return hipSuccess;
     const int ntiles = (n + kShardTile - 1) / kShardTile;
@@ -1106,10 +1102,12 @@ hipError_t launch_ancestors_sharded(hipStream_t stream, const int32_t* first_all
     int32_t* pfx = gsrc + n;
     int32_t* boff = pfx + 2 * (int64_t)n;
     int32_t* rplan = boff + 2 * ntiles;
+    shard_search_kernel<<<blocks_for(n), kBlock, 0, stream>>>(first_all, n_total, n, rank, gsrc);
     shard_flag_scan_kernel<<<dim3(ntiles, 2), kBlock, 0, stream>>>(first_all, n_total, n, rank, gsrc, pfx, boff, ntiles);
     shard_plan_kernel<<<1, kBlock, 0, stream>>>(first_all, n_total, n, rank, world, pfx, boff, ntiles, plan, rplan,
                                                 host_plan, host_flag, seq);
-    ancestors_sharded_kernel<<<blocks_for(n), kBlock, 0, stream>>>(gsrc, pfx, boff, ntiles, rplan, n, rank, world, src);
+    ancestors_sharded_kernel<<<blocks_for(n), kBlock, 0, stream>>>(gsrc, pfx, boff, ntiles, rplan, n, rank, world, src,
+                                                                   pose_idx);
     return hipGetLastError();
 }
 

@@ -84,8 +84,8 @@ class HipOps:
     def ancestors_from_scan(self, n, seed, frame, anc):
         self.e.ancestors_from_scan_dev(n, seed, frame, anc)
 
-    def ancestors_sharded(self, first_all, n_total, n_local, rank, world, src, plan):
-        self.e.ancestors_sharded_dev(first_all, n_total, n_local, rank, world, src, plan)
+    def ancestors_sharded(self, first_all, n_total, n_local, rank, world, src, plan, pose_idx=None):
+        self.e.ancestors_sharded_dev(first_all, n_total, n_local, rank, world, src, plan, pose_idx)
 
     def read_plan(self, d_plan, world):
         return self.e.exchange_plan_host(world)   # zero-copy: the plan kernel wrote it to mapped host memory
@@ -125,7 +125,7 @@ class ParticleFilter:
         self.cap = self.n + self.recv_cap
         dv = self.device
         f32, i32, i64 = torch.float32, torch.int32, torch.int64
-        self.pose = torch.zeros((2, 3, self.cap), dtype=f32, device=dv)         # [buffer][x,y,theta][particle]
+        self.pose = torch.zeros((2, 3, self.n), dtype=f32, device=dv)           # [buffer][x,y,theta][particle]
         # landmark maps: one row per particle, [buffer][particle][plane][Lp]; planes padded to 32 floats so that
         # every row starts on a 128-byte boundary (include/slam_hip.h, slam_ekf_update_dev)
         self.Lp = (self.L + 31) // 32 * 32
@@ -143,6 +143,13 @@ class ParticleFilter:
         self.d_sum = torch.zeros(1, dtype=i64, device=dv)
         self.totals = torch.zeros(world, dtype=i64, device=dv)
         self.plan = torch.zeros(1 + 3 * world, dtype=i32, device=dv)         # exchange plan of the frame (slam_hip.h)
+        # several GPUs: the poses of every rank are all-gathered each frame (12 B per particle, overlapped with the
+        # EKF), so that the next frame's motion + score launch does not have to wait for the exchange of map rows
+        self.pose_all = torch.zeros(3 * self.n_total, dtype=f32, device=dv) if self.multi else None   # [rank][x|y|th][n]
+        self.pose_stage = torch.zeros((3, self.cap), dtype=f32, device=dv) if self.multi else None    # unpack target
+        self.pose_idx = torch.zeros((2, self.n), dtype=i32, device=dv) if self.multi else None
+        self._pose_work = None           # async all-gather of the poses in flight
+        self._exchange_pending = False   # resample done, map rows not exchanged yet
         self.frame = 0
         self.migrated_last = 0
         # gloo cannot move GPU tensors for every collective used here: stage them through the host then
@@ -160,13 +167,13 @@ class ParticleFilter:
         else:
             dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
 
-    def _all_gather(self, out, t):
+    def _all_gather(self, out, t, async_op=False):
         if self._host_staged:
             h = torch.empty(out.shape, dtype=out.dtype)
             dist.all_gather_into_tensor(h, t.cpu(), group=self.group)
             out.copy_(h)
-        else:
-            dist.all_gather_into_tensor(out, t, group=self.group)
+            return None
+        return dist.all_gather_into_tensor(out, t, group=self.group, async_op=async_op)
 
     def _all_to_all(self, out, inp, out_splits, in_splits):
         if self._host_staged:
@@ -188,12 +195,22 @@ class ParticleFilter:
         self.src_idx = None
 
     def poses(self):
-        """Current particle poses [3][n_local] with any pending resample gather applied."""
+        """Current particle poses [3][n_local] with any pending resample gather applied.  (Several GPUs: this and
+        maps() may finish a pending exchange, a collective — call them on every rank or on none.)"""
         p = self.pose[self.cur]
-        return p[:, : self.n] if self.src_idx is None else p[:, self.src_idx.long()]
+        if self.src_idx is None:
+            return p
+        if not self.multi:
+            return p[:, self.src_idx.long()]
+        if self._pose_work is not None:   # the ancestors' poses are in the all-gathered array
+            self._pose_work.wait()
+            self._pose_work = None
+        idx, n = self.pose_idx[self.cur].long(), self.n
+        return torch.stack([self.pose_all[idx], self.pose_all[n + idx], self.pose_all[2 * n + idx]])
 
     def maps(self):
         """Current maps [n_local][5][L] with any pending resample gather applied."""
+        self._finish_exchange()
         m = self.map[self.cur][:, :, : self.L]
         return m[: self.n] if self.src_idx is None else m[self.src_idx.long()]
 
@@ -205,9 +222,26 @@ class ParticleFilter:
         the observation of landmark l, NaN in zx = not observed this frame."""
         o, n, cur, nxt = self.ops, self.n, self.cur, 1 - self.cur
         src, dst = self.pose[cur], self.pose[nxt]
-        # 1+2. motion (+ fused gather of the previous resample) and scan-match score, one launch
-        o.motion_score(self.grid_slot, (src[0], src[1], src[2]), self.src_idx, (dst[0], dst[1], dst[2]), n,
-                       self.rank * n, dp, self.sigma, self.seed, self.frame, self.score, self.count)
+        multi = self.multi
+        # 1+2. motion (+ fused gather of the previous resample) and scan-match score, one launch.  Several GPUs: the
+        # ancestors' poses come out of the all-gathered pose array, so this launch needs nothing from the exchange
+        # below and keeps the GPU busy while the host picks up the exchange plan.
+        if multi and self.src_idx is not None:
+            if self._pose_work is not None:
+                self._pose_work.wait()
+                self._pose_work = None
+            pa = self.pose_all
+            o.motion_score(self.grid_slot, (pa, pa[n:], pa[2 * n:]), self.pose_idx[cur], (dst[0], dst[1], dst[2]), n,
+                           self.rank * n, dp, self.sigma, self.seed, self.frame, self.score, self.count)
+        else:
+            o.motion_score(self.grid_slot, (src[0], src[1], src[2]), self.src_idx, (dst[0], dst[1], dst[2]), n,
+                           self.rank * n, dp, self.sigma, self.seed, self.frame, self.score, self.count)
+        if multi:
+            # this frame's poses to every rank for the next frame's motion + score: starts when the launch above is done
+            # and runs on RCCL's stream beside the EKF (issued after the EKF it would start 160 us later and, with real
+            # inter-GPU latency, risk holding up the next frame)
+            self._pose_work = self._all_gather(self.pose_all, dst.reshape(-1), async_op=True)
+            self._finish_exchange()   # map rows of remote ancestors -> staging tail, behind the launch above
         # 3. per-landmark EKF (+ fused gather); the log-likelihood stays inside the engine for step 4
         use_ll = self.L > 0 and (obs is not None or obs_dev is not None)
         if use_ll:
@@ -221,7 +255,6 @@ class ParticleFilter:
             idx = self.src_idx if self.src_idx is not None else torch.arange(n, dtype=torch.int32, device=self.device)
             o.gather_map(self.map[cur], self.map[nxt], 5 * self.Lp, 5 * self.Lp, self.Lp, self.Lp, self.L, idx, n)
         # 4. weights (fused form: the fixed-point weights are scanned as they are produced, never stored)
-        multi = self.multi
         if use_ll:
             o.logweight_ekf(self.score, self.score_gain, n, self.logw, self.d_max if multi else None)
         else:
@@ -243,12 +276,17 @@ class ParticleFilter:
             # 6. particles whose ancestor lives on another GPU.  The gather index and the exchange plan are made on
             # the device; the host reads the plan once (3 * world + 1 words) for the all-to-all's split sizes.
             self._all_gather(self.first_all, self.first)
-            o.ancestors_sharded(self.first_all, self.n_total, n, self.rank, self.world, anc, self.plan)
-            self._migrate()
+            o.ancestors_sharded(self.first_all, self.n_total, n, self.rank, self.world, anc, self.plan, self.pose_idx[nxt])
+            self._exchange_pending = True   # done at the start of the next frame, behind its motion + score launch
         self.src_idx = anc
         self.frame += 1
 
     # ------------------------------------------------------------------ multi-GPU exchange
+    def _finish_exchange(self):
+        if self._exchange_pending:
+            self._exchange_pending = False
+            self._migrate()
+
     def _migrate(self):
         """pack (one launch) -> one all-to-all carrying poses and map rows -> unpack (one launch) into the
         staging tail of the current buffers, where the next frame's fused gathers pick them up.  A remote ancestor
@@ -268,9 +306,11 @@ class ParticleFilter:
         rbuf = self._exchange_buffer("_rbuf", rows * rtot)
         pose = self.pose[self.cur]
         mp = self.map[self.cur] if L else None
-        o.migrate_pack(n, r, G, plan, pose, self.cap, mp, 5 * self.Lp, self.Lp, L, sbuf)
+        o.migrate_pack(n, r, G, plan, pose, n, mp, 5 * self.Lp, self.Lp, L, sbuf)
         self._all_to_all(rbuf, sbuf, [rows * c for c in rcnt], [rows * c for c in scnt])
-        o.migrate_unpack(rbuf, G, rcnt, n, pose, self.cap, mp, 5 * self.Lp, self.Lp, L)
+        # the records carry the poses too; nothing reads them from here (the next frame takes poses from the
+        # all-gathered array), they land in a scratch staging area
+        o.migrate_unpack(rbuf, G, rcnt, n, self.pose_stage, self.cap, mp, 5 * self.Lp, self.Lp, L)
 
     def _exchange_buffer(self, name, nfloats):
         """Grow-only device buffer for the all-to-all (no allocator traffic in the frame loop)."""

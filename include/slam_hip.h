@@ -270,6 +270,10 @@ uint64_t slam_comb_offset(uint64_t seed, uint32_t frame, uint64_t total);
  *      [1 .. world] send_cnt[q]: rows this rank sends to rank q,  [1+world .. 2*world] recv_cnt[q],
  *      [1+2*world .. 3*world] internal to the pack step.
  *    Needs nothing from the host; the host reads the plan once for the all-to-all's split sizes.
+ *    d_pose_idx (optional, n_local words): for every slot the index of its ancestor's pose in an all-gather of
+ *    the ranks' pose blocks [x[n_local] | y[n_local] | theta[n_local]] — with it the next frame's
+ *    slam_motion_score_dev can run on all-gathered poses (d_src_x = gathered, d_src_y = gathered + n_local,
+ *    d_src_th = gathered + 2 n_local, d_anc = d_pose_idx) before the exchange of the map rows has happened.
  *  - slam_migrate_pack_dev: one launch packs, for every destination q, its send_cnt[q] rows as records of
  *    3 + 5*nlandmarks floats (x, y, theta, then the five map planes of nlandmarks values each) — the layout of
  *    one all-to-all send buffer.  `plan` is the host copy of d_plan; uses state left by the
@@ -279,7 +283,7 @@ uint64_t slam_comb_offset(uint64_t seed, uint32_t frame, uint64_t total);
  *    must have as rows too) and of the map. */
 #define SLAM_PLAN_WORDS(world) (1 + 3 * (world))
 int slam_ancestors_sharded_dev(slam_engine *e, const int32_t *d_first_all, int64_t n_total, int n_local, int rank,
-                               int world, int32_t *d_src, int32_t *d_plan);
+                               int world, int32_t *d_src, int32_t *d_plan, int32_t *d_pose_idx);
 /* The plan of the last slam_ancestors_sharded_dev call on this engine, on the host: the plan kernel also writes it to
  * pinned host memory mapped into the device and releases an arrival flag; this call waits for that flag (no
  * device-to-host copy, no stream synchronisation) and copies the SLAM_PLAN_WORDS(world) words out. */

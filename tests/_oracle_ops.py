@@ -101,7 +101,7 @@ class OracleOps:
         self.offspring_from_scan(n, None, None, seed, frame, n, first)
         self.ancestors(first, n, 0, n, anc)
 
-    def ancestors_sharded(self, first_all, n_total, n_local, rank, world, src, plan):
+    def ancestors_sharded(self, first_all, n_total, n_local, rank, world, src, plan, pose_idx=None):
         """Independent restatement with numpy set operations: rank s sends rank r the DISTINCT ancestors (its own
         particles) of r's slots, in particle order; r stages them in rank order behind its n_local particles."""
         fa = _np(first_all)[:n_total]
@@ -135,6 +135,8 @@ class OracleOps:
                 out_plan[1 + 2 * world + d] = int(np.count_nonzero(cnt[: int(uniq[0] - rank * n) + 1] > 0))
         src[:n] = torch.from_numpy(out.astype(np.int32))
         plan[:] = torch.from_numpy(out_plan)
+        if pose_idx is not None:   # position of the ancestor's pose in the all-gathered [rank][x|y|theta][n] array
+            pose_idx[:n] = torch.from_numpy(((mine // n) * 3 * n + mine % n).astype(np.int32))
 
     def read_plan(self, d_plan, world):
         return d_plan.tolist()
