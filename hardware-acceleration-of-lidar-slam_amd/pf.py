@@ -184,15 +184,23 @@ class ParticleFilter:
             dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group)
 
     # ------------------------------------------------------------------ state access
+    def _drop_resample(self):
+        """set_poses / set_map discard the pending resample gather: nothing of it may run later."""
+        self.src_idx = None
+        self._exchange_pending = False
+        if self._pose_work is not None:
+            self._pose_work.wait()
+            self._pose_work = None
+
     def set_poses(self, x, y, th):
         for k, a in enumerate((x, y, th)):
             self.pose[self.cur, k, : self.n] = torch.as_tensor(a, dtype=torch.float32).to(self.device)
-        self.src_idx = None
+        self._drop_resample()
 
     def set_map(self, rows):
         """rows: float32 [n_local][5][L] (mu_x, mu_y, P_xx, P_xy, P_yy per landmark)"""
         self.map[self.cur, : self.n, :, : self.L] = torch.as_tensor(rows, dtype=torch.float32).to(self.device)
-        self.src_idx = None
+        self._drop_resample()
 
     def poses(self):
         """Current particle poses [3][n_local] with any pending resample gather applied.  (Several GPUs: this and
