@@ -245,11 +245,12 @@ class ParticleFilter:
             o.motion_score(self.grid_slot, (src[0], src[1], src[2]), self.src_idx, (dst[0], dst[1], dst[2]), n,
                            self.rank * n, dp, self.sigma, self.seed, self.frame, self.score, self.count)
         if multi:
-            # this frame's poses to every rank for the next frame's motion + score: starts when the launch above is done
-            # and runs on RCCL's stream beside the EKF (issued after the EKF it would start 160 us later and, with real
-            # inter-GPU latency, risk holding up the next frame)
+            # map rows of remote ancestors -> staging tail; issued behind the launch above, which does not need them
+            self._finish_exchange()
+            # this frame's poses to every rank for the next frame's motion + score.  Collectives of one communicator run
+            # in issue order: after the exchange (the EKF waits for that one), before this frame's all-reduce (so that it
+            # runs beside the EKF, not in front of the weight normaliser).
             self._pose_work = self._all_gather(self.pose_all, dst.reshape(-1), async_op=True)
-            self._finish_exchange()   # map rows of remote ancestors -> staging tail, behind the launch above
         # 3. per-landmark EKF (+ fused gather); the log-likelihood stays inside the engine for step 4
         use_ll = self.L > 0 and (obs is not None or obs_dev is not None)
         if use_ll:
