@@ -530,6 +530,35 @@ def test_c_session_equals_python_frame_loop_and_oracle(eng, orc):
         ses.close()
 
 
+def test_ranks_on_one_card_equal_one_rank_at_scale(tmp_path):
+    """Sharded == unsharded at a scale the CPU specification cannot check: 4 ranks x 8192 particles x 40 landmarks
+    sharing one MI355X against the same filter as ONE rank of 32 768 particles on that MI355X, 15 frames, bit for
+    bit (poses, maps, weights, heaviest particle).  (4 ranks + this process = 5 processes on the card.)"""
+    import socket
+
+    import _shard_worker as W
+    import torch.multiprocessing as mp
+
+    world, n_total, L, frames = 4, 32768, 40, 15
+    ctx = mp.get_context("spawn")
+    outs = {}
+    for tag, g in (("one", 1), ("many", world)):
+        d = tmp_path / tag
+        d.mkdir()
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        mp.spawn(W.worker_gpu, args=(g, port, n_total, L, frames, str(d)), nprocs=g, join=True)
+        outs[tag] = [np.load(d / f"rank{r}.npz") for r in range(g)]
+    ref, parts = outs["one"][0], outs["many"]
+    assert np.array_equal(bits(np.concatenate([p["pose"] for p in parts], axis=1)), bits(ref["pose"]))
+    assert np.array_equal(bits(np.concatenate([p["logw"] for p in parts])), bits(ref["logw"]))
+    assert np.array_equal(bits(np.concatenate([p["map"] for p in parts], axis=0)), bits(ref["map"]))
+    for p in parts:
+        assert tuple(p["best"]) == tuple(ref["best"])
+    assert max(int(p["migrated"].max()) for p in parts) > 100     # the exchange really carried rows
+
+
 def test_full_size_ekf_config2_vs_oracle(eng, orc):
     """BASELINE config 2 at full size — 65 536 particles x 500 landmarks, every landmark observed, resample
     gather fused in: the whole 2 x 655 MB update against the CPU specification, bit for bit."""
