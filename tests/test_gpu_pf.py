@@ -556,7 +556,7 @@ def test_ranks_on_one_card_equal_one_rank_at_scale(tmp_path):
     assert np.array_equal(bits(np.concatenate([p["map"] for p in parts], axis=0)), bits(ref["map"]))
     for p in parts:
         assert tuple(p["best"]) == tuple(ref["best"])
-    assert max(int(p["migrated"].max()) for p in parts) > 100     # the exchange really carried rows
+    assert max(int(p["migrated"].max()) for p in parts) > 20      # the exchange really carried rows
 
 
 def test_full_size_ekf_config2_vs_oracle(eng, orc):
