@@ -800,14 +800,16 @@ __global__ __launch_bounds__(kBlock) void shard_plan_kernel(const int32_t* __res
     }
     __threadfence_block();
     __syncthreads();
-    if (threadIdx.x != 0) return;
+    // one thread per peer (their binary searches run side by side: one thread doing all peers in turn is ~10 us of
+    // dependent L2 round trips per peer), then thread 0 strings the receive offsets together
+    __shared__ int32_t s_scnt[kMaxRanks], s_rcnt[kMaxRanks], s_sbase[kMaxRanks], s_rbase[kMaxRanks], s_any[kMaxRanks];
     const int64_t my_lo = (int64_t)rank * n, my_hi = my_lo + n;
-    const int64_t a_me = first_or_total(first_all, my_lo, n_total), b_me = first_or_total(first_all, my_hi, n_total);
-    int32_t anything = 0, roff = 0;
-    for (int q = 0; q < world; ++q) {
+    if ((int)threadIdx.x < world) {
+        const int q = threadIdx.x;
+        const int64_t a_me = first_or_total(first_all, my_lo, n_total), b_me = first_or_total(first_all, my_hi, n_total);
         const int64_t aq = first_or_total(first_all, (int64_t)q * n, n_total);
         const int64_t bq = first_or_total(first_all, (int64_t)(q + 1) * n, n_total);
-        if (q > 0 && aq != (int64_t)q * n) anything = 1;   // a run boundary off a rank boundary: somebody exchanges
+        s_any[q] = (q > 0 && aq != (int64_t)q * n) ? 1 : 0;   // a run boundary off a rank boundary: somebody exchanges
         // what I receive from q: my slots [lo, hi) descend from q's particles
         int64_t lo = aq > my_lo ? aq : my_lo, hi = bq < my_hi ? bq : my_hi;
         int32_t rcnt = 0, rbase = 0;
@@ -815,9 +817,6 @@ __global__ __launch_bounds__(kBlock) void shard_plan_kernel(const int32_t* __res
             rbase = shard_prefix(pfx, boff, 0, n, ntiles, (int)(lo - my_lo));
             rcnt = shard_prefix(pfx, boff, 0, n, ntiles, (int)(hi - 1 - my_lo)) - rbase + 1;
         }
-        rplan[q] = roff;
-        rplan[world + q] = rbase;
-        roff += rcnt;
         // what I send to q: q's slots [lo, hi) descend from my particles
         const int64_t q_lo = (int64_t)q * n, q_hi = q_lo + n;
         lo = a_me > q_lo ? a_me : q_lo;
@@ -829,13 +828,26 @@ __global__ __launch_bounds__(kBlock) void shard_plan_kernel(const int32_t* __res
             sbase = shard_prefix(pfx, boff, 1, n, ntiles, a_lo);
             scnt = shard_prefix(pfx, boff, 1, n, ntiles, a_hi) - sbase + 1;
         }
-        plan[1 + q] = scnt;
-        plan[1 + world + q] = rcnt;
-        plan[1 + 2 * world + q] = sbase;
+        s_scnt[q] = scnt;
+        s_rcnt[q] = rcnt;
+        s_sbase[q] = sbase;
+        s_rbase[q] = rbase;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    int32_t anything = 0, roff = 0;
+    for (int q = 0; q < world; ++q) {
+        anything |= s_any[q];
+        rplan[q] = roff;
+        rplan[world + q] = s_rbase[q];
+        roff += s_rcnt[q];
+        plan[1 + q] = s_scnt[q];
+        plan[1 + world + q] = s_rcnt[q];
+        plan[1 + 2 * world + q] = s_sbase[q];
         if (host_plan) {
-            host_plan[1 + q] = scnt;
-            host_plan[1 + world + q] = rcnt;
-            host_plan[1 + 2 * world + q] = sbase;
+            host_plan[1 + q] = s_scnt[q];
+            host_plan[1 + world + q] = s_rcnt[q];
+            host_plan[1 + 2 * world + q] = s_sbase[q];
         }
     }
     plan[0] = anything;
