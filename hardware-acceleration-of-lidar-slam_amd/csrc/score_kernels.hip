@@ -62,9 +62,23 @@ __global__ __launch_bounds__(kScoreBlock) void score_poses_kernel(ScoreGrid g, c
     constexpr int kRound = LPP * kQuadDepth;
     // (at least one round, so that an empty scan still runs the pipeline prologue on NaN beams)
     const int nb_pad = LPP == 1 ? nbeams : (nbeams > 0 ? (nbeams + kRound - 1) / kRound * kRound : kRound);
-    for (int b = threadIdx.x; b < nb_pad; b += kScoreBlock)
-        s_beam[b] = b < nbeams ? make_float2(bx[b] * g.ipix, by[b] * g.ipix)
-                               : make_float2(__builtin_nanf(""), __builtin_nanf(""));
+    if constexpr (LPP == 1) {
+        for (int b = threadIdx.x; b < nb_pad; b += kScoreBlock)
+            s_beam[b] = b < nbeams ? make_float2(bx[b] * g.ipix, by[b] * g.ipix)
+                                   : make_float2(__builtin_nanf(""), __builtin_nanf(""));
+    } else {
+        // LPP lanes per pose: lane `sub` takes beams sub + LPP*k and handles them two at a time (k = 2m, 2m+1) on
+        // float2 arithmetic; the pair is staged side by side — slot sub + LPP*m = (x_k, x_k+1, y_k, y_k+1) — so one
+        // 16-byte LDS read delivers both operands already packed (no register shuffling before the v_pk_* ops)
+        float4* s_pair = reinterpret_cast<float4*>(s_beam);
+        const float nanv = __builtin_nanf("");
+        for (int p = threadIdx.x; p < nb_pad / 2; p += kScoreBlock) {
+            const int m = p / LPP, su = p - m * LPP;
+            const int b0 = su + LPP * (2 * m), b1 = b0 + LPP;
+            s_pair[p] = make_float4(b0 < nbeams ? bx[b0] * g.ipix : nanv, b1 < nbeams ? bx[b1] * g.ipix : nanv,
+                                    b0 < nbeams ? by[b0] * g.ipix : nanv, b1 < nbeams ? by[b1] * g.ipix : nanv);
+        }
+    }
     __syncthreads();
 
     const int t = blockIdx.x * kScoreBlock + threadIdx.x;
@@ -124,30 +138,53 @@ __global__ __launch_bounds__(kScoreBlock) void score_poses_kernel(ScoreGrid g, c
 #pragma unroll UNROLL
         for (int b = 0; b < nbeams; ++b) total = total + beam(b);
     } else {
-        // software pipeline: kQuadDepth gathers stay in flight per lane; the hit of step s is summed while
-        // the loads of steps s+1 .. s+kQuadDepth are outstanding (hipcc alone waits vmcnt(0) every step)
-        float hq[kQuadDepth];
+        // software pipeline: kQuadDepth gathers stay in flight per lane; the hits of step s are summed while
+        // the loads of steps s+1 .. are outstanding (hipcc alone waits vmcnt(0) every step)
+        typedef float v2f __attribute__((ext_vector_type(2)));
+        const float4* s_pair = reinterpret_cast<const float4*>(s_beam);
+        const v2f c2 = {ct, ct}, s2 = {st, st}, ns2 = {nst, nst}, ox2 = {off_x, off_x}, oy2 = {off_y, off_y};
+        auto beam2 = [&](int m) {   // beams sub + LPP*2m and sub + LPP*(2m+1)
+            const float4 q = s_pair[sub + LPP * m];
+            const v2f X = {q.x, q.y}, Y = {q.z, q.w};
+            const v2f fx = ((X * c2) + (Y * s2)) + ox2;
+            const v2f fy = ((X * ns2) + (Y * c2)) + oy2;
+            v2f h;
 #pragma unroll
-        for (int k = 0; k < kQuadDepth; ++k) hq[k] = beam(sub + LPP * k);
-        for (int b0 = kRound; b0 < nb_pad; b0 += kRound) {
-#pragma unroll
-            for (int k = 0; k < kQuadDepth; ++k) {
-                const float h = hq[k];
-                hq[k] = beam(sub + b0 + LPP * k);
-                // beams 4j, 4j+1, 4j+2, 4j+3 in order, identically in all four lanes of the quad
-                total = total + quad_bcast<0x00>(h);
-                total = total + quad_bcast<0x55>(h);
-                total = total + quad_bcast<0xAA>(h);
-                total = total + quad_bcast<0xFF>(h);
+            for (int e = 0; e < 2; ++e) {
+                const int ix = __float2int_rz(round_half_away(fx[e]));
+                const int iy = __float2int_rz(round_half_away(fy[e]));
+                const bool in = (unsigned)(ix - 1) < lim_x && (unsigned)(iy - 1) < lim_y;
+                unsigned off = (unsigned)(iy * ld + ix) * 4u;
+                off = in ? off : 0u;
+                const float v = *(__attribute__((address_space(1))) const float*)(edt + off);
+                n_in += in ? 1 : 0;
+                h[e] = in ? v : 0.0f;   // adding +0 leaves the running sum's bits unchanged
             }
-        }
-#pragma unroll
-        for (int k = 0; k < kQuadDepth; ++k) {
-            const float h = hq[k];
+            return h;
+        };
+        auto add_quad = [&](float h) {   // beams 4j, 4j+1, 4j+2, 4j+3 in order, identically in all four lanes of the quad
             total = total + quad_bcast<0x00>(h);
             total = total + quad_bcast<0x55>(h);
             total = total + quad_bcast<0xAA>(h);
             total = total + quad_bcast<0xFF>(h);
+        };
+        constexpr int kPairs = kQuadDepth / 2;
+        v2f hq[kPairs];
+#pragma unroll
+        for (int m = 0; m < kPairs; ++m) hq[m] = beam2(m);
+        for (int r = 1; r < nb_pad / kRound; ++r) {
+#pragma unroll
+            for (int m = 0; m < kPairs; ++m) {
+                const v2f h = hq[m];
+                hq[m] = beam2(r * kPairs + m);
+                add_quad(h[0]);
+                add_quad(h[1]);
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < kPairs; ++m) {
+            add_quad(hq[m][0]);
+            add_quad(hq[m][1]);
         }
     }
     if (LPP == 4) {
