@@ -150,6 +150,14 @@ class ParticleFilter:
         self.pose_idx = torch.zeros((2, self.n), dtype=i32, device=dv) if self.multi else None
         self._pose_work = None           # async all-gather of the poses in flight
         self._exchange_pending = False   # resample done, map rows not exchanged yet
+        # views used every frame, made once (slicing a tensor costs a few microseconds of host time each)
+        self._rows = [tuple(self.pose[b][k] for k in range(3)) for b in range(2)]
+        self._flat = [self.pose[b].reshape(-1) for b in range(2)]
+        if self.multi:
+            pa, n_ = self.pose_all, self.n
+            self._all_rows = (pa, pa[n_:], pa[2 * n_:])
+            self._pidx = [self.pose_idx[b] for b in range(2)]
+        self._anc = [self.anc[b] for b in range(2)]
         self.frame = 0
         self.migrated_last = 0
         # gloo cannot move GPU tensors for every collective used here: stage them through the host then
@@ -229,7 +237,7 @@ class ParticleFilter:
         obs_dev = (d_zx_by_landmark, d_zy_by_landmark): the table form already resident on the device — entry l is
         the observation of landmark l, NaN in zx = not observed this frame."""
         o, n, cur, nxt = self.ops, self.n, self.cur, 1 - self.cur
-        src, dst = self.pose[cur], self.pose[nxt]
+        src, dst = self._rows[cur], self._rows[nxt]
         multi = self.multi
         # 1+2. motion (+ fused gather of the previous resample) and scan-match score, one launch.  Several GPUs: the
         # ancestors' poses come out of the all-gathered pose array, so this launch needs nothing from the exchange
@@ -238,11 +246,10 @@ class ParticleFilter:
             if self._pose_work is not None:
                 self._pose_work.wait()
                 self._pose_work = None
-            pa = self.pose_all
-            o.motion_score(self.grid_slot, (pa, pa[n:], pa[2 * n:]), self.pose_idx[cur], (dst[0], dst[1], dst[2]), n,
+            o.motion_score(self.grid_slot, self._all_rows, self._pidx[cur], dst, n,
                            self.rank * n, dp, self.sigma, self.seed, self.frame, self.score, self.count)
         else:
-            o.motion_score(self.grid_slot, (src[0], src[1], src[2]), self.src_idx, (dst[0], dst[1], dst[2]), n,
+            o.motion_score(self.grid_slot, src, self.src_idx, dst, n,
                            self.rank * n, dp, self.sigma, self.seed, self.frame, self.score, self.count)
         if multi:
             # map rows of remote ancestors -> staging tail; issued behind the launch above, which does not need them
@@ -250,7 +257,7 @@ class ParticleFilter:
             # this frame's poses to every rank for the next frame's motion + score.  Collectives of one communicator run
             # in issue order: after the exchange (the EKF waits for that one), before this frame's all-reduce (so that it
             # runs beside the EKF, not in front of the weight normaliser).
-            self._pose_work = self._all_gather(self.pose_all, dst.reshape(-1), async_op=True)
+            self._pose_work = self._all_gather(self.pose_all, self._flat[nxt], async_op=True)
         # 3. per-landmark EKF (+ fused gather); the log-likelihood stays inside the engine for step 4
         use_ll = self.L > 0 and (obs is not None or obs_dev is not None)
         if use_ll:
@@ -276,7 +283,7 @@ class ParticleFilter:
             self._all_gather(self.totals, self.d_sum)
             o.offspring_from_scan_sharded(n, self.totals, self.rank, self.world, self.seed, self.frame, self.n_total,
                                           self.first)
-        anc = self.anc[nxt]
+        anc = self._anc[nxt]
         self.cur = nxt
         if not multi:
             o.ancestors_from_scan(n, self.seed, self.frame, anc)   # offspring offsets + ancestors in one launch
@@ -285,7 +292,7 @@ class ParticleFilter:
             # 6. particles whose ancestor lives on another GPU.  The gather index and the exchange plan are made on
             # the device; the host reads the plan once (3 * world + 1 words) for the all-to-all's split sizes.
             self._all_gather(self.first_all, self.first)
-            o.ancestors_sharded(self.first_all, self.n_total, n, self.rank, self.world, anc, self.plan, self.pose_idx[nxt])
+            o.ancestors_sharded(self.first_all, self.n_total, n, self.rank, self.world, anc, self.plan, self._pidx[nxt])
             self._exchange_pending = True   # done at the start of the next frame, behind its motion + score launch
         self.src_idx = anc
         self.frame += 1
@@ -315,11 +322,13 @@ class ParticleFilter:
         rbuf = self._exchange_buffer("_rbuf", rows * rtot)
         pose = self.pose[self.cur]
         mp = self.map[self.cur] if L else None
-        o.migrate_pack(n, r, G, plan, pose, n, mp, 5 * self.Lp, self.Lp, L, sbuf)
+        if stot:
+            o.migrate_pack(n, r, G, plan, pose, n, mp, 5 * self.Lp, self.Lp, L, sbuf)
         self._all_to_all(rbuf, sbuf, [rows * c for c in rcnt], [rows * c for c in scnt])
         # the records carry the poses too; nothing reads them from here (the next frame takes poses from the
         # all-gathered array), they land in a scratch staging area
-        o.migrate_unpack(rbuf, G, rcnt, n, self.pose_stage, self.cap, mp, 5 * self.Lp, self.Lp, L)
+        if rtot:
+            o.migrate_unpack(rbuf, G, rcnt, n, self.pose_stage, self.cap, mp, 5 * self.Lp, self.Lp, L)
 
     def _exchange_buffer(self, name, nfloats):
         """Grow-only device buffer for the all-to-all (no allocator traffic in the frame loop)."""
