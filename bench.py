@@ -265,14 +265,18 @@ def main():
             tab[k, 1, f["ids"]] = f["zy"]
         d_z = torch.from_numpy(tab).to(dev)                                                              # [F][2][L]
 
+    # per-frame views of the resident sensor data, made once (a tensor slice costs microseconds of host time)
+    scan_v = [(d_scan[k, 0], d_scan[k, 1]) for k in range(len(frames))]
+    obs_v = [(d_z[k, 0], d_z[k, 1]) for k in range(len(frames))] if L else None
+
     def one_step(k):
         fr = frames[k]
         if args.host_sensor:
             eng.scan_upload(fr["bx"], fr["by"])
             obs, obs_dev = ((fr["ids"], fr["zx"], fr["zy"]) if L else None), None
         else:
-            eng.scan_set_dev(d_scan[k, 0], d_scan[k, 1], args.beams)
-            obs, obs_dev = None, ((d_z[k, 0], d_z[k, 1]) if L else None)
+            eng.scan_set_dev(scan_v[k][0], scan_v[k][1], args.beams)
+            obs, obs_dev = None, (obs_v[k] if L else None)
         if args.mode == "pf":
             pf.step(fr["dp"], obs, obs_dev)
             if args.stats:
