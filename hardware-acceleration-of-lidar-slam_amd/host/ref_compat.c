@@ -74,6 +74,7 @@ static void edt_into_slot(int slot, const int *in, float *out, int ld, int rows,
     must(slam_grid_upload_host(engine(), slot, in, &m, 10.0f /* MAX_DIST, :217 */, out), "slam_grid_upload_host");
 }
 
+#ifndef SLAM_REF_EDT_WIDTH_HEIGHT
 void euclidean_distance_transform(int input_map[200][200], float output_distance_map[200][200], int height, int width)
 {
     edt_into_slot(0, &input_map[0][0], &output_distance_map[0][0], 200, width, height);
@@ -83,6 +84,22 @@ void euclidean_distance_transform2(int input_map[400][400], float output_distanc
 {
     edt_into_slot(1, &input_map[0][0], &output_distance_map[0][0], 400, width, height);
 }
+#else
+/* -DSLAM_REF_EDT_WIDTH_HEIGHT: the signature of the STAND-ALONE file,
+ * Submodule_2/Accelereated_Euclidean_Distance_Transform.c:1 and :36 — (width, height) in that order, and its body
+ * indexes [i < width][j < height], so the FIRST integer counts rows here.  Behind main.c's call site
+ * (grid_size[1], grid_size[0]) that file is only right for square extents; this variant
+ * reproduces exactly what it computes for a caller written against that file. */
+void euclidean_distance_transform(int input_map[200][200], float output_distance_map[200][200], int width, int height)
+{
+    edt_into_slot(0, &input_map[0][0], &output_distance_map[0][0], 200, width, height);
+}
+
+void euclidean_distance_transform2(int input_map[400][400], float output_distance_map[400][400], int width, int height)
+{
+    edt_into_slot(1, &input_map[0][0], &output_distance_map[0][0], 400, width, height);
+}
+#endif
 
 static void match_on_slot(int slot, const float POSE[3], const float searchResolution[3])
 {

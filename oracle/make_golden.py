@@ -19,6 +19,9 @@ What it writes (SURVEY.md §8c "Fixtures to commit"):
   tests/golden/functions.npz        per-function inputs/outputs: angle table, scan clean-up,
                                     transform, local map, raster, EDT (both reference variants),
                                     single-pose scores (the res={0,0,0} trick), full FastMatch calls
+  tests/golden/edt_standalone.npz   square-grid cases run through the STAND-ALONE scatter EDT file
+                                    Submodule_2/Accelereated_Euclidean_Distance_Transform.c:1,36
+                                    (`--only standalone` rewrites just this file)
 """
 from __future__ import annotations
 
@@ -272,11 +275,45 @@ def per_function(tmp: Path) -> dict:
     return g
 
 
+def standalone_edt() -> dict:
+    """Square grids through Submodule_2/Accelereated_Euclidean_Distance_Transform.c (its (width, height) order is
+    only meaningful when both are equal).  Cells outside the n x n square must stay untouched."""
+    L = C.CDLL(str(oracle.REF / "libref_edt_standalone.so"))
+    L.ref_sa_grid.restype = C.POINTER(C.c_int)
+    L.ref_sa_metric.restype = C.POINTER(C.c_float)
+    L.ref_sa_grid.argtypes = L.ref_sa_metric.argtypes = [C.c_int]
+    L.ref_sa_edt.argtypes = [C.c_int, C.c_int, C.c_int]
+    rng = np.random.default_rng(20261004)
+    g: dict[str, np.ndarray] = {}
+    cases = [("sq64_sparse", 0, 64, 0.02), ("sq120_dense", 0, 120, 0.3), ("sq200_max", 0, 200, 0.008),
+             ("sq37_single", 0, 37, None), ("sq250_fine", 1, 250, 0.01), ("sq400_max", 1, 400, 0.004), ("sq16_empty", 1, 16, 0.0)]
+    for tag, which, n, dens in cases:
+        ld = 400 if which else 200
+        occ = np.ctypeslib.as_array(L.ref_sa_grid(which), shape=(ld, ld))
+        met = np.ctypeslib.as_array(L.ref_sa_metric(which), shape=(ld, ld))
+        occ[:] = 0
+        if dens is None:
+            occ[n // 3, n - 5] = 1
+        else:
+            occ[:n, :n] = rng.random((n, n)) < dens
+        met[:] = -1.0
+        L.ref_sa_edt(which, n, n)
+        assert np.all(met[n:, :] == -1.0) and np.all(met[:, n:] == -1.0)
+        g[f"{tag}_occ"] = occ[:n, :n].astype(np.int8)
+        g[f"{tag}_out"] = met[:n, :n].copy()
+        g[f"{tag}_which"] = np.array([which], np.int32)
+    return g
+
+
 def main():
     if not Path("/root/reference/Subsystem_1/main.c").exists():
         sys.exit("make_golden: /root/reference is not present; golden vectors can only be made in the build container")
     oracle.build(ref=True)
     GOLD.mkdir(parents=True, exist_ok=True)
+    np.savez_compressed(GOLD / "edt_standalone.npz", **standalone_edt())
+    if sys.argv[1:] == ["--only", "standalone"]:
+        print("golden vectors written to", GOLD / "edt_standalone.npz")
+        return
     info: dict = {}
     with tempfile.TemporaryDirectory() as d:
         tmp = Path(d)

@@ -29,6 +29,17 @@ def golden():
 
 
 @pytest.fixture(scope="session")
+def golden_edt_standalone():
+    """Square-grid cases captured from the reference's STAND-ALONE scatter EDT file,
+    Submodule_2/Accelereated_Euclidean_Distance_Transform.c:1,36 (oracle/make_golden.py standalone_edt)."""
+    with np.load(GOLDEN / "edt_standalone.npz", allow_pickle=False) as z:
+        return {k: z[k] for k in z.files}
+
+
+SA_CASES = ["sq64_sparse", "sq120_dense", "sq200_max", "sq37_single", "sq250_fine", "sq400_max", "sq16_empty"]
+
+
+@pytest.fixture(scope="session")
 def orc():
     import oracle
 

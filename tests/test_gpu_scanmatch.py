@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 
 from __graft_entry__ import PKG_DIR, load_package
-from conftest import GOLDEN, bits
+from conftest import GOLDEN, SA_CASES, bits
 
 pytestmark = pytest.mark.gpu
 NB = 1079
@@ -41,6 +41,21 @@ def test_edt_golden(eng, golden, case):
     eng.edt_host(occ, rows, cols, 10.0, out=out)
     assert np.array_equal(bits(out[:rows, :cols]), bits(golden[f"edt_{case}_out"]))
     assert np.all(out[rows:, :] == -1.0) and np.all(out[:, cols:] == -1.0)   # Q7: outside stays untouched
+
+
+@pytest.mark.parametrize("case", SA_CASES)
+def test_edt_standalone_file_golden(eng, golden_edt_standalone, case):
+    """HIP EDT vs the file the north star names (Submodule_2/Accelereated_Euclidean_Distance_Transform.c:1,36)."""
+    g = golden_edt_standalone
+    occ_rc = g[f"{case}_occ"].astype(np.int32)
+    n = occ_rc.shape[0]
+    ld = 400 if g[f"{case}_which"][0] else 200
+    occ = np.zeros((ld, ld), np.int32)
+    occ[:n, :n] = occ_rc
+    out = np.full((ld, ld), -1.0, np.float32)
+    eng.edt_host(occ, n, n, 10.0, out=out)
+    assert np.array_equal(bits(out[:n, :n]), bits(g[f"{case}_out"]))
+    assert np.all(out[n:, :] == -1.0) and np.all(out[:, n:] == -1.0)
 
 
 @pytest.mark.parametrize("which", [0, 1])

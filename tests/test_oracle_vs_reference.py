@@ -13,7 +13,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, bits
+from conftest import GOLDEN, SA_CASES, bits
 
 NB = 1079
 
@@ -103,6 +103,23 @@ def test_a6_edt(orc, golden, case, variant):
     assert np.array_equal(bits(out[:rows, :cols]), bits(golden[f"edt_{case}_out"]))
     # cells outside the used rectangle are never written
     assert np.all(out[rows:, :] == -1.0) and np.all(out[:, cols:] == -1.0)
+
+
+@pytest.mark.parametrize("case", SA_CASES)
+@pytest.mark.parametrize("variant", ["gather", "scatter", "window"])
+def test_a6_edt_standalone_file(orc, golden_edt_standalone, case, variant):
+    """The file the north star names, Submodule_2/Accelereated_Euclidean_Distance_Transform.c:1,36, compiled by
+    oracle/Makefile (`ref`) and run on square grids (its (width, height) order is only valid there)."""
+    g = golden_edt_standalone
+    occ_rc = g[f"{case}_occ"].astype(np.int32)
+    n = occ_rc.shape[0]
+    ld = 400 if g[f"{case}_which"][0] else 200
+    occ = np.zeros((ld, ld), np.int32)
+    occ[:n, :n] = occ_rc
+    out = np.full((ld, ld), -1.0, np.float32)
+    orc.edt(occ, n, n, 10.0, variant, out=out)
+    assert np.array_equal(bits(out[:n, :n]), bits(g[f"{case}_out"]))
+    assert np.all(out[n:, :] == -1.0) and np.all(out[:, n:] == -1.0)
 
 
 @pytest.mark.parametrize("which", [0, 1])
