@@ -18,10 +18,17 @@ value = N_total_particles * K / max-over-ranks wall time.
 Other workloads (never the default; used to fill BASELINE.md):
     --mode score   scan-match-only microbench (configs[2]: --particles 1048576 --grid 2048)
     --mode ekf     EKF sweep only (north-star roofline case: --particles 1048576 --landmarks 1000)
+    --scaling strong --particles-total 1048576 --landmarks 1000
+                   the north-star target: N ranks split the SAME problem (what ">= 6x at 8 GPUs" is defined on)
 
 One JSON line on stdout (rank 0), including
-  roofline     — dominant kernel, algorithmic bytes / average launch duration from HIP events recorded
-                 on the kernel's own stream inside the timed region (slam_profile_* in the C ABI)
+  roofline     — dominant kernel: launch duration from HIP events recorded on the kernel's own stream inside the
+                 timed region (slam_profile_* in the C ABI).  `achieved` is the HBM traffic rate when the PMC traffic of
+                 this workload is on file (profiles/traffic.json), else the algorithmic-byte rate; `logical_rate_gbs` is
+                 always the algorithmic-byte rate (40 B per particle and OBSERVED landmark); `no_reuse` is a
+                 short sweep of the same kernel on the same buffers with identity ancestors, run after the timed region
+                 (nothing comes out of L2 there: the streaming figure); `read_only_frac` is the north star's definition
+                 (20 B x n x L_observed / t / peak) on that sweep
   cpu_baseline — the CPU port of the same frame loop (oracle/, single thread) timed on this host
                  on a bounded sample (rank 0, N = 1 only)
 """
@@ -155,7 +162,16 @@ def cpu_baseline(args, occ, meta_t, frames, landmarks, budget_s=12.0):
         el = time.perf_counter() - t0
         if el > budget_s and done >= 3:
             break
+    model = "unknown"
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                model = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
     return {"value": n * done / el, "unit": "particle-updates/s", "cores": 1, "kind": "port",
+            "host_cpu": model, "host_cores_total": os.cpu_count(),
             "sample": f"{n} particles x {done} frames of the same workload ({args.beams} beams, {L} landmarks, "
                       f"{args.grid}^2 EDT), oracle/ C port, 1 thread, {el:.1f} s"}
 
@@ -166,11 +182,20 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--mode", choices=["pf", "score", "ekf"], default="pf")
-    ap.add_argument("--particles", type=int, default=65536, help="per GPU")
+    ap.add_argument("--particles", type=int, default=65536, help="per GPU (weak scaling, the default)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: --particles per GPU (default; BASELINE configs[1] per GPU).  strong: --particles-total is "
+                         "split over the ranks (the north star's 8-vs-1-GPU target is defined on the same total problem)")
+    ap.add_argument("--particles-total", type=int, default=None, help="total population for --scaling strong")
     ap.add_argument("--beams", type=int, default=360)
     ap.add_argument("--landmarks", type=int, default=500)
     ap.add_argument("--grid", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--driver", choices=["c", "py"], default="c",
+                    help="c (default): the C session slam_pf_* — one call per frame, several GPUs: the engine issues every RCCL "
+                         "exchange itself.  py: pf.py on the stage entry points with torch.distributed (rehearsal with gloo)")
+    ap.add_argument("--no-sweep", action="store_true",
+                    help="skip the no-reuse EKF sweep after the timed region (so that a kernel trace of this run holds in-filter launches only)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, production) | gloo (functional rehearsal)")
     ap.add_argument("--device-index", type=int, default=None, help="force every rank onto this GPU (rehearsal only)")
     ap.add_argument("--host-sensor", action="store_true", help="upload scan + observations from the host every frame")
@@ -193,6 +218,10 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch N>1 with torch.distributed.run")
+    if args.scaling == "strong":
+        if not args.particles_total or args.particles_total % world:
+            sys.exit("bench.py: --scaling strong needs --particles-total divisible by the number of ranks")
+        args.particles = args.particles_total // world
 
     import torch
     import torch.distributed as dist
@@ -207,7 +236,7 @@ def main():
     dev_index = local_rank if args.device_index is None else args.device_index
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    if world == 1 and args.force_collectives:
+    if world == 1 and args.force_collectives and args.driver == "py":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group(args.dist_backend, rank=0, world_size=1, **({"device_id": dev} if args.dist_backend == "nccl" else {}))
@@ -219,8 +248,15 @@ def main():
             dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
 
     eng = pkg.Engine(dev_index)
-    ops = HipOps(eng)
-    ops.bind_stream()
+    use_c = args.driver == "c"
+    if use_c and args.dist_backend != "nccl":
+        sys.exit("bench.py: --driver c exchanges over RCCL; use --driver py for a gloo rehearsal")
+    if use_c and args.stats:
+        sys.exit("bench.py: --stats needs --driver py (the C session keeps its weights to itself)")
+    ops = None
+    if not use_c:
+        ops = HipOps(eng)
+        ops.bind_stream()   # the py driver shares torch's current stream; the C session runs on the engine's own
 
     # ---- synthetic inputs (identical on every rank)
     rng = np.random.default_rng(4321)
@@ -234,26 +270,57 @@ def main():
 
     d_occ = torch.from_numpy(occ).to(dev)
     d_edt = torch.empty((args.grid, args.grid), dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
     eng.edt_dev(d_occ, args.grid, args.grid, args.grid, 10.0, d_edt)
     meta = pkg.grid_meta(args.grid, args.grid, args.grid, pixel, min_x, min_y)
     eng.grid_set_dev(0, d_edt, meta)
 
     n = args.particles
-    pf = ParticleFilter(ops, n, L, device=dev, rank=rank, world=world, seed=1234, sigma=args.sigma,
-                        meas_var=args.meas_var, score_gain=args.score_gain, grid_slot=0,
-                        force_collectives=args.force_collectives and world == 1)
+    multi_path = world > 1 or args.force_collectives
+    comm = None
+    if use_c:
+        if multi_path:
+            # rendezvous token of the engine's own RCCL communicator: made by rank 0, handed out through the process
+            # group torchrun set up (used for nothing else but this, the barriers and the final timing reduction)
+            uid = torch.zeros(pkg.COMM_ID_BYTES, dtype=torch.uint8, device=dev)
+            if rank == 0:
+                uid = torch.tensor(list(pkg.comm_unique_id()), dtype=torch.uint8, device=dev)
+            if world > 1:
+                dist.broadcast(uid, src=0)
+            comm = pkg.Comm.rccl(eng, rank, world, bytes(uid.cpu().tolist()))
+        pf = pkg.PfSession(eng, n, L, sigma=args.sigma, meas_var=args.meas_var, score_gain=args.score_gain, seed=1234, comm=comm)
+        Lp = (L + 31) // 32 * 32
+    else:
+        pf = ParticleFilter(ops, n, L, device=dev, rank=rank, world=world, seed=1234, sigma=args.sigma,
+                            meas_var=args.meas_var, score_gain=args.score_gain, grid_slot=0,
+                            force_collectives=args.force_collectives and world == 1)
+        Lp = pf.Lp
+
+    def views():
+        """(pose [3][n], current map [rows][5][Lp], spare map, pending gather index or None) as torch tensors."""
+        if use_c:
+            v = pf.device_view()
+            t = {k: (torch.as_tensor(v[k], device=dev) if v[k] is not None else None) for k in ("pose", "map", "map_spare", "anc")}
+            return t["pose"], t["map"], t["map_spare"], t["anc"]
+        return pf.pose[pf.cur], (pf.map[pf.cur] if L else None), (pf.map[1 - pf.cur] if L else None), pf.src_idx
+
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
     p0 = true_pose(0)
-    pf.set_poses(p0[0] + 0.05 * torch.randn(n, generator=g), p0[1] + 0.05 * torch.randn(n, generator=g),
-                 p0[2] + 0.01 * torch.randn(n, generator=g))
+    pf.set_poses(*((p0[k] + s * torch.randn(n, generator=g)).numpy() for k, s in ((0, 0.05), (1, 0.05), (2, 0.01))))
     if L:
         lm = torch.from_numpy(landmarks.astype(np.float32)).to(dev)
-        m0 = pf.map[pf.cur]                               # [particle][plane][Lp]
-        m0[:n, 0, :L] = lm[:, 0] + 0.1 * torch.randn((n, L), device=dev)
-        m0[:n, 1, :L] = lm[:, 1] + 0.1 * torch.randn((n, L), device=dev)
+        m0 = views()[1]                                   # [particle][plane][Lp]
+        for i0 in range(0, n, 65536):                     # in chunks: the temporaries of a 1M x 1k map are 4 GB each
+            i1 = min(i0 + 65536, n)
+            m0[i0:i1, 0, :L] = lm[:, 0] + 0.1 * torch.randn((i1 - i0, L), device=dev)
+            m0[i0:i1, 1, :L] = lm[:, 1] + 0.1 * torch.randn((i1 - i0, L), device=dev)
         m0[:n, 2, :L] = 0.05
         m0[:n, 3, :L] = 0.0
         m0[:n, 4, :L] = 0.05
+    score_t = torch.zeros(n, dtype=torch.float32, device=dev)
+    count_t = torch.zeros(n, dtype=torch.int32, device=dev)
+    loglik_t = torch.zeros(n, dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
 
     # sensor data of every frame resident in HBM before the timed region (bench contract); --host-sensor
     # uploads it frame by frame through the host-buffer entry points instead (8.9 KB per frame over PCIe)
@@ -269,7 +336,10 @@ def main():
     scan_v = [(d_scan[k, 0], d_scan[k, 1]) for k in range(len(frames))]
     obs_v = [(d_z[k, 0], d_z[k, 1]) for k in range(len(frames))] if L else None
 
+    sweep_pose, sweep_maps = None, None
+
     def one_step(k):
+        nonlocal sweep_pose, sweep_maps
         fr = frames[k]
         if args.host_sensor:
             eng.scan_upload(fr["bx"], fr["by"])
@@ -277,23 +347,35 @@ def main():
         else:
             eng.scan_set_dev(scan_v[k][0], scan_v[k][1], args.beams)
             obs, obs_dev = None, (obs_v[k] if L else None)
-        if args.mode == "pf":
+        if args.mode == "pf" and use_c:
+            if obs_dev:
+                eng.obs_set_dev(*obs_dev, L)
+            elif obs:
+                eng.obs_upload(*obs, L)
+            pf.step(0, fr["dp"], L > 0)
+        elif args.mode == "pf":
             pf.step(fr["dp"], obs, obs_dev)
             if args.stats:
                 w = torch.exp((pf.logw - pf.logw.max()).double())
                 print(f"[stats] rank {rank} frame {k}: distinct ancestors {torch.unique(pf.src_idx).numel()} of {n}, "
                       f"ESS {float(w.sum() ** 2 / (w * w).sum()):.1f}, received rows {pf.migrated_last}", file=sys.stderr)
-        elif args.mode == "score":
-            p = pf.pose[0]
-            eng.score_poses_dev(0, p[0], p[1], p[2], n, pf.score, pf.count)
-        else:   # ekf sweep: out of place, ping-pong between the two map buffers
-            p = pf.pose[0]
-            if obs_dev:
-                eng.obs_set_dev(*obs_dev, L)
-            else:
-                eng.obs_upload(*obs, L)
-            eng.ekf_update_dev(pf.map[k & 1], pf.map[1 - (k & 1)], 5 * pf.Lp, pf.Lp, L, p[0], p[1], p[2], None, n,
-                               args.meas_var, pf.loglik)
+        else:
+            if sweep_pose is None:
+                sweep_pose, a, b, _ = views()
+                sweep_maps = (a, b)
+            p = sweep_pose
+            if args.mode == "score":
+                eng.score_poses_dev(0, p[0], p[1], p[2], n, score_t, count_t)
+            else:   # ekf sweep: out of place, ping-pong between the two map buffers
+                if obs_dev:
+                    eng.obs_set_dev(*obs_dev, L)
+                else:
+                    eng.obs_upload(*obs, L)
+                eng.ekf_update_dev(sweep_maps[k & 1], sweep_maps[1 - (k & 1)], 5 * Lp, Lp, L, p[0], p[1], p[2], None, n,
+                                   args.meas_var, loglik_t)
+
+    def rows_received():
+        return (pf.rows_received() if use_c else pf.migrated_last) if args.mode == "pf" else 0
 
     def barrier():
         torch.cuda.synchronize()
@@ -313,7 +395,7 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.warmup, args.warmup + args.steps):
         one_step(k)
-        migrated += pf.migrated_last
+        migrated += rows_received()
     barrier()
     elapsed = time.perf_counter() - t0
     eng.profile_enable()
@@ -329,8 +411,7 @@ def main():
     ekf_ms, ekf_n = eng.profile_read(eng.PROF_EKF)
     # A start/stop event bracket around ONE kernel also contains the stream's marker handling; an empty bracket
     # measures it (~5-7 us).  Both are reported; the kernel duration used for the roofline is bracket - empty
-    # bracket, which is what rocprofv3's kernel trace of the same process shows (checked in one profiled run:
-    # EKF bracket 264.0 us vs trace 258.1 us, score 43.9 vs 38.7 us; profiles/README.md).
+    # bracket, which is what rocprofv3's kernel trace of the same process shows (profiles/README.md).
     bracket_overhead_ms = eng.profile_bracket_overhead()
     if args.events != "all":   # the kernels not timed inside the region: a short extra pass, outside the timing
         eng.profile_enable(eng.PROF_SCORE, eng.PROF_EKF)
@@ -346,44 +427,86 @@ def main():
     n_total = n * world
     value = n_total * args.steps / elapsed
 
-    # dominant kernel + its algorithmic bytes per launch (DESIGN.md "Measurement")
-    score_bytes = (12 + 4 * args.beams + 4) * n              # pose read + one EDT gather per beam + score write
-    ekf_bytes = 40 * n * L                                   # 20 B read + 20 B written per (particle, landmark)
     def kernel_ms(total_ms, launches):
         return max(total_ms / max(launches, 1) - bracket_overhead_ms, 0.0)
+
+    # how much of the population the resample kept distinct (the rows of repeated ancestors come out of L2, which is
+    # what makes the in-filter EKF faster than a sweep): one torch.unique, outside the timed region
+    distinct_frac = None
+    torch.cuda.synchronize()
+    if args.mode == "pf" and views()[3] is not None:
+        distinct_frac = torch.unique(views()[3]).numel() / n
+
+    # the same EKF kernel WITHOUT ancestor sharing: identity ancestors on the same buffers, after the timed region.
+    # Every row is read from HBM once and written once: the streaming figure of the kernel.
+    L_obs = args.observed if 0 < args.observed < L else L
+    score_bytes = (12 + 4 * args.beams + 4) * n              # pose read + one EDT gather per beam + score write
+    ekf_bytes = 40 * n * L_obs                               # 20 B read + 20 B written per (particle, OBSERVED landmark)
+    no_reuse = None
+    if L and args.mode != "score" and not args.no_sweep:
+        eng.profile_enable(eng.PROF_EKF)
+        eng.profile_read(eng.PROF_EKF)
+        p, ma, mb, _ = views()
+        base = args.warmup + args.steps
+        for k in range(12):
+            eng.obs_set_dev(*obs_v[(base + k) % len(frames)], L)
+            eng.ekf_update_dev((ma, mb)[k & 1], (mb, ma)[k & 1], 5 * Lp, Lp, L, p[0], p[1], p[2], None, n,
+                               args.meas_var, loglik_t)
+        eng.profile_enable()
+        nr_ms, nr_n = eng.profile_read(eng.PROF_EKF)
+        t_nr = kernel_ms(nr_ms, nr_n)
+        if t_nr > 0:
+            no_reuse = {"achieved": ekf_bytes / (t_nr * 1e-3) / 1e9, "frac": ekf_bytes / (t_nr * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        "avg_launch_ms": t_nr, "launches": int(nr_n), "bytes_per_launch": ekf_bytes,
+                        "what": "ekf_update_kernel, identity ancestors (no row is shared), same buffers and observations"}
 
     if ekf_n and (ekf_ms >= score_ms or args.mode == "ekf"):
         kern, raw_ms, dur_ms, alg = "ekf_update_kernel", ekf_ms / ekf_n, kernel_ms(ekf_ms, ekf_n), ekf_bytes
     else:
         kern, raw_ms, dur_ms, alg = ("score_poses_kernel", score_ms / max(score_n, 1), kernel_ms(score_ms, score_n),
                                      score_bytes)
-    achieved = alg / (dur_ms * 1e-3) / 1e9 if dur_ms > 0 else 0.0
-    traffic = None
-    tfile = ROOT / "profiles" / "traffic.json"   # HBM bytes per launch from rocprofv3 --pmc runs of this command
+    logical = alg / (dur_ms * 1e-3) / 1e9 if dur_ms > 0 else 0.0
+    traffic, traffic_src = None, None
+    tfile = ROOT / "profiles" / "traffic.json"   # HBM bytes per launch from rocprofv3 --pmc runs of this same command
     if tfile.exists():
-        rec = json.loads(tfile.read_text()).get(f"{args.mode}:{n}:{args.beams}:{L}:{args.grid}", {})
-        traffic = rec.get(kern) if not (0 < args.observed < L) else None   # measured for the all-observed workload
+        key = f"{args.mode}:{n}:{args.beams}:{L}:{args.grid}" + (f":obs{L_obs}" if L_obs != L else "")
+        rec = json.loads(tfile.read_text()).get(key, {})
+        traffic, traffic_src = rec.get(kern), rec.get("source")
+    # `achieved`: the rate at which HBM itself was driven when the PMC traffic of this workload is on file; else the
+    # no-reuse sweep of the same kernel (a filter's EKF re-reads shared ancestor rows from L2, so its algorithmic-byte
+    # rate is not an HBM rate and can exceed the peak); the scorer's EDT gathers are cache-resident by design, its
+    # logical rate is reported against the HBM peak because BASELINE.json asks for it.
+    if traffic and dur_ms > 0:
+        achieved, basis = traffic / (dur_ms * 1e-3) / 1e9, f"hbm_traffic (PMC, {traffic_src}) / launch time in the timed region"
+    elif kern.startswith("ekf") and no_reuse and args.mode == "pf":
+        achieved, basis = no_reuse["achieved"], "no_reuse sweep (no PMC traffic on file for this workload)"
+    else:
+        achieved, basis = logical, "algorithmic bytes / launch time in the timed region"
+    t_ro = no_reuse["avg_launch_ms"] if no_reuse else (dur_ms if kern.startswith("ekf") else 0.0)
     out = {
         "metric": "particle-updates/sec (N_particles x scans/s) on 360-beam lidar",
         "value": value, "unit": "particle-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": {"pf": "BASELINE configs[1]: full particle-filter frame (motion, scan-match score, "
-                                      "EKF over all landmarks, weights, resample)",
+        "config": {"workload": {"pf": ("BASELINE configs[1]" if (n, L, args.beams, args.grid) == (65536, 500, 360, 1024)
+                                       else "particle filter") + ": full frame (motion, scan-match score, EKF, weights, resample)",
                                 "score": "scan-match score only", "ekf": "EKF sweep only"}[args.mode],
                    "mode": args.mode, "particles_per_gpu": n, "particles_total": n_total, "beams": args.beams,
-                   "landmarks": L, "landmarks_observed_per_frame": (args.observed if 0 < args.observed < L else L),
+                   "landmarks": L, "landmarks_observed_per_frame": L_obs,
                    "edt_grid": f"{args.grid}x{args.grid}", "parallelism": f"particle-shard x{world}" + (" (multi-GPU code path forced)" if args.force_collectives else ""),
-                   "rows_received_per_frame_max_rank": migrated if world > 1 else 0},
+                   "rows_received_per_frame_max_rank": migrated if world > 1 else 0,
+                   "distinct_ancestor_frac": distinct_frac},
         "roofline": {"bound": "hbm", "kernel": kern, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": alg,
-                     # the EKF re-reads the rows of repeated ancestors from L2, so its HBM traffic (PMC) is BELOW the
-                     # algorithmic 40 B per (particle, landmark); this is the rate at which HBM itself was driven
-                     "hbm_traffic_rate_gbs": (traffic / (dur_ms * 1e-3) / 1e9) if traffic and dur_ms > 0 else None,
-                     "note": ("achieved = SURVEY 8(d) algorithmic bytes (40 B per particle and landmark, no reuse assumed) / "
-                              "launch time; rows of repeated resample ancestors are re-read from L2, so the HBM traffic "
-                              "(`traffic`, PMC) is lower and `frac` can exceed 1; --mode ekf is the sweep without sharing"
-                              if kern.startswith("ekf") else
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "achieved_basis": basis,
+                     "algorithmic_bytes_per_launch": alg, "logical_rate_gbs": logical,
+                     "logical_frac": logical / HBM_PEAK_GBS,
+                     "no_reuse": no_reuse,
+                     # the north star's own definition: 20 B x n x L_observed / t / peak, t from the no-reuse sweep
+                     "read_only_frac": (20 * n * L_obs / (t_ro * 1e-3) / 1e9 / HBM_PEAK_GBS) if t_ro > 0 and L else None,
+                     "note": ("in a running filter the rows of repeated resample ancestors are re-read from L2: "
+                              "`logical_rate_gbs` (SURVEY 8d's 40 B per particle and observed landmark / launch time) is then "
+                              "not an HBM rate; `achieved` is, see `achieved_basis`; `no_reuse` is the kernel streaming "
+                              "every row from HBM" if kern.startswith("ekf") else
                               "EDT gathers are served by L2 / Infinity Cache: logical-byte rate, not HBM traffic"),
                      "avg_launch_ms": dur_ms, "avg_event_bracket_ms": raw_ms,
                      "event_bracket_overhead_ms": bracket_overhead_ms,
@@ -397,7 +520,12 @@ def main():
         out["cpu_baseline"] = None
     if rank == 0:
         print(json.dumps(out))
-    if world > 1 or (world == 1 and args.force_collectives):
+    torch.cuda.synchronize()
+    if use_c:
+        pf.close()
+        if comm:
+            comm.close()
+    if dist.is_initialized():
         dist.destroy_process_group()
     eng.close()
 

@@ -99,6 +99,18 @@ SIGNATURES = {
     "slam_mapper_first_frame": (_i, [_vp, _vp]),
     "slam_mapper_next_frame": (_i, [_vp, _vp, _fp]),
     "slam_mapper_get_map_host": (_i, [_vp, _vp, _vp, C.c_int32, C.POINTER(C.c_int32)]),
+    "slam_exchange_set_capacity": (_i, [_vp, _i]),
+    "slam_comm_unique_id": (_i, [_vp]),
+    "slam_comm_create_rccl": (_i, [_vp, _i, _i, _vp, C.POINTER(_vp)]),
+    "slam_local_group_create": (_i, [_i, C.POINTER(_vp)]),
+    "slam_local_group_destroy": (_i, [_vp]),
+    "slam_comm_create_local": (_i, [_vp, _vp, _i, C.POINTER(_vp)]),
+    "slam_comm_rank": (_i, [_vp]),
+    "slam_comm_world": (_i, [_vp]),
+    "slam_comm_destroy": (_i, [_vp]),
+    "slam_pf_create_sharded": (_i, [_vp, _vp, _vp, _i, C.POINTER(_vp)]),
+    "slam_pf_rows_received": (_i, [_vp]),
+    "slam_pf_device_view": (_i, [_vp, _vp]),
     "slam_pf_create": (_i, [_vp, _vp, C.POINTER(_vp)]),
     "slam_pf_destroy": (_i, [_vp]),
     "slam_pf_reset": (_i, [_vp, _fp]),
@@ -355,6 +367,9 @@ class Engine:
         self._ck(self.lib.slam_ancestors_sharded_dev(self.h, _ptr(d_first_all), n_total, n_local, rank, world,
                                                      _ptr(d_src), _ptr(d_plan), _ptr(d_pose_idx)), "ancestors_sharded_dev")
 
+    def exchange_set_capacity(self, rows: int):
+        self._ck(self.lib.slam_exchange_set_capacity(self.h, int(rows)), "exchange_set_capacity")
+
     def exchange_plan_host(self, world):
         """The plan of the last ancestors_sharded_dev call, delivered through mapped host memory (no copy, no sync)."""
         plan = np.zeros(plan_words(world), np.int32)
@@ -391,16 +406,118 @@ class PfConfig(C.Structure):
                 ("meas_var", C.c_float), ("score_gain", C.c_float), ("seed", C.c_uint64)]
 
 
+COMM_ID_BYTES = 128
+
+
+class PfView(C.Structure):
+    """``slam_pf_view``"""
+
+    _fields_ = [("pose", C.c_void_p), ("map", C.c_void_p), ("map_spare", C.c_void_p), ("anc", C.c_void_p), ("row_stride", C.c_int64),
+                ("plane_stride", C.c_int32), ("map_rows", C.c_int32)]
+
+
+class DeviceArray:
+    """A device buffer owned by the engine, exposed through ``__cuda_array_interface__`` so that array libraries
+    (``torch.as_tensor(a, device="cuda")``, cupy) can view it without a copy.  Plumbing only."""
+
+    def __init__(self, ptr: int, shape, typestr: str, owner=None):
+        self._owner = owner
+        self.__cuda_array_interface__ = {"shape": tuple(int(v) for v in shape), "typestr": typestr,
+                                         "data": (int(ptr), False), "version": 2, "strides": None}
+
+
+def comm_unique_id() -> bytes:
+    """``slam_comm_unique_id``: the rendezvous token rank 0 makes and hands to the other ranks."""
+    buf = (C.c_uint8 * COMM_ID_BYTES)()
+    rc = load_library().slam_comm_unique_id(buf)
+    if rc != 0:
+        raise SlamError(rc, "comm_unique_id")
+    return bytes(buf)
+
+
+class LocalGroup:
+    """``slam_local_group``: the rendezvous of an in-process group of ranks (one host thread per rank)."""
+
+    def __init__(self, world: int):
+        self.lib = load_library()
+        h = C.c_void_p()
+        rc = self.lib.slam_local_group_create(world, C.byref(h))
+        if rc != 0:
+            raise SlamError(rc, "local_group_create")
+        self.h, self.world = h, world
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.slam_local_group_destroy(self.h)
+            self.h = None
+
+
+class Comm:
+    """``slam_comm``: how one rank of a sharded filter reaches the others.  ``Comm.rccl`` (one rank per GPU, RCCL over
+    xGMI) or ``Comm.local`` (threads of one process).  Creation over RCCL is collective."""
+
+    def __init__(self, engine: Engine, handle, keep=None):
+        self.e, self.h, self._keep = engine, handle, keep
+
+    @classmethod
+    def rccl(cls, engine: Engine, rank: int, world: int, unique_id: bytes):
+        assert len(unique_id) == COMM_ID_BYTES
+        buf = (C.c_uint8 * COMM_ID_BYTES).from_buffer_copy(unique_id)
+        h = C.c_void_p()
+        engine._ck(engine.lib.slam_comm_create_rccl(engine.h, rank, world, buf, C.byref(h)), "comm_create_rccl")
+        return cls(engine, h)
+
+    @classmethod
+    def local(cls, engine: Engine, group: LocalGroup, rank: int):
+        h = C.c_void_p()
+        engine._ck(engine.lib.slam_comm_create_local(engine.h, group.h, rank, C.byref(h)), "comm_create_local")
+        return cls(engine, h, keep=group)
+
+    @property
+    def rank(self):
+        return self.e.lib.slam_comm_rank(self.h)
+
+    @property
+    def world(self):
+        return self.e.lib.slam_comm_world(self.h)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.e.lib.slam_comm_destroy(self.h)
+            self.h = None
+
+
 class PfSession:
-    """``slam_pf`` — the C-level particle-filter session (what a plain C host uses)."""
+    """``slam_pf`` — the C-level particle-filter session (what a plain C host uses).  With ``comm`` it is one rank
+    of a population sharded over several GPUs (``n_particles`` = this rank's share); every call is then collective."""
 
     def __init__(self, engine: Engine, n_particles, n_landmarks=0, sigma=(0.01, 0.01, 0.002), meas_var=0.01,
-                 score_gain=1.0, seed=1):
-        self.e, self.n, self.L = engine, n_particles, n_landmarks
+                 score_gain=1.0, seed=1, comm: Comm | None = None, recv_capacity: int = 0):
+        self.e, self.n, self.L, self.comm = engine, n_particles, n_landmarks, comm
         cfg = PfConfig(n_particles, n_landmarks, (C.c_float * 3)(*sigma), meas_var, score_gain, seed)
         h = C.c_void_p()
-        engine._ck(engine.lib.slam_pf_create(engine.h, C.byref(cfg), C.byref(h)), "pf_create")
+        if comm is None:
+            engine._ck(engine.lib.slam_pf_create(engine.h, C.byref(cfg), C.byref(h)), "pf_create")
+        else:
+            engine._ck(engine.lib.slam_pf_create_sharded(engine.h, C.byref(cfg), comm.h, recv_capacity, C.byref(h)),
+                       "pf_create_sharded")
         self.h = h
+
+    def rows_received(self) -> int:
+        return self.e.lib.slam_pf_rows_received(self.h)
+
+    def device_view(self):
+        """dict of DeviceArray views of the session's CURRENT buffers (``slam_pf_device_view``): pose [3][n], map and
+        map_spare [map_rows][5][plane_stride] (None without landmarks), anc [n] (None when no gather is pending).
+        They move with every step."""
+        v = PfView()
+        self.e._ck(self.e.lib.slam_pf_device_view(self.h, C.byref(v)), "pf_device_view")
+        shape = (v.map_rows, 5, v.plane_stride)
+        return {"pose": DeviceArray(v.pose, (3, self.n), "<f4", self),
+                "map": DeviceArray(v.map, shape, "<f4", self) if v.map else None,
+                "map_spare": DeviceArray(v.map_spare, shape, "<f4", self) if v.map_spare else None,
+                "anc": DeviceArray(v.anc, (self.n,), "<i4", self) if v.anc else None,
+                "plane_stride": v.plane_stride, "row_stride": v.row_stride}
 
     def close(self):
         if getattr(self, "h", None):

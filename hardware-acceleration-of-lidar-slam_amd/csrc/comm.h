@@ -1,0 +1,38 @@
+// comm.h — the exchange steps between the ranks of a sharded particle filter, as the engine issues them itself
+// (no host framework between the launches).  Two transports behind one interface:
+//   RCCL   one process (or host thread) per GPU, collectives over xGMI: the production transport;
+//   local  all ranks live in ONE process, one host thread each, and exchange through device-to-device copies and a
+//          host rendezvous — for single-process hosts and for rehearsing many ranks on few GPUs (RCCL refuses two
+//          ranks on one device).
+// Every collective of a communicator is issued on ONE dedicated stream in program order (the model of
+// torch.distributed's nccl backend); `fork` makes that stream wait for the engine's stream, `join` the reverse.
+// No counterpart in the reference (it has no multi-device code).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "kernels.h"
+
+struct slam_comm;
+
+namespace slam {
+
+int comm_rank(const slam_comm* c);
+int comm_world(const slam_comm* c);
+slam_engine* comm_engine(const slam_comm* c);
+
+// All of these return a slam_status.  Buffers are device memory of the communicator's engine.
+// in-place MAX over ranks of `count` floats; the engine's stream sees the result
+int comm_all_reduce_max_f32(slam_comm* c, float* d_buf, int count);
+// d_recv[q * bytes .. ) = rank q's d_send[0 .. bytes)
+int comm_all_gather(slam_comm* c, const void* d_send, void* d_recv, size_t bytes);
+// asynchronous form: the gather may run beside later work of the engine's stream until comm_all_gather_finish
+int comm_all_gather_begin(slam_comm* c, const void* d_send, void* d_recv, size_t bytes);
+int comm_all_gather_finish(slam_comm* c);
+// rank q receives send_floats[q] floats from my d_send (blocks in rank order); I receive recv_floats[q] from q
+int comm_all_to_all_f32(slam_comm* c, const float* d_send, const int64_t* send_floats, float* d_recv,
+                        const int64_t* recv_floats);
+
+}  // namespace slam

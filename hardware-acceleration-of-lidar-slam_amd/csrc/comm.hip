@@ -1,0 +1,324 @@
+// comm.hip — communicators of the sharded particle filter (see comm.h): RCCL over xGMI, and the in-process
+// transport.  The C ABI half (creation / destruction) is declared in include/slam_hip.h.
+
+#include "comm.h"
+
+#include <rccl/rccl.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <chrono>
+#include <condition_variable>
+#include <mutex>
+#include <new>
+
+#include "engine_internal.h"
+
+using namespace slam;
+
+// ------------------------------------------------------------------ in-process group (rehearsal / single-process hosts)
+struct slam_local_group {
+    int world = 0;
+    std::mutex m;
+    std::condition_variable cv;
+    int arrived = 0;
+    uint64_t generation = 0;
+    bool broken = false;
+    // what every rank published for the collective in flight
+    const void* send[kMaxRanks] = {};
+    int64_t cnt[kMaxRanks][kMaxRanks] = {};   // all-to-all: cnt[src][dst] floats
+    float fmax[kMaxRanks][4] = {};
+
+    // reusable barrier; false when a rank failed to arrive within the time limit (the group is then broken for good)
+    bool barrier()
+    {
+        std::unique_lock<std::mutex> lk(m);
+        if (broken) return false;
+        const uint64_t gen = generation;
+        if (++arrived == world) {
+            arrived = 0;
+            ++generation;
+            cv.notify_all();
+            return true;
+        }
+        if (!cv.wait_for(lk, std::chrono::seconds(120), [&] { return generation != gen || broken; })) {
+            broken = true;
+            cv.notify_all();
+            return false;
+        }
+        return !broken;
+    }
+};
+
+struct slam_comm {
+    slam_engine* e = nullptr;
+    int rank = 0, world = 1;
+    ncclComm_t nccl = nullptr;            // RCCL transport
+    slam_local_group* group = nullptr;    // in-process transport
+    hipStream_t stream = nullptr;         // every collective of this communicator, in program order
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_afork = nullptr, ev_ajoin = nullptr;
+    bool async_pending = false;
+};
+
+namespace {
+
+int fail_nccl(slam_comm* c, ncclResult_t r, const char* what)
+{
+    snprintf(c->e->err, sizeof c->e->err, "%s: %s", what, ncclGetErrorString(r));
+    return SLAM_ERR_COMM;
+}
+
+#define NCCL_TRY(c, call)                                          \
+    do {                                                           \
+        ncclResult_t r__ = (call);                                 \
+        if (r__ != ncclSuccess) return fail_nccl((c), r__, #call); \
+    } while (0)
+
+#define CHIP_TRY(c, call) SLAM_HIP_TRY((c)->e, call)
+
+// the communicator's stream waits for everything queued on the engine's stream so far
+int fork(slam_comm* c, hipEvent_t ev)
+{
+    CHIP_TRY(c, hipEventRecord(ev, c->e->stream));
+    CHIP_TRY(c, hipStreamWaitEvent(c->stream, ev, 0));
+    return SLAM_OK;
+}
+// the engine's stream waits for everything queued on the communicator's stream so far
+int join(slam_comm* c, hipEvent_t ev)
+{
+    CHIP_TRY(c, hipEventRecord(ev, c->stream));
+    CHIP_TRY(c, hipStreamWaitEvent(c->e->stream, ev, 0));
+    return SLAM_OK;
+}
+
+int local_fail(slam_comm* c, const char* what)
+{
+    snprintf(c->e->err, sizeof c->e->err, "in-process group: %s (a rank did not arrive)", what);
+    return SLAM_ERR_COMM;
+}
+
+// in-process all-gather: publish, rendezvous, pull every rank's block, rendezvous again (nobody may reuse its send
+// buffer before every peer has copied it)
+int local_all_gather(slam_comm* c, const void* d_send, void* d_recv, size_t bytes)
+{
+    slam_local_group* g = c->group;
+    CHIP_TRY(c, hipStreamSynchronize(c->e->stream));
+    g->send[c->rank] = d_send;
+    if (!g->barrier()) return local_fail(c, "all_gather");
+    for (int q = 0; q < c->world; ++q)
+        CHIP_TRY(c, hipMemcpyAsync(static_cast<char*>(d_recv) + (size_t)q * bytes, g->send[q], bytes, hipMemcpyDefault,
+                                   c->e->stream));
+    CHIP_TRY(c, hipStreamSynchronize(c->e->stream));
+    if (!g->barrier()) return local_fail(c, "all_gather");
+    return SLAM_OK;
+}
+
+}  // namespace
+
+namespace slam {
+
+int comm_rank(const slam_comm* c) { return c->rank; }
+int comm_world(const slam_comm* c) { return c->world; }
+slam_engine* comm_engine(const slam_comm* c) { return c->e; }
+
+int comm_all_reduce_max_f32(slam_comm* c, float* d_buf, int count)
+{
+    if (count <= 0) return SLAM_OK;
+    if (c->group) {
+        if (count > 4) return SLAM_ERR_INVALID_ARG;
+        slam_local_group* g = c->group;
+        float mine[4];
+        CHIP_TRY(c, hipMemcpyAsync(mine, d_buf, sizeof(float) * count, hipMemcpyDeviceToHost, c->e->stream));
+        CHIP_TRY(c, hipStreamSynchronize(c->e->stream));
+        for (int k = 0; k < count; ++k) g->fmax[c->rank][k] = mine[k];
+        if (!g->barrier()) return local_fail(c, "all_reduce");
+        for (int q = 0; q < c->world; ++q)
+            for (int k = 0; k < count; ++k)
+                if (g->fmax[q][k] > mine[k]) mine[k] = g->fmax[q][k];
+        CHIP_TRY(c, hipMemcpyAsync(d_buf, mine, sizeof(float) * count, hipMemcpyHostToDevice, c->e->stream));
+        CHIP_TRY(c, hipStreamSynchronize(c->e->stream));   // `mine` is a stack buffer
+        if (!g->barrier()) return local_fail(c, "all_reduce");
+        return SLAM_OK;
+    }
+    if (int rc = fork(c, c->ev_fork)) return rc;
+    NCCL_TRY(c, ncclAllReduce(d_buf, d_buf, (size_t)count, ncclFloat, ncclMax, c->nccl, c->stream));
+    return join(c, c->ev_join);
+}
+
+int comm_all_gather(slam_comm* c, const void* d_send, void* d_recv, size_t bytes)
+{
+    if (bytes == 0) return SLAM_OK;
+    if (c->group) return local_all_gather(c, d_send, d_recv, bytes);
+    if (int rc = fork(c, c->ev_fork)) return rc;
+    NCCL_TRY(c, ncclAllGather(d_send, d_recv, bytes, ncclChar, c->nccl, c->stream));
+    return join(c, c->ev_join);
+}
+
+int comm_all_gather_begin(slam_comm* c, const void* d_send, void* d_recv, size_t bytes)
+{
+    if (c->async_pending) return SLAM_ERR_INVALID_ARG;   // one asynchronous gather at a time
+    if (bytes == 0) return SLAM_OK;
+    if (c->group) return local_all_gather(c, d_send, d_recv, bytes);   // the in-process transport has no overlap
+    if (int rc = fork(c, c->ev_afork)) return rc;
+    NCCL_TRY(c, ncclAllGather(d_send, d_recv, bytes, ncclChar, c->nccl, c->stream));
+    CHIP_TRY(c, hipEventRecord(c->ev_ajoin, c->stream));
+    c->async_pending = true;
+    return SLAM_OK;
+}
+
+int comm_all_gather_finish(slam_comm* c)
+{
+    if (!c->async_pending) return SLAM_OK;
+    c->async_pending = false;
+    CHIP_TRY(c, hipStreamWaitEvent(c->e->stream, c->ev_ajoin, 0));
+    return SLAM_OK;
+}
+
+int comm_all_to_all_f32(slam_comm* c, const float* d_send, const int64_t* send_floats, float* d_recv,
+                        const int64_t* recv_floats)
+{
+    if (c->group) {
+        slam_local_group* g = c->group;
+        CHIP_TRY(c, hipStreamSynchronize(c->e->stream));
+        g->send[c->rank] = d_send;
+        for (int q = 0; q < c->world; ++q) g->cnt[c->rank][q] = send_floats[q];
+        if (!g->barrier()) return local_fail(c, "all_to_all");
+        int64_t roff = 0;
+        for (int q = 0; q < c->world; ++q) {
+            if (g->cnt[q][c->rank] != recv_floats[q]) return local_fail(c, "all_to_all split sizes disagree");
+            int64_t soff = 0;   // where my block starts inside rank q's send buffer
+            for (int d = 0; d < c->rank; ++d) soff += g->cnt[q][d];
+            if (recv_floats[q] > 0)
+                CHIP_TRY(c, hipMemcpyAsync(d_recv + roff, static_cast<const float*>(g->send[q]) + soff,
+                                           sizeof(float) * (size_t)recv_floats[q], hipMemcpyDefault, c->e->stream));
+            roff += recv_floats[q];
+        }
+        CHIP_TRY(c, hipStreamSynchronize(c->e->stream));
+        if (!g->barrier()) return local_fail(c, "all_to_all");
+        return SLAM_OK;
+    }
+    if (int rc = fork(c, c->ev_fork)) return rc;
+    // one grouped exchange: direct peer-to-peer transfers over xGMI, every link busy, no ring
+    NCCL_TRY(c, ncclGroupStart());
+    int64_t soff = 0, roff = 0;
+    ncclResult_t first_bad = ncclSuccess;
+    for (int q = 0; q < c->world; ++q) {
+        if (send_floats[q] > 0 && first_bad == ncclSuccess)
+            first_bad = ncclSend(d_send + soff, (size_t)send_floats[q], ncclFloat, q, c->nccl, c->stream);
+        if (recv_floats[q] > 0 && first_bad == ncclSuccess)
+            first_bad = ncclRecv(d_recv + roff, (size_t)recv_floats[q], ncclFloat, q, c->nccl, c->stream);
+        soff += send_floats[q];
+        roff += recv_floats[q];
+    }
+    const ncclResult_t end = ncclGroupEnd();   // always close the group, even after a failed call inside it
+    if (first_bad != ncclSuccess) return fail_nccl(c, first_bad, "ncclSend/ncclRecv");
+    if (end != ncclSuccess) return fail_nccl(c, end, "ncclGroupEnd");
+    return join(c, c->ev_join);
+}
+
+}  // namespace slam
+
+// ------------------------------------------------------------------ C ABI
+namespace {
+
+int comm_common_init(slam_comm* c)
+{
+    slam_engine* e = c->e;
+    SLAM_HIP_TRY(e, hipSetDevice(e->device));
+    SLAM_HIP_TRY(e, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    for (hipEvent_t* ev : { &c->ev_fork, &c->ev_join, &c->ev_afork, &c->ev_ajoin })
+        SLAM_HIP_TRY(e, hipEventCreateWithFlags(ev, hipEventDisableTiming));
+    return SLAM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int slam_comm_unique_id(uint8_t id[SLAM_COMM_ID_BYTES])
+{
+    static_assert(sizeof(ncclUniqueId) == SLAM_COMM_ID_BYTES, "ncclUniqueId size");
+    if (!id) return SLAM_ERR_INVALID_ARG;
+    ncclUniqueId u;
+    if (ncclGetUniqueId(&u) != ncclSuccess) return SLAM_ERR_COMM;
+    memcpy(id, &u, sizeof u);
+    return SLAM_OK;
+}
+
+int slam_comm_create_rccl(slam_engine* e, int rank, int world, const uint8_t id[SLAM_COMM_ID_BYTES], slam_comm** out)
+{
+    if (!e || !out || !id || world < 1 || world > kMaxRanks || rank < 0 || rank >= world) return SLAM_ERR_INVALID_ARG;
+    *out = nullptr;
+    slam_comm* c = new (std::nothrow) slam_comm();
+    if (!c) return SLAM_ERR_HIP;
+    c->e = e;
+    c->rank = rank;
+    c->world = world;
+    if (int rc = comm_common_init(c)) {
+        slam_comm_destroy(c);
+        return rc;
+    }
+    ncclUniqueId u;
+    memcpy(&u, id, sizeof u);
+    const ncclResult_t r = ncclCommInitRank(&c->nccl, world, u, rank);   // collective: every rank calls it
+    if (r != ncclSuccess) {
+        const int rc = fail_nccl(c, r, "ncclCommInitRank");
+        c->nccl = nullptr;
+        slam_comm_destroy(c);
+        return rc;
+    }
+    *out = c;
+    return SLAM_OK;
+}
+
+int slam_local_group_create(int world, slam_local_group** out)
+{
+    if (!out || world < 1 || world > kMaxRanks) return SLAM_ERR_INVALID_ARG;
+    slam_local_group* g = new (std::nothrow) slam_local_group();
+    if (!g) return SLAM_ERR_HIP;
+    g->world = world;
+    *out = g;
+    return SLAM_OK;
+}
+
+int slam_local_group_destroy(slam_local_group* g)
+{
+    delete g;
+    return SLAM_OK;
+}
+
+int slam_comm_create_local(slam_engine* e, slam_local_group* g, int rank, slam_comm** out)
+{
+    if (!e || !g || !out || rank < 0 || rank >= g->world) return SLAM_ERR_INVALID_ARG;
+    *out = nullptr;
+    slam_comm* c = new (std::nothrow) slam_comm();
+    if (!c) return SLAM_ERR_HIP;
+    c->e = e;
+    c->rank = rank;
+    c->world = g->world;
+    c->group = g;
+    if (int rc = comm_common_init(c)) {
+        slam_comm_destroy(c);
+        return rc;
+    }
+    *out = c;
+    return SLAM_OK;
+}
+
+int slam_comm_rank(const slam_comm* c) { return c ? c->rank : -1; }
+int slam_comm_world(const slam_comm* c) { return c ? c->world : -1; }
+
+int slam_comm_destroy(slam_comm* c)
+{
+    if (!c) return SLAM_OK;
+    (void)hipSetDevice(c->e->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->nccl) (void)ncclCommDestroy(c->nccl);
+    for (hipEvent_t ev : { c->ev_fork, c->ev_join, c->ev_afork, c->ev_ajoin })
+        if (ev) (void)hipEventDestroy(ev);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return SLAM_OK;
+}
+
+}  // extern "C"

@@ -799,9 +799,16 @@ int slam_ancestors_sharded_dev(slam_engine* e, const int32_t* d_first_all, int64
     const uint32_t seq = ++e->plan_seq;
     HIP_TRY(launch_ancestors_sharded(e->stream, d_first_all, n_total, n_local, rank, world, e->shard_buf.as<int32_t>(),
                                      d_plan, d_src, d_pose_idx, e->d_hplan,
-                                     reinterpret_cast<uint32_t*>(e->d_hplan + SLAM_PLAN_WORDS(kMaxRanks)), seq));
+                                     reinterpret_cast<uint32_t*>(e->d_hplan + SLAM_PLAN_WORDS(kMaxRanks)), seq, e->exch_cap));
     e->shard_n = n_local;   // what slam_migrate_pack_dev will read
     e->plan_world = world;
+    return SLAM_OK;
+}
+
+int slam_exchange_set_capacity(slam_engine* e, int recv_capacity)
+{
+    ENTER(e);
+    e->exch_cap = recv_capacity > 0 ? recv_capacity : 0x7fffffff;
     return SLAM_OK;
 }
 

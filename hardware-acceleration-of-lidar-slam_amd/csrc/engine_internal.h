@@ -81,6 +81,7 @@ struct slam_engine {
     int32_t* d_hplan = nullptr;
     uint32_t plan_seq = 0;
     int plan_world = 0;
+    int exch_cap = 0x7fffffff;   // staging rows a rank can take in one exchange (slam_exchange_set_capacity)
     DevBuf scratch;            // per-call temporaries of the *_dev stages
     DevBuf bmax_buf;           // block maxima left by slam_logweight_dev (read by slam_quantise_scan_dev)
     int bmax_count = 0, bmax_n = -1;

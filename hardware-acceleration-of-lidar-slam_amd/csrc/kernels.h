@@ -125,7 +125,7 @@ int shard_scan_words(int n);   // int32 words of scratch the two launchers below
 // host_plan / host_flag / seq (optional): also deliver the plan to mapped pinned host memory and release `seq`
 hipError_t launch_ancestors_sharded(hipStream_t stream, const int32_t* first_all, int64_t n_total, int n, int rank,
                                     int world, int32_t* scratch, int32_t* plan, int32_t* src, int32_t* pose_idx,
-                                    int32_t* host_plan, uint32_t* host_flag, uint32_t seq);
+                                    int32_t* host_plan, uint32_t* host_flag, uint32_t seq, int recv_cap);
 hipError_t launch_migrate_pack(hipStream_t stream, const int32_t* scratch, int n, const MigratePlan& plan,
                                const float* pose, int64_t pose_ld, const float* map, int64_t row_stride,
                                int plane_stride, int nlandmarks, float* out);

@@ -5,9 +5,10 @@
 // reference anchor is the zero-noise motion step = the constant-velocity predict of
 // Subsystem_1/main.c:875-898.
 //
-// Data layout (HBM): particles are SoA float arrays; the per-particle landmark maps are five
-// planes [L][ld] (mu_x, mu_y, P_xx, P_xy, P_yy) with the particle index fastest, so a wavefront
-// reads/writes 64 consecutive particles of one landmark = 256 contiguous bytes per plane.
+// Data layout (HBM): particles are SoA float arrays; the landmark maps are ONE ROW PER PARTICLE,
+// [particle][5 planes: mu_x, mu_y, P_xx, P_xy, P_yy][plane_stride floats], so that a wavefront walking one
+// particle's landmarks moves 256 contiguous bytes per plane and access, and the offspring of one resample
+// ancestor (neighbouring particles) share its row through L2.
 // All kernels are HBM-streaming or latency-bound integer work; there is no GEMM shape here
 // (the largest matrix is 2x2), hence no MFMA.
 
@@ -777,7 +778,7 @@ __global__ __launch_bounds__(kBlock) void shard_plan_kernel(const int32_t* __res
                                                             int32_t* __restrict__ boff, int ntiles,
                                                             int32_t* __restrict__ plan, int32_t* __restrict__ rplan,
                                                             int32_t* __restrict__ host_plan,
-                                                            uint32_t* __restrict__ host_flag, uint32_t seq)
+                                                            uint32_t* __restrict__ host_flag, uint32_t seq, int recv_cap)
 {
     __shared__ int32_t s_part[kBlock];
     for (int y = 0; y < 2; ++y) {   // exclusive scan of the tile totals, kBlock-sized chunks with a running carry
@@ -810,6 +811,13 @@ __global__ __launch_bounds__(kBlock) void shard_plan_kernel(const int32_t* __res
         const int64_t aq = first_or_total(first_all, (int64_t)q * n, n_total);
         const int64_t bq = first_or_total(first_all, (int64_t)(q + 1) * n, n_total);
         s_any[q] = (q > 0 && aq != (int64_t)q * n) ? 1 : 0;   // a run boundary off a rank boundary: somebody exchanges
+        {   // could rank q's staging area overflow?  Decided from the boundary values alone, so that EVERY rank reaches
+            // the same verdict about EVERY rank: the slots of q with an ancestor on another rank bound what q receives
+            const int64_t q0 = (int64_t)q * n, q1 = q0 + n;
+            const int64_t l = aq > q0 ? aq : q0, h = bq < q1 ? bq : q1;
+            const int64_t local_slots = h > l ? h - l : 0;
+            if ((int64_t)n - local_slots > (int64_t)recv_cap) s_any[q] |= 2;
+        }
         // what I receive from q: my slots [lo, hi) descend from q's particles
         int64_t lo = aq > my_lo ? aq : my_lo, hi = bq < my_hi ? bq : my_hi;
         int32_t rcnt = 0, rbase = 0;
@@ -850,7 +858,7 @@ __global__ __launch_bounds__(kBlock) void shard_plan_kernel(const int32_t* __res
             host_plan[1 + 2 * world + q] = s_sbase[q];
         }
     }
-    plan[0] = anything;
+    plan[0] = anything;   // bit 0: somebody exchanges rows; bit 1: some rank's staging area might not hold them
     if (host_plan) {   // zero-copy delivery: the host polls the flag instead of a device-to-host copy + stream sync
         host_plan[0] = anything;
         __threadfence_system();
@@ -1106,7 +1114,7 @@ int shard_scan_words(int n) { const int t = (n + kShardTile - 1) / kShardTile; r
 // scratch (int32 words, shard_scan_words(n)): gsrc[n] | pfx[2][n] | boff[2][ntiles] | rplan[2*kMaxRanks]
 hipError_t launch_ancestors_sharded(hipStream_t stream, const int32_t* first_all, int64_t n_total, int n, int rank,
                                     int world, int32_t* scratch, int32_t* plan, int32_t* src, int32_t* pose_idx,
-                                    int32_t* host_plan, uint32_t* host_flag, uint32_t seq)
+                                    int32_t* host_plan, uint32_t* host_flag, uint32_t seq, int recv_cap)
 {
     if (n <= 0) return hipSuccess;
     const int ntiles = (n + kShardTile - 1) / kShardTile;
@@ -1117,7 +1125,7 @@ hipError_t launch_ancestors_sharded(hipStream_t stream, const int32_t* first_all
     shard_search_kernel<<<blocks_for(n), kBlock, 0, stream>>>(first_all, n_total, n, rank, gsrc);
     shard_flag_scan_kernel<<<dim3(ntiles, 2), kBlock, 0, stream>>>(first_all, n_total, n, rank, gsrc, pfx, boff, ntiles);
     shard_plan_kernel<<<1, kBlock, 0, stream>>>(first_all, n_total, n, rank, world, pfx, boff, ntiles, plan, rplan,
-                                                host_plan, host_flag, seq);
+                                                host_plan, host_flag, seq, recv_cap);
     ancestors_sharded_kernel<<<blocks_for(n), kBlock, 0, stream>>>(gsrc, pfx, boff, ntiles, rplan, n, rank, world, src,
                                                                    pose_idx);
     return hipGetLastError();

@@ -1,13 +1,20 @@
-// pf_session.hip — the slam_pf_* convenience object of include/slam_hip.h: device buffers + one frame per
-// call, built entirely on the public stage entry points (so it runs exactly what pf.py runs on one GPU).
-// No counterpart in the reference; specification: oracle/slam_oracle_pf.c.
+// pf_session.hip — the slam_pf_* session of include/slam_hip.h: device buffers + one whole frame per call, for a
+// plain C host.  One GPU (slam_pf_create) or one rank of a population sharded over several GPUs
+// (slam_pf_create_sharded): the frame is built on the public stage entry points either way, and in the sharded
+// form every exchange step between the ranks is issued from here through comm.h (RCCL over xGMI, or the
+// in-process transport) — nothing but this file sits between the launches.
+// No counterpart in the reference; specification: oracle/slam_oracle_pf.c; the shape
+// "handle created once in main and threaded through" is the reference's (Hadrware_acclereated.cpp:842-845, 284).
 
 #include <hip/hip_runtime.h>
+#include <stdio.h>
 #include <string.h>
 
 #include <new>
 #include <vector>
 
+#include "comm.h"
+#include "engine_internal.h"
 #include "kernels.h"
 
 using namespace slam;
@@ -17,7 +24,7 @@ struct slam_pf {
     slam_pf_config cfg{};
     int n = 0, L = 0;
     float* pose[2] = { nullptr, nullptr };     // [3][n] each
-    float* map[2] = { nullptr, nullptr };      // [n][5][Lp] each: one row per particle, planes padded to Lp floats
+    float* map[2] = { nullptr, nullptr };      // [cap][5][Lp] each: one row per particle, planes padded to Lp floats
     int Lp = 0;                                // plane stride: L rounded up to 32 floats (128-byte rows)
     int32_t* anc[2] = { nullptr, nullptr };
     float *score = nullptr, *logw = nullptr;
@@ -27,18 +34,106 @@ struct slam_pf {
     int map_cur = 0;   // map buffer holding the current maps (flips only when the maps are rewritten)
     bool has_anc = false;
     uint32_t frame = 0;
+
+    // ---- sharded form (comm != nullptr): this rank holds particles [rank*n, (rank+1)*n) of world*n
+    slam_comm* comm = nullptr;
+    int rank = 0, world = 1, recv_cap = 0, cap = 0;   // cap = n + recv_cap rows per map buffer (staging tail)
+    int64_t n_total = 0;
+    float* pose_all = nullptr;      // [world][x|y|theta][n]: every rank's poses, all-gathered each frame beside the EKF
+    float* pose_stage = nullptr;    // [3][cap]: where the poses inside migrated records land (nothing reads them)
+    int32_t* pose_idx[2] = { nullptr, nullptr };   // position of every slot's ancestor in pose_all
+    int32_t* first_all = nullptr;   // [n_total]
+    float* d_max = nullptr;         // weight normaliser (all-reduced)
+    uint64_t *d_sum = nullptr, *totals = nullptr;   // shard total; all-gathered shard totals [world]
+    int32_t* d_plan = nullptr;      // exchange plan of the frame, device copy
+    float *sbuf = nullptr, *rbuf = nullptr;   // grow-only exchange buffers
+    size_t sbuf_floats = 0, rbuf_floats = 0;
+    float* cand = nullptr;          // [world][5] best-particle candidates
+    bool exchange_pending = false;  // resample done, map rows not exchanged yet
+    int rows_received = 0;
 };
 
 namespace {
 
-// the engine's stream, obtained through the public API only
 hipError_t dev_alloc(void** p, size_t bytes) { return hipMalloc(p, bytes ? bytes : 4); }
 
-int gathered_copy_out(slam_pf* pf, const float* d_src, float* h_dst, float* d_tmp)
+int grow(slam_pf* pf, float** buf, size_t* have, size_t want)
 {
-    // d_src: n floats; apply the pending gather on the device, then copy back
-    if (pf->has_anc) {
-        int rc = slam_gather_f32_dev(pf->e, d_src, pf->anc[pf->cur], pf->n, d_tmp);
+    if (want <= *have) return SLAM_OK;
+    slam_engine* e = pf->e;
+    SLAM_HIP_TRY(e, hipStreamSynchronize(e->stream));   // an exchange still in flight may read the old buffer
+    const size_t cap = want > 2 * *have ? want + want / 2 : 2 * *have;
+    if (*buf) (void)hipFree(*buf);
+    *buf = nullptr;
+    *have = 0;
+    SLAM_HIP_TRY(e, hipMalloc((void**)buf, cap * sizeof(float)));
+    *have = cap;
+    return SLAM_OK;
+}
+
+// Map rows (and poses) of ancestors that live on another rank -> the staging tail of the current buffers, where
+// the next EKF's fused gather picks them up.  pack (one launch) -> one grouped send/recv -> unpack (one launch).
+// A remote ancestor travels once per destination rank, however many slots there descend from it.
+int migrate(slam_pf* pf)
+{
+    slam_engine* e = pf->e;
+    const int G = pf->world, n = pf->n, L = pf->L;
+    int32_t plan[SLAM_PLAN_WORDS(kMaxRanks)];
+    // the one point of a frame where the host waits for the device (a flag in mapped memory, no copy, no stream sync)
+    if (int rc = slam_exchange_plan_host(e, G, plan)) return rc;
+    if (plan[0] & 2) {   // the same verdict on every rank: all refuse the frame together
+        snprintf(e->err, sizeof e->err, "exchange might exceed recv_capacity %d on some rank", pf->recv_cap);
+        return SLAM_ERR_CAPACITY;
+    }
+    pf->rows_received = 0;
+    if (!(plan[0] & 1) && G > 1) return SLAM_OK;   // every run boundary coincides with a rank boundary: all ranks skip
+    const int32_t *scnt = plan + 1, *rcnt = plan + 1 + G;
+    int64_t stot = 0, rtot = 0, sfl[kMaxRanks], rfl[kMaxRanks];
+    const int64_t rec = 3 + 5 * (int64_t)L;
+    for (int q = 0; q < G; ++q) {
+        stot += scnt[q];
+        rtot += rcnt[q];
+        sfl[q] = rec * scnt[q];
+        rfl[q] = rec * rcnt[q];
+    }
+    if (rtot > pf->recv_cap) return SLAM_ERR_CAPACITY;   // cannot happen: bit 1 above bounds it
+    pf->rows_received = (int)rtot;
+    if (int rc = grow(pf, &pf->sbuf, &pf->sbuf_floats, (size_t)(rec * stot))) return rc;
+    if (int rc = grow(pf, &pf->rbuf, &pf->rbuf_floats, (size_t)(rec * rtot))) return rc;
+    const float* mp = L ? pf->map[pf->map_cur] : nullptr;
+    if (stot)
+        if (int rc = slam_migrate_pack_dev(e, n, pf->rank, G, plan, pf->pose[pf->cur], n, mp, 5 * (int64_t)pf->Lp, pf->Lp, L,
+                                           pf->sbuf))
+            return rc;
+    if (int rc = comm_all_to_all_f32(pf->comm, pf->sbuf, sfl, pf->rbuf, rfl)) return rc;
+    if (rtot)
+        if (int rc = slam_migrate_unpack_dev(e, pf->rbuf, G, rcnt, n, pf->pose_stage, pf->cap,
+                                             L ? pf->map[pf->map_cur] : nullptr, 5 * (int64_t)pf->Lp, pf->Lp, L))
+            return rc;
+    return SLAM_OK;
+}
+
+int finish_exchange(slam_pf* pf)
+{
+    if (!pf->exchange_pending) return SLAM_OK;
+    pf->exchange_pending = false;
+    return migrate(pf);
+}
+
+// set_poses / set_map / reset discard the pending resample gather: nothing of it may run later
+int drop_resample(slam_pf* pf)
+{
+    pf->has_anc = false;
+    pf->exchange_pending = false;
+    if (pf->comm) return comm_all_gather_finish(pf->comm);
+    return SLAM_OK;
+}
+
+int gathered_copy_out(slam_pf* pf, const float* d_src, const int32_t* idx, float* h_dst, float* d_tmp)
+{
+    // d_src gathered through idx on the device (idx == nullptr: as is), then copied back
+    if (idx) {
+        int rc = slam_gather_f32_dev(pf->e, d_src, idx, pf->n, d_tmp);
         if (rc != SLAM_OK) return rc;
         d_src = d_tmp;
     }
@@ -48,15 +143,12 @@ int gathered_copy_out(slam_pf* pf, const float* d_src, float* h_dst, float* d_tm
                                                                                                       : SLAM_ERR_HIP;
 }
 
-}  // namespace
-
-extern "C" {
-
-int slam_pf_create(slam_engine* e, const slam_pf_config* cfg, slam_pf** out)
+int create_common(slam_engine* e, const slam_pf_config* cfg, slam_comm* comm, int recv_capacity, slam_pf** out)
 {
     if (!e || !cfg || !out || cfg->n_particles <= 0 || cfg->n_landmarks < 0 || !(cfg->meas_var > 0.0f))
         return SLAM_ERR_INVALID_ARG;
     *out = nullptr;
+    if (comm && comm_engine(comm) != e) return SLAM_ERR_INVALID_ARG;
     if (int rc = slam_engine_sync(e)) return rc;   // also selects the engine's device
     slam_pf* pf = new (std::nothrow) slam_pf();
     if (!pf) return SLAM_ERR_HIP;
@@ -65,41 +157,90 @@ int slam_pf_create(slam_engine* e, const slam_pf_config* cfg, slam_pf** out)
     pf->n = cfg->n_particles;
     pf->L = cfg->n_landmarks;
     pf->Lp = (pf->L + 31) / 32 * 32;
-    const size_t n = (size_t)pf->n, L = (size_t)pf->L, Lp = (size_t)pf->Lp;
+    pf->comm = comm;
+    if (comm) {
+        pf->rank = comm_rank(comm);
+        pf->world = comm_world(comm);
+        pf->recv_cap = recv_capacity > 0 && recv_capacity < pf->n ? recv_capacity : pf->n;
+    }
+    pf->cap = pf->n + pf->recv_cap;
+    pf->n_total = (int64_t)pf->n * pf->world;
+    if (3 * pf->n_total > 0x7fffffff) {   // int32 ancestor indices into the all-gathered pose array
+        delete pf;
+        return SLAM_ERR_CAPACITY;
+    }
+    const size_t n = (size_t)pf->n, L = (size_t)pf->L, Lp = (size_t)pf->Lp, cap = (size_t)pf->cap, G = (size_t)pf->world;
     bool ok = true;
     for (int b = 0; b < 2; ++b) {
         ok = ok && dev_alloc((void**)&pf->pose[b], 3 * n * 4) == hipSuccess;
         ok = ok && dev_alloc((void**)&pf->anc[b], n * 4) == hipSuccess;
-        if (L) ok = ok && dev_alloc((void**)&pf->map[b], 5 * Lp * n * 4) == hipSuccess;
+        if (L) ok = ok && dev_alloc((void**)&pf->map[b], 5 * Lp * cap * 4) == hipSuccess;
+        if (comm) ok = ok && dev_alloc((void**)&pf->pose_idx[b], n * 4) == hipSuccess;
     }
     ok = ok && dev_alloc((void**)&pf->score, n * 4) == hipSuccess && dev_alloc((void**)&pf->logw, n * 4) == hipSuccess &&
          dev_alloc((void**)&pf->count, n * 4) == hipSuccess && dev_alloc((void**)&pf->first, n * 4) == hipSuccess &&
          dev_alloc((void**)&pf->best_idx, 4) == hipSuccess && dev_alloc((void**)&pf->best_val, 4) == hipSuccess;
+    if (comm)
+        ok = ok && dev_alloc((void**)&pf->pose_all, 3 * n * G * 4) == hipSuccess &&
+             dev_alloc((void**)&pf->pose_stage, 3 * cap * 4) == hipSuccess &&
+             dev_alloc((void**)&pf->first_all, n * G * 4) == hipSuccess && dev_alloc((void**)&pf->d_max, 4) == hipSuccess &&
+             dev_alloc((void**)&pf->d_sum, 8) == hipSuccess && dev_alloc((void**)&pf->totals, 8 * G) == hipSuccess &&
+             dev_alloc((void**)&pf->d_plan, 4 * SLAM_PLAN_WORDS(kMaxRanks)) == hipSuccess &&
+             dev_alloc((void**)&pf->cand, 4 * 5 * G) == hipSuccess;
     if (!ok) {
         (void)hipGetLastError();
         slam_pf_destroy(pf);
         return SLAM_ERR_HIP;
     }
-    *out = pf;
+    if (comm)
+        if (int rc = slam_exchange_set_capacity(e, pf->recv_cap)) {
+            slam_pf_destroy(pf);
+            return rc;
+        }
     const float origin[3] = { 0, 0, 0 };
-    return slam_pf_reset(pf, origin);
+    if (int rc = slam_pf_reset(pf, origin)) {   // a failed reset must not hand back a live object with an error code
+        slam_pf_destroy(pf);
+        return rc;
+    }
+    *out = pf;
+    return SLAM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int slam_pf_create(slam_engine* e, const slam_pf_config* cfg, slam_pf** out)
+{
+    return create_common(e, cfg, nullptr, 0, out);
+}
+
+int slam_pf_create_sharded(slam_engine* e, const slam_pf_config* cfg, slam_comm* comm, int recv_capacity, slam_pf** out)
+{
+    if (!comm) return SLAM_ERR_INVALID_ARG;
+    return create_common(e, cfg, comm, recv_capacity, out);
 }
 
 int slam_pf_destroy(slam_pf* pf)
 {
     if (!pf) return SLAM_OK;
     (void)slam_engine_sync(pf->e);
+    if (pf->comm) {
+        (void)comm_all_gather_finish(pf->comm);
+        (void)slam_engine_sync(pf->e);
+        (void)slam_exchange_set_capacity(pf->e, 0);
+    }
     for (int b = 0; b < 2; ++b) {
         (void)hipFree(pf->pose[b]);
         (void)hipFree(pf->anc[b]);
         (void)hipFree(pf->map[b]);
+        (void)hipFree(pf->pose_idx[b]);
     }
-    (void)hipFree(pf->score);
-    (void)hipFree(pf->logw);
-    (void)hipFree(pf->count);
-    (void)hipFree(pf->first);
-    (void)hipFree(pf->best_idx);
-    (void)hipFree(pf->best_val);
+    for (void* p : { (void*)pf->score, (void*)pf->logw, (void*)pf->count, (void*)pf->first, (void*)pf->best_idx,
+                     (void*)pf->best_val, (void*)pf->pose_all, (void*)pf->pose_stage, (void*)pf->first_all,
+                     (void*)pf->d_max, (void*)pf->d_sum, (void*)pf->totals, (void*)pf->d_plan, (void*)pf->sbuf,
+                     (void*)pf->rbuf, (void*)pf->cand })
+        (void)hipFree(p);
     delete pf;
     return SLAM_OK;
 }
@@ -111,17 +252,23 @@ int slam_pf_reset(slam_pf* pf, const float pose[3])
     std::vector<float> h(3 * n);
     for (int k = 0; k < 3; ++k)
         for (size_t i = 0; i < n; ++i) h[k * n + i] = pose[k];
+    if (int rc = drop_resample(pf)) return rc;
     if (int rc = slam_engine_sync(pf->e)) return rc;
     if (hipMemcpy(pf->pose[pf->cur], h.data(), 3 * n * 4, hipMemcpyHostToDevice) != hipSuccess) return SLAM_ERR_HIP;
     if (pf->L) {   // P_xx = -1: "not seen yet"
         const size_t Lp = (size_t)pf->Lp;
-        std::vector<float> m(5 * Lp * n, 0.0f);
-        for (size_t i = 0; i < n; ++i)
-            for (size_t l = 0; l < Lp; ++l) m[(5 * i + 2) * Lp + l] = -1.0f;
-        if (hipMemcpy(pf->map[pf->map_cur], m.data(), m.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
-            return SLAM_ERR_HIP;
+        std::vector<float> row(5 * Lp, 0.0f);
+        for (size_t l = 0; l < Lp; ++l) row[2 * Lp + l] = -1.0f;
+        // one row on the host, replicated over the particles in chunks (a 52 GB map does not pass through host memory)
+        const size_t chunk = n < 4096 ? n : 4096;
+        std::vector<float> m(5 * Lp * chunk);
+        for (size_t i = 0; i < chunk; ++i) memcpy(&m[i * 5 * Lp], row.data(), 5 * Lp * 4);
+        for (size_t i0 = 0; i0 < n; i0 += chunk) {
+            const size_t k = n - i0 < chunk ? n - i0 : chunk;
+            if (hipMemcpy(pf->map[pf->map_cur] + i0 * 5 * Lp, m.data(), k * 5 * Lp * 4, hipMemcpyHostToDevice) != hipSuccess)
+                return SLAM_ERR_HIP;
+        }
     }
-    pf->has_anc = false;
     pf->frame = 0;
     return SLAM_OK;
 }
@@ -130,13 +277,13 @@ int slam_pf_set_poses_host(slam_pf* pf, const float* x, const float* y, const fl
 {
     if (!pf || !x || !y || !theta) return SLAM_ERR_INVALID_ARG;
     const size_t n = (size_t)pf->n;
+    if (int rc = drop_resample(pf)) return rc;
     if (int rc = slam_engine_sync(pf->e)) return rc;
     float* d = pf->pose[pf->cur];
     if (hipMemcpy(d, x, n * 4, hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(d + n, y, n * 4, hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(d + 2 * n, theta, n * 4, hipMemcpyHostToDevice) != hipSuccess)
         return SLAM_ERR_HIP;
-    pf->has_anc = false;
     return SLAM_OK;
 }
 
@@ -156,22 +303,44 @@ int slam_pf_step(slam_pf* pf, int slot, const float dp[3], int use_observations)
 {
     if (!pf || !dp) return SLAM_ERR_INVALID_ARG;
     slam_engine* e = pf->e;
+    slam_comm* comm = pf->comm;
     const int n = pf->n, L = pf->L, cur = pf->cur, nxt = 1 - cur;
     const size_t sn = (size_t)n;
     const float* src = pf->pose[cur];
     float* dst = pf->pose[nxt];
     const int32_t* anc = pf->has_anc ? pf->anc[cur] : nullptr;
-    int rc = slam_motion_score_dev(e, slot, src, src + sn, src + 2 * sn, anc, dst, dst + sn, dst + 2 * sn, n, 0, dp,
+    const int64_t first_id = (int64_t)pf->rank * n;
+    int rc;
+    // 1 + 2. motion (+ the fused gather of the previous resample) and scan-match score, one launch.  Sharded: the
+    // ancestors' poses come out of the array of every rank's poses, so this launch needs nothing from the exchange
+    // below and keeps the GPU busy while the host picks up the exchange plan.
+    if (comm && pf->has_anc) {
+        if ((rc = comm_all_gather_finish(comm)) != SLAM_OK) return rc;
+        const float* pa = pf->pose_all;
+        rc = slam_motion_score_dev(e, slot, pa, pa + sn, pa + 2 * sn, pf->pose_idx[cur], dst, dst + sn, dst + 2 * sn, n,
+                                   first_id, dp, pf->cfg.sigma, pf->cfg.seed, pf->frame, pf->score, pf->count);
+    } else {
+        rc = slam_motion_score_dev(e, slot, src, src + sn, src + 2 * sn, anc, dst, dst + sn, dst + 2 * sn, n, first_id, dp,
                                    pf->cfg.sigma, pf->cfg.seed, pf->frame, pf->score, pf->count);
+    }
     if (rc != SLAM_OK) return rc;
+    if (comm) {
+        // map rows of remote ancestors -> staging tail; issued behind the launch above, which does not need them
+        if ((rc = finish_exchange(pf)) != SLAM_OK) return rc;
+        // this frame's poses to every rank, for the next frame's motion + score: runs beside the EKF.  Collectives of a
+        // communicator run in issue order: after the exchange (the EKF waits for that one), before the all-reduce.
+        if ((rc = comm_all_gather_begin(comm, dst, pf->pose_all, 3 * sn * sizeof(float))) != SLAM_OK) return rc;
+    }
+    // 3. per-landmark EKF (+ fused gather); the log-likelihood stays inside the engine for step 4
     const bool ekf = L > 0 && use_observations;
     const int mc = pf->map_cur, mn = 1 - mc;
+    float* d_max = comm ? pf->d_max : nullptr;
     if (ekf) {
         rc = slam_ekf_update_dev(e, pf->map[mc], pf->map[mn], 5 * (int64_t)pf->Lp, pf->Lp, L, dst, dst + sn, dst + 2 * sn, anc, n,
                                  pf->cfg.meas_var, nullptr);
         if (rc != SLAM_OK) return rc;
         pf->map_cur = mn;
-        rc = slam_logweight_ekf_dev(e, pf->score, pf->cfg.score_gain, n, pf->logw, nullptr);
+        rc = slam_logweight_ekf_dev(e, pf->score, pf->cfg.score_gain, n, pf->logw, d_max);
     } else {
         if (L > 0 && anc) {   // the maps follow their particles even without an observation
             rc = slam_gather_map_dev(e, pf->map[mc], pf->map[mn], 5 * (int64_t)pf->Lp, 5 * (int64_t)pf->Lp, pf->Lp, pf->Lp, L,
@@ -179,34 +348,86 @@ int slam_pf_step(slam_pf* pf, int slot, const float dp[3], int use_observations)
             if (rc != SLAM_OK) return rc;
             pf->map_cur = mn;
         }
-        rc = slam_logweight_dev(e, pf->score, nullptr, pf->cfg.score_gain, n, pf->logw, nullptr);
+        rc = slam_logweight_dev(e, pf->score, nullptr, pf->cfg.score_gain, n, pf->logw, d_max);
     }
     if (rc != SLAM_OK) return rc;
-    if ((rc = slam_quantise_scan_dev(e, pf->logw, nullptr, n, nullptr)) != SLAM_OK) return rc;
-    if ((rc = slam_ancestors_from_scan_dev(e, n, pf->cfg.seed, pf->frame, pf->anc[nxt])) != SLAM_OK) return rc;
+    // 4. weights: the maximum over all ranks, then fixed-point weights scanned as they are produced
+    if (comm && (rc = comm_all_reduce_max_f32(comm, pf->d_max, 1)) != SLAM_OK) return rc;
+    if ((rc = slam_quantise_scan_dev(e, pf->logw, d_max, n, comm ? pf->d_sum : nullptr)) != SLAM_OK) return rc;
+    // 5. resample on the integer CDF
+    if (!comm) {
+        if ((rc = slam_ancestors_from_scan_dev(e, n, pf->cfg.seed, pf->frame, pf->anc[nxt])) != SLAM_OK) return rc;
+    } else {
+        if ((rc = comm_all_gather(comm, pf->d_sum, pf->totals, sizeof(uint64_t))) != SLAM_OK) return rc;
+        if ((rc = slam_offspring_from_scan_sharded_dev(e, n, pf->totals, pf->rank, pf->world, pf->cfg.seed, pf->frame,
+                                                       pf->n_total, pf->first)) != SLAM_OK)
+            return rc;
+        // the "all-gather of surviving indices": 4 B x N_total
+        if ((rc = comm_all_gather(comm, pf->first, pf->first_all, sn * sizeof(int32_t))) != SLAM_OK) return rc;
+        // 6. gather index of every slot (remote ancestors -> rows of the staging tail) and the exchange plan, on the
+        // device; the exchange itself happens at the start of the next frame, behind its motion + score launch
+        if ((rc = slam_ancestors_sharded_dev(e, pf->first_all, pf->n_total, n, pf->rank, pf->world, pf->anc[nxt], pf->d_plan,
+                                             pf->pose_idx[nxt])) != SLAM_OK)
+            return rc;
+        pf->exchange_pending = true;
+    }
     pf->cur = nxt;
     pf->has_anc = true;
     pf->frame++;
     return SLAM_OK;
 }
 
+int slam_pf_rows_received(const slam_pf* pf) { return pf ? pf->rows_received : 0; }
+
+int slam_pf_device_view(slam_pf* pf, slam_pf_view* out)
+{
+    if (!pf || !out) return SLAM_ERR_INVALID_ARG;
+    out->pose = pf->pose[pf->cur];
+    out->map = pf->L ? pf->map[pf->map_cur] : nullptr;
+    out->map_spare = pf->L ? pf->map[1 - pf->map_cur] : nullptr;
+    out->anc = pf->has_anc ? pf->anc[pf->cur] : nullptr;
+    out->row_stride = 5 * (int64_t)pf->Lp;
+    out->plane_stride = pf->Lp;
+    out->map_rows = pf->cap;
+    return SLAM_OK;
+}
+
 int slam_pf_best(slam_pf* pf, float pose[3], float* logw, int32_t* index)
 {
     if (!pf || !pose) return SLAM_ERR_INVALID_ARG;
+    slam_engine* e = pf->e;
     // the log-weights of the last frame belong to pose[cur] BEFORE the pending gather
-    int rc = slam_argmax_dev(pf->e, pf->logw, pf->n, pf->best_idx, pf->best_val);
+    int rc = slam_argmax_dev(e, pf->logw, pf->n, pf->best_idx, pf->best_val);
     if (rc != SLAM_OK) return rc;
-    if ((rc = slam_engine_sync(pf->e)) != SLAM_OK) return rc;
+    if ((rc = slam_engine_sync(e)) != SLAM_OK) return rc;
     int32_t idx = 0;
     float val = 0;
     if (hipMemcpy(&idx, pf->best_idx, 4, hipMemcpyDeviceToHost) != hipSuccess ||
         hipMemcpy(&val, pf->best_val, 4, hipMemcpyDeviceToHost) != hipSuccess)
         return SLAM_ERR_HIP;
     const float* p = pf->pose[pf->cur];
+    float mine[5] = { val, 0, 0, 0, 0 };
     for (int k = 0; k < 3; ++k)
-        if (hipMemcpy(&pose[k], p + (size_t)k * pf->n + idx, 4, hipMemcpyDeviceToHost) != hipSuccess) return SLAM_ERR_HIP;
-    if (logw) *logw = val;
-    if (index) *index = idx;
+        if (hipMemcpy(&mine[2 + k], p + (size_t)k * pf->n + idx, 4, hipMemcpyDeviceToHost) != hipSuccess) return SLAM_ERR_HIP;
+    int32_t gid = (int32_t)((int64_t)pf->rank * pf->n + idx);
+    if (pf->comm) {   // every rank's candidate to every rank; the first maximum = the lowest rank = the lowest id
+        memcpy(&mine[1], &gid, 4);
+        float* mine_dev = pf->pose_stage;   // scratch
+        SLAM_HIP_TRY(e, hipMemcpyAsync(mine_dev, mine, sizeof mine, hipMemcpyHostToDevice, e->stream));
+        SLAM_HIP_TRY(e, hipStreamSynchronize(e->stream));
+        if ((rc = comm_all_gather(pf->comm, mine_dev, pf->cand, sizeof mine)) != SLAM_OK) return rc;
+        std::vector<float> all(5 * (size_t)pf->world);
+        SLAM_HIP_TRY(e, hipMemcpyAsync(all.data(), pf->cand, all.size() * 4, hipMemcpyDeviceToHost, e->stream));
+        SLAM_HIP_TRY(e, hipStreamSynchronize(e->stream));
+        int best = 0;
+        for (int q = 1; q < pf->world; ++q)
+            if (all[5 * q] > all[5 * best]) best = q;
+        memcpy(mine, &all[5 * best], sizeof mine);
+        memcpy(&gid, &mine[1], 4);
+    }
+    for (int k = 0; k < 3; ++k) pose[k] = mine[2 + k];
+    if (logw) *logw = mine[0];
+    if (index) *index = gid;
     return SLAM_OK;
 }
 
@@ -214,11 +435,17 @@ int slam_pf_get_poses_host(slam_pf* pf, float* x, float* y, float* theta)
 {
     if (!pf || !x || !y || !theta) return SLAM_ERR_INVALID_ARG;
     const size_t n = (size_t)pf->n;
-    const float* p = pf->pose[pf->cur];
     float* tmp = pf->pose[1 - pf->cur];   // the other buffer is free between frames
     float* out[3] = { x, y, theta };
+    if (pf->comm && pf->has_anc) {   // the ancestors' poses are in the all-gathered array
+        if (int rc = comm_all_gather_finish(pf->comm)) return rc;
+        for (int k = 0; k < 3; ++k)
+            if (int rc = gathered_copy_out(pf, pf->pose_all + k * n, pf->pose_idx[pf->cur], out[k], tmp)) return rc;
+        return SLAM_OK;
+    }
+    const float* p = pf->pose[pf->cur];
     for (int k = 0; k < 3; ++k)
-        if (int rc = gathered_copy_out(pf, p + k * n, out[k], tmp)) return rc;
+        if (int rc = gathered_copy_out(pf, p + k * n, pf->has_anc ? pf->anc[pf->cur] : nullptr, out[k], tmp)) return rc;
     return SLAM_OK;
 }
 
@@ -226,6 +453,8 @@ int slam_pf_get_map_host(slam_pf* pf, float* rows)
 {
     if (!pf || !rows || !pf->L) return SLAM_ERR_INVALID_ARG;
     const size_t n = (size_t)pf->n, L = (size_t)pf->L, Lp = (size_t)pf->Lp;
+    if (pf->comm)
+        if (int rc = finish_exchange(pf)) return rc;   // collective: remote ancestors' rows into the staging tail
     const float* src = pf->map[pf->map_cur];
     if (pf->has_anc) {
         int rc = slam_gather_map_dev(pf->e, pf->map[pf->map_cur], pf->map[1 - pf->map_cur], 5 * (int64_t)Lp,

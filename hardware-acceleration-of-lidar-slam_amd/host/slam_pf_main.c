@@ -1,5 +1,5 @@
 /*
- * slam_pf_main — particle-filter form of the reference's SLAM program, host code in C.
+ * slam_pf_main — particle-filter form of the reference's SLAM program, host code in C, one or several GPUs.
  *
  * Same scan-frame CSV input and the same pose / map outputs as Subsystem_1/main_accelerated.c
  * ("scan N", "pose = %f  %f  %f" on stdout, "%f,%f" map lines; main.c:22-30, :860, :965, :982-985), and the
@@ -10,12 +10,23 @@
  * weights are normalised and the population is resampled; the frame's pose is the mean of the resampled
  * (hence equally weighted) population, accumulated in double in index order — or, with estimator "best", the
  * heaviest particle.
- * All of it goes through the C ABI (slam_pf_* in include/slam_hip.h); no HIP type appears here.
+ * All of it goes through the C ABI (slam_pf_* in include/slam_hip.h); no HIP or RCCL type appears here.
+ *
+ * Several GPUs: the accelerator handle is created once per GPU and threaded through, the shape of the reference's
+ * FPGA host (Submodule_2/Hadrware_acclereated.cpp:842-845, 284): one host thread per GPU owns one engine, one
+ * communicator and one sharded session, runs this same frame loop, and the engine issues every exchange between
+ * the GPUs itself (RCCL over xGMI).  The population is split in contiguous blocks; the output does not depend on
+ * the number of GPUs (bit for bit: pose log and map file).
  *
  * usage: slam_pf_main dataset.csv frames beams map_out.csv particles [seed [mean|best]]
+ *                     [--gpus N] [--transport rccl|local] [--same-device]
+ *   particles      the whole population (a multiple of N)
+ *   --transport    rccl (default when N > 1): RCCL, one GPU per rank.  local: the in-process transport.
+ *   --same-device  every rank on device 0 (only with the local transport; RCCL refuses two ranks on one GPU)
  */
 #define _POSIX_C_SOURCE 200809L
 #include <math.h>
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -30,56 +41,83 @@ static double now_s(void)
     return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
 }
 
-#define CHECK(call)                                                                                         \
-    do {                                                                                                    \
-        int rc__ = (call);                                                                                  \
-        if (rc__ != SLAM_OK) {                                                                              \
-            fprintf(stderr, "%s failed: %s (%s)\n", #call, slam_status_string(rc__), slam_last_error(eng)); \
-            return 1;                                                                                       \
-        }                                                                                                   \
+typedef struct {
+    /* the run */
+    const char *dataset, *map_out;
+    int frames, beams, particles_total, use_mean;
+    unsigned long long seed;
+    /* the ranks */
+    int world, use_rccl, same_device;
+    uint8_t comm_id[SLAM_COMM_ID_BYTES];
+    slam_local_group *group;
+    pthread_barrier_t barrier;
+    float *px, *py, *pt;   /* [particles_total] host copies of the population, one block per rank (mean estimator) */
+} run_t;
+
+typedef struct {
+    run_t *run;
+    int rank, rc;
+} rank_t;
+
+#define CHECK(call)                                                                                               \
+    do {                                                                                                          \
+        int rc__ = (call);                                                                                        \
+        if (rc__ != SLAM_OK) {                                                                                    \
+            fprintf(stderr, "rank %d: %s failed: %s (%s)\n", rank, #call, slam_status_string(rc__),                \
+                    eng ? slam_last_error(eng) : "");                                                             \
+            goto fail;                                                                                            \
+        }                                                                                                         \
     } while (0)
 
-int main(int argc, char **argv)
+static void rendezvous(run_t *run)
 {
-    if (argc < 6) {
-        fprintf(stderr, "usage: %s dataset.csv frames beams map_out.csv particles [seed]\n", argv[0]);
-        return 2;
-    }
-    FILE *in = fopen(argv[1], "r");
-    if (!in) { perror(argv[1]); return 1; }
-    const int frames = atoi(argv[2]);
-    const int beams = atoi(argv[3]);
-    const int particles = atoi(argv[5]);
-    const unsigned long long seed = argc > 6 ? strtoull(argv[6], NULL, 10) : 1;
-    const int use_mean = !(argc > 7 && strcmp(argv[7], "best") == 0);
-    float *px = (float *)calloc((size_t)particles, sizeof(float)), *py = (float *)calloc((size_t)particles, sizeof(float)),
-          *pt = (float *)calloc((size_t)particles, sizeof(float));
+    if (run->world > 1) pthread_barrier_wait(&run->barrier);
+}
 
+static void *rank_main(void *arg)
+{
+    rank_t *me = (rank_t *)arg;
+    run_t *run = me->run;
+    const int rank = me->rank, world = run->world;
+    const int beams = run->beams, frames = run->frames;
+    const int n = run->particles_total / world, n_total = run->particles_total;
     const float border = 1, pixel_coarse = 0.2f, pixel_fine = 0.1f;   /* main.c:834-836 */
     const float key_dt = 0.3f, key_dr = 0.0872665f, edt_cap = 10;     /* main.c:838-839, :224 */
-
     slam_engine *eng = NULL;
+    slam_comm *comm = NULL;
+    slam_pf *pf = NULL;
+    FILE *in = NULL;
+    float *hits = NULL;
+    fe_scan scan = { 0 };
+    fe_points map = { 0 }, local = { 0 };
+    fe_grid coarse = { 0 }, fine = { 0 };
+    me->rc = 1;
+
+    in = fopen(run->dataset, "r");   /* every rank reads the (small) scan stream itself: no host-side broadcast */
+    if (!in) { perror(run->dataset); goto fail; }
     {
-        int rc = slam_engine_create(0, &eng);
+        int rc = slam_engine_create(run->same_device ? 0 : rank, &eng);
         if (rc != SLAM_OK) {
-            fprintf(stderr, "slam_engine_create: %s\n", slam_status_string(rc));
-            return 1;
+            fprintf(stderr, "rank %d: slam_engine_create: %s\n", rank, slam_status_string(rc));
+            eng = NULL;
+            goto fail;
         }
     }
-    slam_pf *pf = NULL;
     /* motion noise of the order of the reference's fine lattice step (0.025 m, 0.004363 rad; main.c:833) */
-    const slam_pf_config cfg = { particles, 0, { 0.01f, 0.01f, 0.002f }, 1.0f, 0.25f, seed };
-    CHECK(slam_pf_create(eng, &cfg, &pf));
-
-    fe_scan scan;
-    fe_points map, local;
-    fe_grid coarse, fine;
-    if (fe_scan_init(&scan, beams, -2.351831f, 0.004363f) || fe_points_init(&map, FE_MAP_CAPACITY + beams) ||
-        fe_points_init(&local, FE_LOCAL_CAPACITY) || fe_grid_init(&coarse, FE_COARSE_LD) || fe_grid_init(&fine, FE_FINE_LD)) {
-        fprintf(stderr, "out of memory\n");
-        return 1;
+    const slam_pf_config cfg = { n, 0, { 0.01f, 0.01f, 0.002f }, 1.0f, 0.25f, run->seed };
+    if (world > 1 || run->use_rccl || run->group) {
+        if (run->group) CHECK(slam_comm_create_local(eng, run->group, rank, &comm));
+        else CHECK(slam_comm_create_rccl(eng, rank, world, run->comm_id, &comm));
+        CHECK(slam_pf_create_sharded(eng, &cfg, comm, 0, &pf));
+    } else {
+        CHECK(slam_pf_create(eng, &cfg, &pf));
     }
-    float *hits = (float *)calloc((size_t)beams + 1, sizeof(float));
+    if (fe_scan_init(&scan, beams, -2.351831f, 0.004363f) || fe_points_init(&map, FE_MAP_CAPACITY + beams) ||
+        fe_points_init(&local, FE_LOCAL_CAPACITY) || fe_grid_init(&coarse, FE_COARSE_LD) || fe_grid_init(&fine, FE_FINE_LD) ||
+        !(hits = (float *)calloc((size_t)beams + 1, sizeof(float)))) {
+        fprintf(stderr, "rank %d: out of memory\n", rank);
+        goto fail;
+    }
     int32_t nhits = 0;
     double t_step = 0;
     const double t_begin = now_s();
@@ -96,18 +134,18 @@ int main(int argc, char **argv)
     int mini_updated = 1;
 
     for (int k = 1; k < frames; ++k) {
-        printf("scan %d\n", k + 1);
+        if (rank == 0) printf("scan %d\n", k + 1);
         fe_read_frame(in, &scan);
         fe_clean(&scan, 0.023f, 24);
         CHECK(slam_scan_upload_host(eng, scan.bx, scan.by, scan.nscan));
         int in_world = 0;
-        if (mini_updated) {
+        if (mini_updated) {   /* map, rasters and EDTs are replicated on every GPU (<= 16 MiB) */
             fe_to_world(&scan, pose);
             in_world = 1;
             fe_crop(&map, &scan, border, &local);
             if (fe_rasterise(&local, pixel_coarse, &coarse) || fe_rasterise(&local, pixel_fine, &fine)) {
                 fprintf(stderr, "frame %d: map extent exceeds the grids\n", k + 1);
-                return 1;
+                goto fail;
             }
             CHECK(slam_grid_upload_host(eng, 0, coarse.cell, &coarse.meta, edt_cap, NULL));
             CHECK(slam_grid_upload_host(eng, 1, fine.cell, &fine.meta, edt_cap, NULL));
@@ -118,13 +156,27 @@ int main(int argc, char **argv)
         const double t0 = now_s();
         CHECK(slam_pf_step(pf, 1, dp, 0));
         float best[3];
-        if (use_mean) {   /* posterior mean = plain mean of the resampled population */
-            CHECK(slam_pf_get_poses_host(pf, px, py, pt));
-            double sx = 0, sy = 0, st = 0;
-            for (int i = 0; i < particles; ++i) { sx += px[i]; sy += py[i]; st += pt[i]; }
-            best[0] = (float)(sx / particles); best[1] = (float)(sy / particles); best[2] = (float)(st / particles);
+        if (run->use_mean) {
+            /* posterior mean = plain mean of the resampled population, over ALL ranks' particles in index order (so the
+             * result does not depend on the number of GPUs).  Headings are averaged on the circle, around the predicted
+             * heading, so that a population straddling +-pi does not average to nonsense and theta stays unwrapped
+             * (the reference never normalises angles). */
+            CHECK(slam_pf_get_poses_host(pf, run->px + (size_t)rank * n, run->py + (size_t)rank * n, run->pt + (size_t)rank * n));
+            rendezvous(run);
+            const double ref = (double)pose[2] + (double)dp[2];
+            double sx = 0, sy = 0, ss = 0, sc = 0;
+            for (int i = 0; i < n_total; ++i) {
+                sx += run->px[i];
+                sy += run->py[i];
+                ss += sin((double)run->pt[i] - ref);
+                sc += cos((double)run->pt[i] - ref);
+            }
+            best[0] = (float)(sx / n_total);
+            best[1] = (float)(sy / n_total);
+            best[2] = (float)(ref + atan2(ss, sc));
+            rendezvous(run);   /* nobody overwrites the shared arrays before everyone has summed them */
         } else {
-            CHECK(slam_pf_best(pf, best, NULL, NULL));
+            CHECK(slam_pf_best(pf, best, NULL, NULL));   /* sharded: the heaviest of the whole population, on every rank */
         }
         t_step += now_s() - t0;
         memcpy(prev, pose, sizeof prev);
@@ -148,22 +200,95 @@ int main(int argc, char **argv)
         } else {
             mini_updated = 0;
         }
-        printf("pose = %f  %f  %f\n", pose[0], pose[1], pose[2]);
+        if (rank == 0) printf("pose = %f  %f  %f\n", pose[0], pose[1], pose[2]);
     }
-    const double wall = now_s() - t_begin;
-    fclose(in);
-    fprintf(stderr, "frames %d  particles %d  wall %.6f s  pf steps %.6f s (%.3e particle-updates/s)\n", frames, particles,
-            wall, t_step, (double)particles * (frames - 1) / t_step);
-
-    FILE *out = fopen(argv[4], "w");
-    if (!out) { perror(argv[4]); return 1; }
-    for (int j = 0; j < map.size; ++j) fprintf(out, "%f,%f\n", map.x[j], map.y[j]);
-    fclose(out);
-    free(hits); free(px); free(py); free(pt);
+    if (rank == 0) {
+        const double wall = now_s() - t_begin;
+        fprintf(stderr, "frames %d  particles %d  gpus %d  wall %.6f s  pf steps %.6f s (%.3e particle-updates/s)\n", frames,
+                n_total, world, wall, t_step, (double)n_total * (frames - 1) / t_step);
+        FILE *out = fopen(run->map_out, "w");
+        if (!out) { perror(run->map_out); goto fail; }
+        for (int j = 0; j < map.size; ++j) fprintf(out, "%f,%f\n", map.x[j], map.y[j]);
+        fclose(out);
+    }
+    me->rc = 0;
+fail:
+    if (me->rc && world > 1) exit(1);   /* the other ranks would wait for this one for ever: end the whole program */
+    free(hits);
     fe_grid_free(&coarse); fe_grid_free(&fine);
     fe_points_free(&map); fe_points_free(&local);
     fe_scan_free(&scan);
+    if (in) fclose(in);
     slam_pf_destroy(pf);
+    slam_comm_destroy(comm);
     slam_engine_destroy(eng);
-    return 0;
+    return NULL;
+}
+
+int main(int argc, char **argv)
+{
+    run_t run;
+    memset(&run, 0, sizeof run);
+    run.world = 1;
+    run.use_mean = 1;
+    run.seed = 1;
+    const char *pos[8];
+    int npos = 0, transport_given = 0, use_local = 0;
+    for (int a = 1; a < argc; ++a) {
+        if (!strcmp(argv[a], "--gpus") && a + 1 < argc) run.world = atoi(argv[++a]);
+        else if (!strcmp(argv[a], "--transport") && a + 1 < argc) { use_local = !strcmp(argv[++a], "local"); transport_given = 1; }
+        else if (!strcmp(argv[a], "--same-device")) run.same_device = 1;
+        else if (npos < 8) pos[npos++] = argv[a];
+    }
+    if (npos < 5 || run.world < 1 || run.world > 16) {
+        fprintf(stderr, "usage: %s dataset.csv frames beams map_out.csv particles [seed [mean|best]] [--gpus N] "
+                        "[--transport rccl|local] [--same-device]\n", argv[0]);
+        return 2;
+    }
+    run.dataset = pos[0];
+    run.frames = atoi(pos[1]);
+    run.beams = atoi(pos[2]);
+    run.map_out = pos[3];
+    run.particles_total = atoi(pos[4]);
+    if (npos > 5) run.seed = strtoull(pos[5], NULL, 10);
+    if (npos > 6 && !strcmp(pos[6], "best")) run.use_mean = 0;
+    if (run.particles_total <= 0 || run.particles_total % run.world) {
+        fprintf(stderr, "particles must be a positive multiple of the number of GPUs\n");
+        return 2;
+    }
+    if (run.same_device && !use_local && run.world > 1) {
+        fprintf(stderr, "--same-device needs --transport local (RCCL refuses two ranks on one GPU)\n");
+        return 2;
+    }
+    run.use_rccl = transport_given && !use_local;   /* "--gpus 1 --transport rccl": the sharded path on a one-rank group */
+    if (use_local) {
+        if (slam_local_group_create(run.world, &run.group) != SLAM_OK) return 1;
+    } else if (run.world > 1 || run.use_rccl) {
+        if (slam_comm_unique_id(run.comm_id) != SLAM_OK) {
+            fprintf(stderr, "slam_comm_unique_id failed\n");
+            return 1;
+        }
+    }
+    const size_t nt = (size_t)run.particles_total;
+    run.px = (float *)calloc(nt, sizeof(float));
+    run.py = (float *)calloc(nt, sizeof(float));
+    run.pt = (float *)calloc(nt, sizeof(float));
+    if (!run.px || !run.py || !run.pt) { fprintf(stderr, "out of memory\n"); return 1; }
+    if (run.world > 1) pthread_barrier_init(&run.barrier, NULL, (unsigned)run.world);
+
+    rank_t ranks[16];
+    pthread_t th[16];
+    for (int r = 0; r < run.world; ++r) { ranks[r].run = &run; ranks[r].rank = r; ranks[r].rc = 1; }
+    if (run.world == 1) {
+        rank_main(&ranks[0]);
+    } else {
+        for (int r = 0; r < run.world; ++r) pthread_create(&th[r], NULL, rank_main, &ranks[r]);
+        for (int r = 0; r < run.world; ++r) pthread_join(th[r], NULL);
+        pthread_barrier_destroy(&run.barrier);
+    }
+    int rc = 0;
+    for (int r = 0; r < run.world; ++r) rc |= ranks[r].rc;
+    slam_local_group_destroy(run.group);
+    free(run.px); free(run.py); free(run.pt);
+    return rc;
 }

@@ -87,6 +87,9 @@ class HipOps:
     def ancestors_sharded(self, first_all, n_total, n_local, rank, world, src, plan, pose_idx=None):
         self.e.ancestors_sharded_dev(first_all, n_total, n_local, rank, world, src, plan, pose_idx)
 
+    def set_exchange_capacity(self, rows):
+        self.e.exchange_set_capacity(rows)
+
     def read_plan(self, d_plan, world):
         return self.e.exchange_plan_host(world)   # zero-copy: the plan kernel wrote it to mapped host memory
 
@@ -165,6 +168,8 @@ class ParticleFilter:
         self._host_staged = self.multi and self.device.type == "cuda" and dist.get_backend(group) == "gloo"
         if hasattr(ops, "bind_stream"):
             ops.bind_stream()
+        if self.multi:
+            ops.set_exchange_capacity(self.recv_cap)   # every plan then says whether ANY rank's staging area could overflow
 
     # ------------------------------------------------------------------ collectives (plumbing only)
     def _all_reduce_max(self, t):
@@ -309,13 +314,13 @@ class ParticleFilter:
         travels once per destination rank, however many slots there descend from it."""
         o, n, r, G, dv, L = self.ops, self.n, self.rank, self.world, self.device, self.L
         plan = o.read_plan(self.plan, G)   # the one point of a frame where the host waits for the device
-        anything, scnt, rcnt = plan[0], plan[1:1 + G], plan[1 + G:1 + 2 * G]
+        anything, scnt, rcnt = plan[0] & 1, plan[1:1 + G], plan[1 + G:1 + 2 * G]
+        if plan[0] & 2:   # the same verdict on every rank (derived from the all-gathered offsets): all raise, nobody hangs
+            raise RuntimeError(f"rank {r}: the exchange of this frame might exceed recv_capacity {self.recv_cap} on some rank")
         if not anything and self.world > 1:   # every run boundary coincides with a rank boundary: all ranks skip
             self.migrated_last = 0
             return
         stot, rtot = sum(scnt), sum(rcnt)
-        if rtot > self.recv_cap:
-            raise RuntimeError(f"rank {r}: {rtot} particles to receive exceed recv_capacity {self.recv_cap}")
         self.migrated_last = rtot
         rows = 3 + 5 * L
         sbuf = self._exchange_buffer("_sbuf", rows * stot)
@@ -341,7 +346,7 @@ class ParticleFilter:
 
     # ------------------------------------------------------------------ estimate
     def best_particle(self):
-        """(log-weight, global id, pose) of the heaviest particle of the last frame (lowest id on ties)."""
+        """(log-weight, global id) of the heaviest particle of the last frame (lowest id on ties)."""
         lw, i = torch.max(self.logw, dim=0)
         cand = torch.stack([lw.double(), (self.rank * self.n + i).double()])
         if self.world > 1:

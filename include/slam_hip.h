@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define SLAM_ABI_VERSION 1
+#define SLAM_ABI_VERSION 2
 
 typedef enum {
     SLAM_OK = 0,
@@ -45,7 +45,9 @@ typedef enum {
     SLAM_ERR_INVALID_ARG = -2, /* null pointer, negative size, slot out of range, ... */
     SLAM_ERR_HIP = -3,         /* a HIP runtime call failed; slam_last_error() has the text */
     SLAM_ERR_NOT_READY = -4,   /* stage called before its inputs were provided (e.g. no grid in slot) */
-    SLAM_ERR_CAPACITY = -5     /* request exceeds a fixed capacity (beams, lattice size, ...) */
+    SLAM_ERR_CAPACITY = -5,    /* request exceeds a fixed capacity (beams, lattice size, ...) */
+    SLAM_ERR_COMM = -6         /* an exchange between ranks failed (RCCL error, or a rank of an in-process group
+                                  did not arrive); slam_last_error() has the text */
 } slam_status;
 
 typedef struct slam_engine slam_engine;
@@ -266,7 +268,8 @@ uint64_t slam_comb_offset(uint64_t seed, uint32_t frame, uint64_t total);
  *    ancestor is received ONCE, however many of this rank's slots descend from it: the tail holds, in rank
  *    order and inside a rank in particle order, the distinct remote ancestors of this rank's slots.  Also writes
  *    the exchange plan of the frame to d_plan (SLAM_PLAN_WORDS(world) int32 words, device memory):
- *      [0] nonzero when any rank exchanges anything this frame (the same value on every rank),
+ *      [0] bit 0: some rank exchanges something this frame; bit 1: some rank's staging area (see
+ *          slam_exchange_set_capacity) might not hold what it would receive — both the same on every rank,
  *      [1 .. world] send_cnt[q]: rows this rank sends to rank q,  [1+world .. 2*world] recv_cnt[q],
  *      [1+2*world .. 3*world] internal to the pack step.
  *    Needs nothing from the host; the host reads the plan once for the all-to-all's split sizes.
@@ -288,6 +291,11 @@ int slam_ancestors_sharded_dev(slam_engine *e, const int32_t *d_first_all, int64
  * pinned host memory mapped into the device and releases an arrival flag; this call waits for that flag (no
  * device-to-host copy, no stream synchronisation) and copies the SLAM_PLAN_WORDS(world) words out. */
 int slam_exchange_plan_host(slam_engine *e, int world, int32_t *plan);
+/* Rows of staging space behind the local particles (the same on every rank; <= 0 = unlimited, the initial state).
+ * With it set, every later plan carries bit 1 of plan[0] when the slots of ANY rank whose ancestor lives on another
+ * rank outnumber it — an upper bound of the rows that rank receives, derived from the all-gathered offsets alone, so
+ * that all ranks reach the same verdict and can refuse the frame together instead of one rank failing alone. */
+int slam_exchange_set_capacity(slam_engine *e, int recv_capacity);
 int slam_migrate_pack_dev(slam_engine *e, int n_local, int rank, int world, const int32_t *plan, const float *d_pose,
                           int64_t pose_ld, const float *d_map, int64_t row_stride, int plane_stride, int nlandmarks,
                           float *d_out);
@@ -311,8 +319,8 @@ int slam_gather_map_dev(slam_engine *e, const float *d_map_in, float *d_map_out,
  * the particle arrays, the landmark maps and the resample indices on the device and runs one whole frame
  * per call by chaining the stage entry points above on the engine's stream — motion+score, EKF (when the
  * filter has landmarks and `use_observations` is set), weights, integer-CDF resample; the resample gather
- * is fused into the next frame.  Single GPU; several GPUs are driven through the stage entry points
- * (pf.py).  The current scan (slam_scan_*), grid (slam_grid_*) and observation list (slam_obs_*) of the
+ * is fused into the next frame.  slam_pf_create: one GPU; slam_pf_create_sharded (below): one session per GPU,
+ * every exchange step between the GPUs issued by the engine itself.  The current scan (slam_scan_*), grid (slam_grid_*) and observation list (slam_obs_*) of the
  * engine are the frame's inputs. */
 typedef struct slam_pf slam_pf;
 typedef struct {
@@ -325,6 +333,46 @@ typedef struct {
 } slam_pf_config;
 
 int slam_pf_create(slam_engine *e, const slam_pf_config *cfg, slam_pf **out);
+
+/* ---- several GPUs: communicators + the sharded session.
+ * The reference has no multi-device code; what it does have is ONE C host program that creates
+ * its accelerator handle once in main and threads it through (Submodule_2/Hadrware_acclereated.cpp:842-845, 284).
+ * The sharded filter keeps that shape: a plain C host creates one engine + one communicator per GPU and then
+ * drives every rank with the same slam_pf_* calls as a single GPU; the engine issues every exchange step itself
+ * (RCCL over xGMI), on its own streams, with no host framework between the launches.
+ *   slam_comm_unique_id      rank 0 makes the rendezvous token (ncclGetUniqueId) and hands it to the other ranks by
+ *                            any means (shared memory of the host process, a file, a socket, torch.distributed ...)
+ *   slam_comm_create_rccl    collective: every rank calls it with the same token (ncclCommInitRank).  One rank per
+ *                            GPU; ranks may be processes or threads of one process.  world <= 16.
+ *   slam_local_group_* / slam_comm_create_local
+ *                            in-process transport: all ranks are threads of ONE process and exchange through
+ *                            device-to-device copies and a host rendezvous.  Same results, no overlap; for hosts that
+ *                            do not want RCCL and for rehearsing many ranks on few GPUs (RCCL refuses two ranks on
+ *                            one device).  Every rank's calls must come from its own host thread (they block).
+ * A communicator belongs to one engine and one session; destroy the session first, then the communicator. */
+typedef struct slam_comm slam_comm;
+typedef struct slam_local_group slam_local_group;
+enum { SLAM_COMM_ID_BYTES = 128 };
+int slam_comm_unique_id(uint8_t id[SLAM_COMM_ID_BYTES]);
+int slam_comm_create_rccl(slam_engine *e, int rank, int world, const uint8_t id[SLAM_COMM_ID_BYTES], slam_comm **out);
+int slam_local_group_create(int world, slam_local_group **out);
+int slam_local_group_destroy(slam_local_group *g);
+int slam_comm_create_local(slam_engine *e, slam_local_group *g, int rank, slam_comm **out);
+int slam_comm_rank(const slam_comm *c);
+int slam_comm_world(const slam_comm *c);
+int slam_comm_destroy(slam_comm *c);
+
+/* The sharded session: cfg->n_particles is THIS rank's share (the same on every rank); the population is
+ * world x n_particles, particle ids are global (rank * n_particles + local index), and every result is
+ * bit-identical to the same population on one GPU.  recv_capacity = rows of staging space for map rows / poses
+ * that arrive from other ranks (<= 0: n_particles, which can never overflow; smaller values save memory and make
+ * slam_pf_step fail with SLAM_ERR_CAPACITY — on every rank alike — in a frame whose exchange might not fit).
+ * Per frame the engine issues, on the communicator's stream: all-reduce MAX of the weight normaliser, all-gather of
+ * the shard totals, all-gather of the offspring offsets ("surviving indices"), an all-gather of the new poses that
+ * runs beside the EKF, and ONE grouped send/recv carrying the map rows of ancestors that live on another rank
+ * (each row once per destination rank).  Every slam_pf_* call on a sharded session is collective. */
+int slam_pf_create_sharded(slam_engine *e, const slam_pf_config *cfg, slam_comm *comm, int recv_capacity,
+                           slam_pf **out);
 int slam_pf_destroy(slam_pf *pf);
 /* all particles at `pose`; maps (if any) marked "not seen yet" */
 int slam_pf_reset(slam_pf *pf, const float pose[3]);
@@ -332,8 +380,25 @@ int slam_pf_set_poses_host(slam_pf *pf, const float *x, const float *y, const fl
 int slam_pf_set_map_host(slam_pf *pf, const float *rows /* [n_particles][5][n_landmarks] */);
 /* one frame against grid `slot`; asynchronous */
 int slam_pf_step(slam_pf *pf, int slot, const float dp[3], int use_observations);
-/* heaviest particle of the last frame (lowest index on ties): its pose, log-weight and index; synchronises */
+/* heaviest particle of the last frame (lowest index on ties): its pose, log-weight and index; synchronises.
+ * Sharded: the heaviest of the whole population (the same answer on every rank), `index` is its global id. */
 int slam_pf_best(slam_pf *pf, float pose[3], float *logw, int32_t *index);
+/* rows this rank received in the exchange of the last completed frame (0 on a single GPU) */
+int slam_pf_rows_received(const slam_pf *pf);
+/* The session's CURRENT device buffers, for hosts that fill or inspect the population on the device instead of
+ * through the *_host copies (a 52 GB map does not want to pass through host memory): pose = [x | y | theta] of
+ * n_particles floats each; map = one row per particle, row_stride floats apart, five planes of plane_stride floats
+ * (layout of slam_ekf_update_dev); anc = the pending resample gather (slot i descends from particle anc[i] of
+ * these buffers; NULL when none is pending: right after create / reset / set_*).  The pointers move with every
+ * slam_pf_step; synchronise (slam_engine_sync) before touching the memory from another stream. */
+typedef struct {
+    float *pose, *map;
+    float *map_spare;                 /* the other map buffer: free between frames (the next EKF writes it) */
+    const int32_t *anc;
+    int64_t row_stride;
+    int32_t plane_stride, map_rows;   /* map_rows = n_particles + staging rows (sharded) */
+} slam_pf_view;
+int slam_pf_device_view(slam_pf *pf, slam_pf_view *out);
 /* current particles with the pending resample gather applied; synchronises */
 int slam_pf_get_poses_host(slam_pf *pf, float *x, float *y, float *theta);
 int slam_pf_get_map_host(slam_pf *pf, float *rows /* [n_particles][5][n_landmarks] */);

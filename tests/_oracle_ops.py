@@ -19,6 +19,10 @@ class OracleOps:
     def __init__(self, grid_meta, edt, bx, by):
         self.meta, self.edt, self.bx, self.by = grid_meta, np.ascontiguousarray(edt, np.float32), bx, by
         self.obs = None
+        self.exch_cap = None
+
+    def set_exchange_capacity(self, rows):
+        self.exch_cap = rows if rows and rows > 0 else None
 
     def motion_sample(self, src, anc, dst, n, first_id, dp, sigma, seed, frame):
         x, y, th = oracle.motion_sample(_np(src[0]), _np(src[1]), _np(src[2]), _np(anc), n, first_id, dp, sigma, seed, frame)
@@ -111,6 +115,11 @@ class OracleOps:
         bounds = [int(fa[q * n]) for q in range(world)] + [n_total]
         out_plan = np.zeros(1 + 3 * world, np.int32)
         out_plan[0] = int(any(bounds[q] != q * n for q in range(1, world)))
+        if self.exch_cap is not None:   # bit 1: could ANY rank's staging area overflow (bound: its slots with a remote ancestor)
+            for q in range(world):
+                lo, hi = max(bounds[q], q * n), min(bounds[q + 1], (q + 1) * n)
+                if n - max(hi - lo, 0) > self.exch_cap:
+                    out_plan[0] |= 2
         mine = g_all[rank * n:(rank + 1) * n]
         out = np.empty(n, np.int64)
         off = 0
