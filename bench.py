@@ -176,6 +176,21 @@ def cpu_baseline(args, occ, meta_t, frames, landmarks, budget_s=12.0):
                       f"{args.grid}^2 EDT), oracle/ C port, 1 thread, {el:.1f} s"}
 
 
+class stdout_to_stderr:
+    """File descriptor 1 points at stderr inside the block (for native libraries that print to stdout)."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -242,10 +257,12 @@ def main():
         dist.init_process_group(args.dist_backend, rank=0, world_size=1, **({"device_id": dev} if args.dist_backend == "nccl" else {}))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.dist_backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
+        with stdout_to_stderr():
+            if args.dist_backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+                dist.barrier()   # RCCL initialises lazily: do it (and print its banner) here, not in the timed region
+            else:
+                dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
 
     eng = pkg.Engine(dev_index)
     use_c = args.driver == "c"
@@ -287,7 +304,8 @@ def main():
                 uid = torch.tensor(list(pkg.comm_unique_id()), dtype=torch.uint8, device=dev)
             if world > 1:
                 dist.broadcast(uid, src=0)
-            comm = pkg.Comm.rccl(eng, rank, world, bytes(uid.cpu().tolist()))
+            with stdout_to_stderr():   # RCCL prints its version banner to stdout; stdout carries ONE JSON line
+                comm = pkg.Comm.rccl(eng, rank, world, bytes(uid.cpu().tolist()))
         pf = pkg.PfSession(eng, n, L, sigma=args.sigma, meas_var=args.meas_var, score_gain=args.score_gain, seed=1234, comm=comm)
         Lp = (L + 31) // 32 * 32
     else:

@@ -100,6 +100,8 @@ SIGNATURES = {
     "slam_mapper_next_frame": (_i, [_vp, _vp, _fp]),
     "slam_mapper_get_map_host": (_i, [_vp, _vp, _vp, C.c_int32, C.POINTER(C.c_int32)]),
     "slam_exchange_set_capacity": (_i, [_vp, _i]),
+    "slam_resample_gate_set": (_i, [_vp, _f]),
+    "slam_resample_happened_host": (_i, [_vp, C.POINTER(C.c_int)]),
     "slam_comm_unique_id": (_i, [_vp]),
     "slam_comm_create_rccl": (_i, [_vp, _i, _i, _vp, C.POINTER(_vp)]),
     "slam_local_group_create": (_i, [_i, C.POINTER(_vp)]),
@@ -111,6 +113,7 @@ SIGNATURES = {
     "slam_pf_create_sharded": (_i, [_vp, _vp, _vp, _i, C.POINTER(_vp)]),
     "slam_pf_rows_received": (_i, [_vp]),
     "slam_pf_device_view": (_i, [_vp, _vp]),
+    "slam_pf_frames_resampled": (_i64, [_vp]),
     "slam_pf_create": (_i, [_vp, _vp, C.POINTER(_vp)]),
     "slam_pf_destroy": (_i, [_vp]),
     "slam_pf_reset": (_i, [_vp, _fp]),
@@ -367,6 +370,14 @@ class Engine:
         self._ck(self.lib.slam_ancestors_sharded_dev(self.h, _ptr(d_first_all), n_total, n_local, rank, world,
                                                      _ptr(d_src), _ptr(d_plan), _ptr(d_pose_idx)), "ancestors_sharded_dev")
 
+    def resample_gate_set(self, ess_frac: float):
+        self._ck(self.lib.slam_resample_gate_set(self.h, float(ess_frac)), "resample_gate_set")
+
+    def resample_happened(self) -> bool:
+        r = C.c_int(1)
+        self._ck(self.lib.slam_resample_happened_host(self.h, C.byref(r)), "resample_happened")
+        return bool(r.value)
+
     def exchange_set_capacity(self, rows: int):
         self._ck(self.lib.slam_exchange_set_capacity(self.h, int(rows)), "exchange_set_capacity")
 
@@ -403,7 +414,7 @@ class PfConfig(C.Structure):
     """``slam_pf_config``"""
 
     _fields_ = [("n_particles", C.c_int32), ("n_landmarks", C.c_int32), ("sigma", C.c_float * 3),
-                ("meas_var", C.c_float), ("score_gain", C.c_float), ("seed", C.c_uint64)]
+                ("meas_var", C.c_float), ("score_gain", C.c_float), ("seed", C.c_uint64), ("resample_ess_frac", C.c_float)]
 
 
 COMM_ID_BYTES = 128
@@ -492,9 +503,9 @@ class PfSession:
     of a population sharded over several GPUs (``n_particles`` = this rank's share); every call is then collective."""
 
     def __init__(self, engine: Engine, n_particles, n_landmarks=0, sigma=(0.01, 0.01, 0.002), meas_var=0.01,
-                 score_gain=1.0, seed=1, comm: Comm | None = None, recv_capacity: int = 0):
+                 score_gain=1.0, seed=1, comm: Comm | None = None, recv_capacity: int = 0, resample_ess_frac: float = 0.0):
         self.e, self.n, self.L, self.comm = engine, n_particles, n_landmarks, comm
-        cfg = PfConfig(n_particles, n_landmarks, (C.c_float * 3)(*sigma), meas_var, score_gain, seed)
+        cfg = PfConfig(n_particles, n_landmarks, (C.c_float * 3)(*sigma), meas_var, score_gain, seed, resample_ess_frac)
         h = C.c_void_p()
         if comm is None:
             engine._ck(engine.lib.slam_pf_create(engine.h, C.byref(cfg), C.byref(h)), "pf_create")
@@ -505,6 +516,9 @@ class PfSession:
 
     def rows_received(self) -> int:
         return self.e.lib.slam_pf_rows_received(self.h)
+
+    def frames_resampled(self) -> int:
+        return int(self.e.lib.slam_pf_frames_resampled(self.h))
 
     def device_view(self):
         """dict of DeviceArray views of the session's CURRENT buffers (``slam_pf_device_view``): pose [3][n], map and

@@ -4,8 +4,8 @@
 //   local  all ranks live in ONE process, one host thread each, and exchange through device-to-device copies and a
 //          host rendezvous — for single-process hosts and for rehearsing many ranks on few GPUs (RCCL refuses two
 //          ranks on one device).
-// Every collective of a communicator is issued on ONE dedicated stream in program order (the model of
-// torch.distributed's nccl backend); `fork` makes that stream wait for the engine's stream, `join` the reverse.
+// Every collective of a communicator is issued on the ENGINE's stream, in program order: stream-ordered with the
+// kernels around it, no second stream and no event hand-overs.
 // No counterpart in the reference (it has no multi-device code).
 #pragma once
 
@@ -28,7 +28,8 @@ slam_engine* comm_engine(const slam_comm* c);
 int comm_all_reduce_max_f32(slam_comm* c, float* d_buf, int count);
 // d_recv[q * bytes .. ) = rank q's d_send[0 .. bytes)
 int comm_all_gather(slam_comm* c, const void* d_send, void* d_recv, size_t bytes);
-// asynchronous form: the gather may run beside later work of the engine's stream until comm_all_gather_finish
+// begin / finish form: the result may be used only after comm_all_gather_finish (today both are stream-ordered, so
+// finish has nothing to wait for; the pair marks where a transport with overlap would hand over)
 int comm_all_gather_begin(slam_comm* c, const void* d_send, void* d_recv, size_t bytes);
 int comm_all_gather_finish(slam_comm* c);
 // rank q receives send_floats[q] floats from my d_send (blocks in rank order); I receive recv_floats[q] from q

@@ -127,6 +127,9 @@ int slam_engine_create(int device, slam_engine** out)
         hipHostGetDevicePointer((void**)&e->d_hfm, e->h_fm, 0) != hipSuccess ||
         hipHostMalloc((void**)&e->h_plan, sizeof(int32_t) * (SLAM_PLAN_WORDS(kMaxRanks) + 1), hipHostMallocMapped) != hipSuccess ||
         hipHostGetDevicePointer((void**)&e->d_hplan, e->h_plan, 0) != hipSuccess ||
+        hipHostMalloc((void**)&e->h_gate, sizeof(int32_t) * 2, hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer((void**)&e->d_hgate, e->h_gate, 0) != hipSuccess ||
+        e->gate_buf.ensure(sizeof(int32_t)) != hipSuccess ||
         e->scan_buf.ensure(sizeof(float) * 2 * SLAM_MAX_BEAMS) != hipSuccess ||
         hipHostMalloc((void**)&e->h_stage, sizeof(float) * kStageSlots * kStageFloats, hipHostMallocDefault) !=
             hipSuccess) {
@@ -136,6 +139,16 @@ int slam_engine_create(int device, slam_engine** out)
     }
     memset(e->h_fm, 0, sizeof(float) * (kFmIn + kFmOut + 4));   // arrival flag starts at 0, sequence numbers at 1
     memset(e->h_plan, 0, sizeof(int32_t) * (SLAM_PLAN_WORDS(kMaxRanks) + 1));
+    e->h_gate[0] = 1;
+    e->h_gate[1] = 0;
+    {
+        const int32_t one = 1;   // "the previous frame resampled": nothing is carried into the first frame
+        if (hipMemcpy(e->gate_buf.p, &one, sizeof one, hipMemcpyHostToDevice) != hipSuccess) {
+            (void)hipGetLastError();
+            slam_engine_destroy(e);
+            return SLAM_ERR_NO_DEVICE;
+        }
+    }
     e->stream = e->own_stream;
     *out = e;
     return SLAM_OK;
@@ -171,6 +184,9 @@ int slam_engine_destroy(slam_engine* e)
         }
     if (e->h_fm) (void)hipHostFree(e->h_fm);
     if (e->h_plan) (void)hipHostFree(e->h_plan);
+    if (e->h_gate) (void)hipHostFree(e->h_gate);
+    e->gate_buf.release();
+    e->carry_buf.release();
     if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
     delete e;
     return SLAM_OK;
@@ -646,7 +662,10 @@ static int logweight_common(slam_engine* e, const float* d_score, const float* d
 {
     if (n <= 0 || !d_logw) return SLAM_ERR_INVALID_ARG;
     HIP_TRY(e->bmax_buf.ensure(sizeof(float) * (size_t)logweight_scratch_elems(n)));
-    HIP_TRY(launch_logweight(e->stream, d_score, d_loglik, score_gain, n, d_logw, e->bmax_buf.as<float>(), d_max));
+    // with a resample gate: the weights of a frame that did not resample carry into this one (device-side decision)
+    const bool carry = e->gate_frac_q16 != 0 && e->carry_n == n;
+    HIP_TRY(launch_logweight(e->stream, d_score, d_loglik, score_gain, n, d_logw, e->bmax_buf.as<float>(), d_max,
+                             carry ? e->carry_buf.as<float>() : nullptr, carry ? e->gate_buf.as<int32_t>() : nullptr));
     e->bmax_count = logweight_scratch_elems(n);
     e->bmax_n = n;
     return SLAM_OK;
@@ -671,11 +690,19 @@ int slam_quantise_scan_dev(slam_engine* e, const float* d_logw, const float* d_m
     ENTER(e);
     if (n <= 0 || !d_logw) return SLAM_ERR_INVALID_ARG;
     if (!d_max && e->bmax_n != n) return SLAM_ERR_NOT_READY;   // needs the maxima of slam_logweight_dev(n)
-    const size_t ntiles = (size_t)prefix_sum_scratch_elems(n);
-    HIP_TRY(e->scan_state.ensure(sizeof(uint64_t) * ((size_t)n + ntiles)));
+    const size_t ntiles = (size_t)scan_tile_count(n);
+    HIP_TRY(e->scan_state.ensure(sizeof(uint64_t) * ((size_t)n + 3 * ntiles + 1)));
     uint64_t* cdf = e->scan_state.as<uint64_t>();
-    HIP_TRY(launch_quantise_scan(e->stream, d_logw, d_max, e->bmax_buf.as<float>(), e->bmax_count, n, cdf, cdf + n, d_sum));
+    uint64_t* tiles = cdf + n;   // tile_total | tile_s16 | tile_q16
+    float* carry = nullptr;
+    if (e->gate_frac_q16 != 0) {
+        HIP_TRY(e->carry_buf.ensure(sizeof(float) * (size_t)n));
+        carry = e->carry_buf.as<float>();
+    }
+    HIP_TRY(launch_quantise_scan(e->stream, d_logw, d_max, e->bmax_buf.as<float>(), e->bmax_count, n, cdf, tiles, d_sum,
+                                 carry, tiles + ntiles, tiles + 2 * ntiles));
     e->scan_n = n;
+    e->carry_n = carry ? n : -1;
     return SLAM_OK;
 }
 
@@ -686,6 +713,7 @@ int slam_offspring_from_scan_dev(slam_engine* e, int n, const uint64_t* d_base, 
     if (n <= 0 || n_total < n || n_total > 0x7fffffff || !d_first) return SLAM_ERR_INVALID_ARG;
     if (e->scan_n != n) return SLAM_ERR_NOT_READY;
     const uint64_t* cdf = e->scan_state.as<uint64_t>();
+    // (a shard of a larger population: base and total come from the caller, so does the gate — not applied here)
     HIP_TRY(launch_offspring_from_scan(e->stream, cdf, cdf + n, n, d_base, d_total, nullptr, 0, 1, seed, frame, n_total,
                                        d_first));
     return SLAM_OK;
@@ -697,14 +725,17 @@ int slam_ancestors_from_scan_dev(slam_engine* e, int n, uint64_t seed, uint32_t 
     if (n <= 0 || !d_anc) return SLAM_ERR_INVALID_ARG;
     if (e->scan_n != n) return SLAM_ERR_NOT_READY;
     const uint64_t* cdf = e->scan_state.as<uint64_t>();
+    const uint32_t frac = e->carry_n == n ? e->gate_frac_q16 : 0;   // the gate needs the sums of a gated quantise_scan
+    const GateOut gate = frac ? e->gate_next() : GateOut();
     if (ancestors_from_scan_fits(n)) {
-        HIP_TRY(launch_ancestors_from_scan(e->stream, cdf, cdf + n, n, seed, frame, d_anc));
+        HIP_TRY(launch_ancestors_from_scan(e->stream, cdf, cdf + n, n, seed, frame, d_anc, frac, gate));
         return SLAM_OK;
     }
     // more tiles than the one-launch form keeps in LDS: the two-launch form through a scratch `first` array
     HIP_TRY(e->first_buf.ensure(sizeof(int32_t) * (size_t)n));
     int32_t* first = e->first_buf.as<int32_t>();
-    HIP_TRY(launch_offspring_from_scan(e->stream, cdf, cdf + n, n, nullptr, nullptr, nullptr, 0, 1, seed, frame, n, first));
+    HIP_TRY(launch_offspring_from_scan(e->stream, cdf, cdf + n, n, nullptr, nullptr, nullptr, 0, 1, seed, frame, n, first,
+                                       frac, gate));
     HIP_TRY(launch_ancestors(e->stream, first, n, 0, n, d_anc));
     return SLAM_OK;
 }
@@ -718,8 +749,41 @@ int slam_offspring_from_scan_sharded_dev(slam_engine* e, int n, const uint64_t* 
         return SLAM_ERR_INVALID_ARG;
     if (e->scan_n != n) return SLAM_ERR_NOT_READY;
     const uint64_t* cdf = e->scan_state.as<uint64_t>();
+    const uint32_t frac = e->carry_n == n ? e->gate_frac_q16 : 0;
     HIP_TRY(launch_offspring_from_scan(e->stream, cdf, cdf + n, n, nullptr, nullptr, d_shard_totals, rank, world, seed,
-                                       frame, n_total, d_first));
+                                       frame, n_total, d_first, frac, frac ? e->gate_next() : GateOut()));
+    return SLAM_OK;
+}
+
+int slam_resample_gate_set(slam_engine* e, float ess_frac)
+{
+    ENTER(e);
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    e->gate_frac_q16 = ess_frac > 0.0f && ess_frac < 1.0f ? (uint32_t)lrintf(ess_frac * 65536.0f) : 0u;
+    e->carry_n = -1;
+    e->h_gate[0] = 1;
+    const int32_t one = 1;   // nothing is carried into the next frame
+    HIP_TRY(hipMemcpy(e->gate_buf.p, &one, sizeof one, hipMemcpyHostToDevice));
+    return SLAM_OK;
+}
+
+int slam_resample_happened_host(slam_engine* e, int* resampled)
+{
+    ENTER(e);
+    if (!resampled) return SLAM_ERR_INVALID_ARG;
+    *resampled = 1;
+    if (e->gate_frac_q16 == 0 || e->gate_seq == 0) return SLAM_OK;   // no gate (or no gated stage yet): every frame resamples
+    volatile uint32_t* h_seq = reinterpret_cast<volatile uint32_t*>(e->h_gate + 1);
+    const uint32_t seq = e->gate_seq;
+    bool arrived = false;
+    for (long spin = 0; spin < 400000000L; ++spin) {   // bounded: a few seconds at most
+        if (__atomic_load_n(h_seq, __ATOMIC_ACQUIRE) == seq) { arrived = true; break; }
+    }
+    if (!arrived) {
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        if (__atomic_load_n(h_seq, __ATOMIC_ACQUIRE) != seq) return fail_hip(e, hipErrorUnknown, "resample gate flag");
+    }
+    *resampled = e->h_gate[0] != 0;
     return SLAM_OK;
 }
 

@@ -92,6 +92,25 @@ struct slam_engine {
     DevBuf first_buf;          // scratch `first` array of slam_ancestors_from_scan_dev's large-n fallback
     DevBuf ll_buf;             // log-likelihood [n] of the last EKF call
     int ll_n = -1;
+    // resample gate (slam_resample_gate_set): threshold, the device flag "the last resample stage did resample", the
+    // same verdict in mapped host memory {int32 resampled, uint32 sequence}, and the weights carried over a frame
+    // that did not resample
+    uint32_t gate_frac_q16 = 0;
+    DevBuf gate_buf;           // int32 flag
+    int32_t* h_gate = nullptr;
+    int32_t* d_hgate = nullptr;
+    uint32_t gate_seq = 0;
+    DevBuf carry_buf;          // float[n]
+    int carry_n = -1;
+
+    slam::GateOut gate_next()
+    {
+        slam::GateOut g;
+        g.d_flag = gate_buf.as<int32_t>();
+        g.h_flag = d_hgate;
+        g.seq = ++gate_seq;
+        return g;
+    }
     // pinned staging ring for the per-frame sensor uploads: one host-to-device copy per upload, and the
     // host only waits if kStageSlots uploads are still in flight
     float* h_stage = nullptr;

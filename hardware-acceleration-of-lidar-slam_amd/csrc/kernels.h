@@ -90,21 +90,35 @@ struct EkfArgs {
 };
 hipError_t launch_ekf_update(hipStream_t stream, const EkfArgs& a, const EventPair* ev = nullptr);
 
+// carry / prev_resampled (optional): see logweight_kernel — the weights a frame without resample left behind
 hipError_t launch_logweight(hipStream_t stream, const float* score, const float* loglik, float gain, int n,
-                            float* logw, float* block_max_scratch, float* d_max);
+                            float* logw, float* block_max_scratch, float* d_max, const float* carry = nullptr,
+                            const int32_t* prev_resampled = nullptr);
 int logweight_scratch_elems(int n);
 hipError_t launch_quantise_weights(hipStream_t stream, const float* logw, const float* d_max, int n, uint64_t* wq,
                                    uint64_t* d_sum);
 
-// fused frame-loop form (quantise + tile scan; offsets straight from the tile-local scan)
+// The resample gate (ESS-gated resampling; oracle: orc_ess_resample).  frac_q16 = threshold * 65536, 0 = no gate
+// (resample every frame).  Where the verdict goes: a device flag and, optionally, mapped host memory
+// {int32 resampled, uint32 sequence number}.
+struct GateOut {
+    int32_t* d_flag = nullptr;
+    int32_t* h_flag = nullptr;
+    uint32_t seq = 0;
+};
+// fused frame-loop form (quantise + tile scan; offsets straight from the tile-local scan).  The scan state is
+// cdf_local[n] followed by tile_total[ntiles] | tile_s16[ntiles] | tile_q16[ntiles] (the last two only with a gate:
+// carry != nullptr).  With a gate d_sum receives three values (total, S, Q) and d_shard_totals holds such triples.
 hipError_t launch_quantise_scan(hipStream_t stream, const float* logw, const float* d_max, const float* block_max,
-                                int nblock_max, int n, uint64_t* cdf_local, uint64_t* tile_total, uint64_t* d_sum);
+                                int nblock_max, int n, uint64_t* cdf_local, uint64_t* tile_total, uint64_t* d_sum,
+                                float* carry = nullptr, uint64_t* tile_s16 = nullptr, uint64_t* tile_q16 = nullptr);
 hipError_t launch_offspring_from_scan(hipStream_t stream, const uint64_t* cdf_local, const uint64_t* tile_total, int n,
                                       const uint64_t* d_base, const uint64_t* d_total, const uint64_t* d_shard_totals,
                                       int rank, int world, uint64_t seed, uint32_t frame, int64_t n_total,
-                                      int32_t* first);
+                                      int32_t* first, uint32_t frac_q16 = 0, const GateOut& gate = GateOut());
 hipError_t launch_prefix_sum(hipStream_t stream, const uint64_t* in, int n, uint64_t* out, uint64_t* block_scratch);
 int prefix_sum_scratch_elems(int n);
+int scan_tile_count(int n);   // 2048-element tiles of the fused quantise + scan
 hipError_t launch_offspring_offsets(hipStream_t stream, const uint64_t* cdf, int n, const uint64_t* d_base,
                                     const uint64_t* d_total, uint64_t seed, uint32_t frame, int64_t n_total,
                                     int32_t* first);
@@ -113,7 +127,8 @@ hipError_t launch_ancestors(hipStream_t stream, const int32_t* first_all, int64_
 // single GPU: offspring offsets + ancestors in one launch (n up to 8M; beyond that use the two launches above)
 bool ancestors_from_scan_fits(int n);
 hipError_t launch_ancestors_from_scan(hipStream_t stream, const uint64_t* cdf_local, const uint64_t* tile_total, int n,
-                                      uint64_t seed, uint32_t frame, int32_t* anc);
+                                      uint64_t seed, uint32_t frame, int32_t* anc, uint32_t frac_q16 = 0,
+                                      const GateOut& gate = GateOut());
 // multi-GPU resample (see pf_kernels.hip): per-peer slot runs, offsets in the packed exchange buffers
 enum { kMaxRanks = 16 };
 struct MigratePlan {

@@ -281,16 +281,22 @@ __device__ __forceinline__ float wave_max(float v)
     return v;
 }
 
+// carry (optional): the normalised log-weights the previous frame left behind; they count only when that frame did
+// NOT resample (*prev_resampled == 0, a device flag written by the previous frame's resample kernel)
 __global__ __launch_bounds__(kBlock) void logweight_kernel(const float* __restrict__ score,
                                                            const float* __restrict__ loglik, float gain, int n,
+                                                           const float* __restrict__ carry,
+                                                           const int32_t* __restrict__ prev_resampled,
                                                            float* __restrict__ logw, float* __restrict__ block_max)
 {
     __shared__ float s_max[kBlock / 64];
     float m = -INFINITY;
+    const bool add_carry = carry && *prev_resampled == 0;
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
         const float ll = loglik ? loglik[i] : 0.0f;
         const float sc = score ? score[i] * gain : 0.0f;
-        const float lw = ll - sc;
+        float lw = ll - sc;
+        if (add_carry) lw = carry[i] + lw;
         logw[i] = lw;
         m = lw > m ? lw : m;
     }
@@ -451,25 +457,41 @@ __device__ __forceinline__ float block_max_of(const float* __restrict__ v, int c
     return r;
 }
 
+// GATED: also what the resample gate needs — the 16-bit weight sums S = sum(wq >> 16), Q = sum((wq >> 16)^2) of the
+// tile (exact integers, hence independent of order and sharding) and carry[i] = logw[i] - max, the weight a particle
+// takes into the next frame when this one does not resample (oracle: orc_ess_terms / orc_weight_carry).
+template <bool GATED>
 __global__ __launch_bounds__(kBlock) void quantise_scan_kernel(const float* __restrict__ logw,
                                                                const float* __restrict__ d_max,
                                                                const float* __restrict__ block_max, int nblock_max,
                                                                int n, uint64_t* __restrict__ cdf_local,
-                                                               uint64_t* __restrict__ tile_total)
+                                                               uint64_t* __restrict__ tile_total,
+                                                               float* __restrict__ carry,
+                                                               uint64_t* __restrict__ tile_s16,
+                                                               uint64_t* __restrict__ tile_q16)
 {
     __shared__ uint64_t s_wave[kBlock / 64];
     __shared__ float s_red[kBlock / 64];
     const float m = d_max ? *d_max : block_max_of(block_max, nblock_max, s_red);
     const int base = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
     uint64_t v[kScanItems];
-    uint64_t run = 0;
+    uint64_t run = 0, s16 = 0, q16 = 0;
 #pragma unroll
     for (int k = 0; k < kScanItems; ++k) {
         const int i = base + k;
         uint64_t q = 0;
-        if (i < n) q = (uint64_t)(det_expf(logw[i] - m) * 4294967296.0f);
+        if (i < n) {
+            const float rel = logw[i] - m;
+            q = (uint64_t)(det_expf(rel) * 4294967296.0f);
+            if (GATED) carry[i] = rel;
+        }
         run += q;
         v[k] = run;
+        if (GATED) {
+            const uint64_t w = q >> 16;
+            s16 += w;
+            q16 += w * w;
+        }
     }
     uint64_t total;
     const uint64_t incl = block_inclusive_scan(run, s_wave, total);
@@ -480,6 +502,26 @@ __global__ __launch_bounds__(kBlock) void quantise_scan_kernel(const float* __re
         if (i < n) cdf_local[i] = v[k] + excl;   // inclusive, local to this 2048-element tile
     }
     if (threadIdx.x == 0) tile_total[blockIdx.x] = total;
+    if (GATED) {
+        s16 = wave_sum_u64(s16);
+        q16 = wave_sum_u64(q16);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) s_wave[threadIdx.x >> 6] = s16;
+        __syncthreads();
+        uint64_t a = 0;
+#pragma unroll
+        for (int w = 0; w < kBlock / 64; ++w) a += s_wave[w];
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) s_wave[threadIdx.x >> 6] = q16;
+        __syncthreads();
+        uint64_t b = 0;
+#pragma unroll
+        for (int w = 0; w < kBlock / 64; ++w) b += s_wave[w];
+        if (threadIdx.x == 0) {
+            tile_s16[blockIdx.x] = a;
+            tile_q16[blockIdx.x] = b;
+        }
+    }
 }
 
 __device__ __forceinline__ uint64_t block_sum_u64(uint64_t v, uint64_t* s_red /*[kBlock/64]*/)
@@ -494,14 +536,44 @@ __device__ __forceinline__ uint64_t block_sum_u64(uint64_t v, uint64_t* s_red /*
     return r;
 }
 
-__global__ __launch_bounds__(kBlock) void sum_tiles_kernel(const uint64_t* __restrict__ tile_total, int ntiles,
+// d_sum[0] = shard total; with the gate also d_sum[1] = S, d_sum[2] = Q of the shard (what the ranks all-gather)
+__global__ __launch_bounds__(kBlock) void sum_tiles_kernel(const uint64_t* __restrict__ tile_total,
+                                                           const uint64_t* __restrict__ tile_s16,
+                                                           const uint64_t* __restrict__ tile_q16, int ntiles,
                                                            uint64_t* __restrict__ d_sum)
 {
     __shared__ uint64_t s_red[kBlock / 64];
-    uint64_t acc = 0;
-    for (int t = threadIdx.x; t < ntiles; t += kBlock) acc += tile_total[t];
-    acc = block_sum_u64(acc, s_red);
-    if (threadIdx.x == 0) *d_sum = acc;
+    const uint64_t* src[3] = { tile_total, tile_s16, tile_q16 };
+    for (int a = 0; a < (tile_s16 ? 3 : 1); ++a) {
+        uint64_t acc = 0;
+        for (int t = threadIdx.x; t < ntiles; t += kBlock) acc += src[a][t];
+        acc = block_sum_u64(acc, s_red);
+        if (threadIdx.x == 0) d_sum[a] = acc;
+    }
+}
+
+// The resample gate (oracle: orc_ess_resample): resample iff ESS < frac * N, i.e. S^2 * 65536 < frac_q16 * N * Q, in
+// 128-bit integer arithmetic (S < 2^47, Q < 2^63, N < 2^31, frac_q16 <= 2^16).
+__device__ __forceinline__ bool ess_wants_resample(uint64_t s16, uint64_t q16, uint64_t n_total, uint32_t frac_q16)
+{
+    uint64_t l_lo = s16 * s16, l_hi = __umul64hi(s16, s16);
+    l_hi = (l_hi << 16) | (l_lo >> 48);
+    l_lo <<= 16;
+    const uint64_t nf = n_total * (uint64_t)frac_q16;
+    const uint64_t r_lo = q16 * nf, r_hi = __umul64hi(q16, nf);
+    return l_hi < r_hi || (l_hi == r_hi && l_lo < r_lo);
+}
+
+// verdict of the gate for the rest of the frame loop: a device flag (the next frame's weight kernel reads it) and the
+// same value in mapped host memory behind a sequence number (the host picks the EKF form for the next frame)
+__device__ __forceinline__ void publish_gate(const GateOut& g, bool resample)
+{
+    *g.d_flag = resample ? 1 : 0;
+    if (g.h_flag) {
+        g.h_flag[0] = resample ? 1 : 0;
+        __threadfence_system();
+        __hip_atomic_store(reinterpret_cast<uint32_t*>(g.h_flag + 1), g.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 // floor((hi:lo) / d) for hi < d < 2^63 (so the quotient fits 64 bits): restoring long division
@@ -575,29 +647,55 @@ __global__ __launch_bounds__(kBlock) void offspring_from_scan_kernel(const uint6
                                                                      const uint64_t* __restrict__ d_shard_totals,
                                                                      int rank, int world, uint32_t key0,
                                                                      uint32_t key1, uint32_t frame, uint64_t n_total,
-                                                                     int32_t* __restrict__ first)
+                                                                     int32_t* __restrict__ first,
+                                                                     const uint64_t* __restrict__ tile_s16,
+                                                                     const uint64_t* __restrict__ tile_q16,
+                                                                     uint32_t frac_q16, GateOut gate)
 {
     __shared__ uint64_t s_red[kBlock / 64];
     const int i = blockIdx.x * kBlock + threadIdx.x;
     const int tile = (blockIdx.x * kBlock) / kScanTile;   // kScanTile is a multiple of kBlock
-    uint64_t before = 0, all = 0;
+    const bool gated = frac_q16 != 0;
+    const int stride = gated ? 3 : 1;   // gated: the ranks all-gather (total, S, Q) triples
+    uint64_t before = 0, all = 0, s16 = 0, q16 = 0;
     for (int t = threadIdx.x; t < ntiles; t += kBlock) {
         const uint64_t v = tile_total[t];
         all += v;
         before += t < tile ? v : 0ull;
+        if (gated && !d_shard_totals) {
+            s16 += tile_s16[t];
+            q16 += tile_q16[t];
+        }
     }
     before = block_sum_u64(before, s_red);
     uint64_t total, shard_base = d_base ? *d_base : 0ull;
     if (d_shard_totals) {   // several GPUs: the all-gathered shard totals give both the base and the grand total
         total = 0;
         shard_base = 0;
+        s16 = q16 = 0;
         for (int q = 0; q < world; ++q) {
-            const uint64_t v = d_shard_totals[q];
+            const uint64_t v = d_shard_totals[(size_t)stride * q];
             total += v;
             shard_base += q < rank ? v : 0ull;
+            if (gated) {
+                s16 += d_shard_totals[3 * (size_t)q + 1];
+                q16 += d_shard_totals[3 * (size_t)q + 2];
+            }
         }
     } else {
         total = d_total ? *d_total : block_sum_u64(all, s_red);
+        if (gated) {
+            s16 = block_sum_u64(s16, s_red);
+            q16 = block_sum_u64(q16, s_red);
+        }
+    }
+    if (gated) {   // the same verdict in every workgroup and on every rank (integer sums over the whole population)
+        const bool resample = ess_wants_resample(s16, q16, n_total, frac_q16);
+        if (blockIdx.x == 0 && threadIdx.x == 0) publish_gate(gate, resample);
+        if (!resample) {   // every particle keeps its slot: slot j descends from particle j
+            if (i < n) first[i] = (int32_t)((int64_t)rank * n + i);
+            return;
+        }
     }
     if (i >= n) return;
     const uint64_t base = shard_base + before;
@@ -614,16 +712,23 @@ template <int kPer>   // tiles per thread: 1 covers n <= 512k with 2 KB of LDS, 
 __global__ __launch_bounds__(kBlock) void ancestors_from_scan_kernel(const uint64_t* __restrict__ cdf_local,
                                                                      const uint64_t* __restrict__ tile_total,
                                                                      int ntiles, int n, uint32_t key0, uint32_t key1,
-                                                                     uint32_t frame, int32_t* __restrict__ anc)
+                                                                     uint32_t frame, int32_t* __restrict__ anc,
+                                                                     const uint64_t* __restrict__ tile_s16,
+                                                                     const uint64_t* __restrict__ tile_q16,
+                                                                     uint32_t frac_q16, GateOut gate)
 {
     __shared__ uint64_t s_off[kPer * kBlock];
     __shared__ uint64_t s_wave[kBlock / 64];
-    uint64_t v[kPer], run = 0;
+    uint64_t v[kPer], run = 0, s16 = 0, q16 = 0;
 #pragma unroll
     for (int k = 0; k < kPer; ++k) {
         const int t = threadIdx.x * kPer + k;
         v[k] = run;   // exclusive within the thread
         run += t < ntiles ? tile_total[t] : 0ull;
+        if (frac_q16 != 0 && t < ntiles) {
+            s16 += tile_s16[t];
+            q16 += tile_q16[t];
+        }
     }
     uint64_t total;
     const uint64_t excl = block_inclusive_scan(run, s_wave, total) - run;
@@ -631,6 +736,16 @@ __global__ __launch_bounds__(kBlock) void ancestors_from_scan_kernel(const uint6
     for (int k = 0; k < kPer; ++k) s_off[threadIdx.x * kPer + k] = v[k] + excl;
     __syncthreads();
     const int j = blockIdx.x * kBlock + threadIdx.x;
+    if (frac_q16 != 0) {   // resample gate: the same verdict in every workgroup
+        s16 = block_sum_u64(s16, s_wave);
+        q16 = block_sum_u64(q16, s_wave);
+        const bool resample = ess_wants_resample(s16, q16, (uint64_t)n, frac_q16);
+        if (blockIdx.x == 0 && threadIdx.x == 0) publish_gate(gate, resample);
+        if (!resample) {
+            if (j < n) anc[j] = j;
+            return;
+        }
+    }
     if (j >= n) return;
     if (total == 0 || (total >> 63)) {   // see offspring_offsets_kernel: every slot gets the last particle
         anc[j] = n - 1;
@@ -1016,11 +1131,12 @@ static int capped_blocks(int n) { const int b = blocks_for(n); return b < 2048 ?
 int logweight_scratch_elems(int n) { return capped_blocks(n > 0 ? n : 1); }
 
 hipError_t launch_logweight(hipStream_t stream, const float* score, const float* loglik, float gain, int n,
-                            float* logw, float* block_max_scratch, float* d_max)
+                            float* logw, float* block_max_scratch, float* d_max, const float* carry,
+                            const int32_t* prev_resampled)
 {
     if (n <= 0) return hipSuccess;
     const int nb = capped_blocks(n);
-    logweight_kernel<<<nb, kBlock, 0, stream>>>(score, loglik, gain, n, logw, block_max_scratch);
+    logweight_kernel<<<nb, kBlock, 0, stream>>>(score, loglik, gain, n, carry, prev_resampled, logw, block_max_scratch);
     if (d_max) max_finalize_kernel<<<1, kBlock, 0, stream>>>(block_max_scratch, nb, d_max);
     return hipGetLastError();
 }
@@ -1037,6 +1153,7 @@ hipError_t launch_quantise_weights(hipStream_t stream, const float* logw, const 
 }
 
 int prefix_sum_scratch_elems(int n) { return (n + kScanTile - 1) / kScanTile + 1; }
+int scan_tile_count(int n) { return (n + kScanTile - 1) / kScanTile; }
 
 hipError_t launch_prefix_sum(hipStream_t stream, const uint64_t* in, int n, uint64_t* out, uint64_t* block_scratch)
 {
@@ -1051,26 +1168,33 @@ hipError_t launch_prefix_sum(hipStream_t stream, const uint64_t* in, int n, uint
 }
 
 hipError_t launch_quantise_scan(hipStream_t stream, const float* logw, const float* d_max, const float* block_max,
-                                int nblock_max, int n, uint64_t* cdf_local, uint64_t* tile_total, uint64_t* d_sum)
+                                int nblock_max, int n, uint64_t* cdf_local, uint64_t* tile_total, uint64_t* d_sum,
+                                float* carry, uint64_t* tile_s16, uint64_t* tile_q16)
 {
     if (n <= 0) return hipSuccess;
     const int ntiles = (n + kScanTile - 1) / kScanTile;
-    quantise_scan_kernel<<<ntiles, kBlock, 0, stream>>>(logw, d_max, block_max, nblock_max, n, cdf_local, tile_total);
-    if (d_sum) sum_tiles_kernel<<<1, kBlock, 0, stream>>>(tile_total, ntiles, d_sum);
+    if (carry)
+        quantise_scan_kernel<true><<<ntiles, kBlock, 0, stream>>>(logw, d_max, block_max, nblock_max, n, cdf_local, tile_total,
+                                                                  carry, tile_s16, tile_q16);
+    else
+        quantise_scan_kernel<false><<<ntiles, kBlock, 0, stream>>>(logw, d_max, block_max, nblock_max, n, cdf_local,
+                                                                   tile_total, nullptr, nullptr, nullptr);
+    if (d_sum) sum_tiles_kernel<<<1, kBlock, 0, stream>>>(tile_total, carry ? tile_s16 : nullptr, tile_q16, ntiles, d_sum);
     return hipGetLastError();
 }
 
 hipError_t launch_offspring_from_scan(hipStream_t stream, const uint64_t* cdf_local, const uint64_t* tile_total, int n,
                                       const uint64_t* d_base, const uint64_t* d_total, const uint64_t* d_shard_totals,
                                       int rank, int world, uint64_t seed, uint32_t frame, int64_t n_total,
-                                      int32_t* first)
+                                      int32_t* first, uint32_t frac_q16, const GateOut& gate)
 {
     if (n <= 0) return hipSuccess;
     const int ntiles = (n + kScanTile - 1) / kScanTile;
     offspring_from_scan_kernel<<<blocks_for(n), kBlock, 0, stream>>>(cdf_local, tile_total, ntiles, n, d_base, d_total,
                                                                      d_shard_totals, rank, world, (uint32_t)seed,
                                                                      (uint32_t)(seed >> 32), frame, (uint64_t)n_total,
-                                                                     first);
+                                                                     first, tile_total + ntiles, tile_total + 2 * ntiles,
+                                                                     frac_q16, gate);
     return hipGetLastError();
 }
 
@@ -1088,16 +1212,18 @@ hipError_t launch_offspring_offsets(hipStream_t stream, const uint64_t* cdf, int
 bool ancestors_from_scan_fits(int n) { return n > 0 && (n + kScanTile - 1) / kScanTile <= kMaxLdsTiles; }
 
 hipError_t launch_ancestors_from_scan(hipStream_t stream, const uint64_t* cdf_local, const uint64_t* tile_total, int n,
-                                      uint64_t seed, uint32_t frame, int32_t* anc)
+                                      uint64_t seed, uint32_t frame, int32_t* anc, uint32_t frac_q16, const GateOut& gate)
 {
     if (n <= 0) return hipSuccess;
     const int ntiles = (n + kScanTile - 1) / kScanTile;
+    const uint64_t *ts = tile_total + ntiles, *tq = tile_total + 2 * ntiles;   // layout of the engine's scan state
     if (ntiles <= kBlock)
         ancestors_from_scan_kernel<1><<<blocks_for(n), kBlock, 0, stream>>>(cdf_local, tile_total, ntiles, n, (uint32_t)seed,
-                                                                            (uint32_t)(seed >> 32), frame, anc);
+                                                                            (uint32_t)(seed >> 32), frame, anc, ts, tq,
+                                                                            frac_q16, gate);
     else
         ancestors_from_scan_kernel<kMaxLdsTiles / kBlock><<<blocks_for(n), kBlock, 0, stream>>>(
-            cdf_local, tile_total, ntiles, n, (uint32_t)seed, (uint32_t)(seed >> 32), frame, anc);
+            cdf_local, tile_total, ntiles, n, (uint32_t)seed, (uint32_t)(seed >> 32), frame, anc, ts, tq, frac_q16, gate);
     return hipGetLastError();
 }
 

@@ -51,6 +51,8 @@ struct slam_pf {
     float* cand = nullptr;          // [world][5] best-particle candidates
     bool exchange_pending = false;  // resample done, map rows not exchanged yet
     int rows_received = 0;
+    bool gated = false;             // cfg.resample_ess_frac in (0, 1): a frame resamples only when its ESS is low
+    int64_t frames_resampled = 0;   // (as far as the host has looked: one frame behind)
 };
 
 namespace {
@@ -125,6 +127,8 @@ int drop_resample(slam_pf* pf)
 {
     pf->has_anc = false;
     pf->exchange_pending = false;
+    if (pf->gated)   // ... and no weight is carried into the next frame
+        if (int rc = slam_resample_gate_set(pf->e, pf->cfg.resample_ess_frac)) return rc;
     if (pf->comm) return comm_all_gather_finish(pf->comm);
     return SLAM_OK;
 }
@@ -184,7 +188,7 @@ int create_common(slam_engine* e, const slam_pf_config* cfg, slam_comm* comm, in
         ok = ok && dev_alloc((void**)&pf->pose_all, 3 * n * G * 4) == hipSuccess &&
              dev_alloc((void**)&pf->pose_stage, 3 * cap * 4) == hipSuccess &&
              dev_alloc((void**)&pf->first_all, n * G * 4) == hipSuccess && dev_alloc((void**)&pf->d_max, 4) == hipSuccess &&
-             dev_alloc((void**)&pf->d_sum, 8) == hipSuccess && dev_alloc((void**)&pf->totals, 8 * G) == hipSuccess &&
+             dev_alloc((void**)&pf->d_sum, 3 * 8) == hipSuccess && dev_alloc((void**)&pf->totals, 3 * 8 * G) == hipSuccess &&
              dev_alloc((void**)&pf->d_plan, 4 * SLAM_PLAN_WORDS(kMaxRanks)) == hipSuccess &&
              dev_alloc((void**)&pf->cand, 4 * 5 * G) == hipSuccess;
     if (!ok) {
@@ -197,6 +201,11 @@ int create_common(slam_engine* e, const slam_pf_config* cfg, slam_comm* comm, in
             slam_pf_destroy(pf);
             return rc;
         }
+    pf->gated = cfg->resample_ess_frac > 0.0f && cfg->resample_ess_frac < 1.0f;
+    if (int rc = slam_resample_gate_set(e, pf->gated ? cfg->resample_ess_frac : 0.0f)) {
+        slam_pf_destroy(pf);
+        return rc;
+    }
     const float origin[3] = { 0, 0, 0 };
     if (int rc = slam_pf_reset(pf, origin)) {   // a failed reset must not hand back a live object with an error code
         slam_pf_destroy(pf);
@@ -230,6 +239,7 @@ int slam_pf_destroy(slam_pf* pf)
         (void)slam_engine_sync(pf->e);
         (void)slam_exchange_set_capacity(pf->e, 0);
     }
+    if (pf->gated) (void)slam_resample_gate_set(pf->e, 0.0f);
     for (int b = 0; b < 2; ++b) {
         (void)hipFree(pf->pose[b]);
         (void)hipFree(pf->anc[b]);
@@ -324,6 +334,16 @@ int slam_pf_step(slam_pf* pf, int slot, const float dp[3], int use_observations)
                                    pf->cfg.sigma, pf->cfg.seed, pf->frame, pf->score, pf->count);
     }
     if (rc != SLAM_OK) return rc;
+    // Resample gate: did the previous frame keep its population?  (Its verdict was made on the device; the host looks at it
+    // only now, behind the launch above — a flag in mapped memory.)  Then the maps have not moved: the EKF runs IN PLACE on
+    // the observed landmarks only, nothing is copied, the buffers do not flip.
+    bool in_place = false;
+    if (pf->gated && pf->has_anc) {
+        int resampled = 1;
+        if ((rc = slam_resample_happened_host(e, &resampled)) != SLAM_OK) return rc;
+        in_place = !resampled;
+        pf->frames_resampled += resampled ? 1 : 0;
+    }
     if (comm) {
         // map rows of remote ancestors -> staging tail; issued behind the launch above, which does not need them
         if ((rc = finish_exchange(pf)) != SLAM_OK) return rc;
@@ -335,14 +355,19 @@ int slam_pf_step(slam_pf* pf, int slot, const float dp[3], int use_observations)
     const bool ekf = L > 0 && use_observations;
     const int mc = pf->map_cur, mn = 1 - mc;
     float* d_max = comm ? pf->d_max : nullptr;
-    if (ekf) {
+    if (ekf && in_place) {
+        rc = slam_ekf_update_dev(e, pf->map[mc], pf->map[mc], 5 * (int64_t)pf->Lp, pf->Lp, L, dst, dst + sn, dst + 2 * sn, nullptr, n,
+                                 pf->cfg.meas_var, nullptr);
+        if (rc != SLAM_OK) return rc;
+        rc = slam_logweight_ekf_dev(e, pf->score, pf->cfg.score_gain, n, pf->logw, d_max);
+    } else if (ekf) {
         rc = slam_ekf_update_dev(e, pf->map[mc], pf->map[mn], 5 * (int64_t)pf->Lp, pf->Lp, L, dst, dst + sn, dst + 2 * sn, anc, n,
                                  pf->cfg.meas_var, nullptr);
         if (rc != SLAM_OK) return rc;
         pf->map_cur = mn;
         rc = slam_logweight_ekf_dev(e, pf->score, pf->cfg.score_gain, n, pf->logw, d_max);
     } else {
-        if (L > 0 && anc) {   // the maps follow their particles even without an observation
+        if (L > 0 && anc && !in_place) {   // the maps follow their particles even without an observation
             rc = slam_gather_map_dev(e, pf->map[mc], pf->map[mn], 5 * (int64_t)pf->Lp, 5 * (int64_t)pf->Lp, pf->Lp, pf->Lp, L,
                                      anc, n);
             if (rc != SLAM_OK) return rc;
@@ -358,7 +383,8 @@ int slam_pf_step(slam_pf* pf, int slot, const float dp[3], int use_observations)
     if (!comm) {
         if ((rc = slam_ancestors_from_scan_dev(e, n, pf->cfg.seed, pf->frame, pf->anc[nxt])) != SLAM_OK) return rc;
     } else {
-        if ((rc = comm_all_gather(comm, pf->d_sum, pf->totals, sizeof(uint64_t))) != SLAM_OK) return rc;
+        // shard totals (with the gate: total, sum v, sum v^2 per rank)
+        if ((rc = comm_all_gather(comm, pf->d_sum, pf->totals, (pf->gated ? 3 : 1) * sizeof(uint64_t))) != SLAM_OK) return rc;
         if ((rc = slam_offspring_from_scan_sharded_dev(e, n, pf->totals, pf->rank, pf->world, pf->cfg.seed, pf->frame,
                                                        pf->n_total, pf->first)) != SLAM_OK)
             return rc;
@@ -378,6 +404,8 @@ int slam_pf_step(slam_pf* pf, int slot, const float dp[3], int use_observations)
 }
 
 int slam_pf_rows_received(const slam_pf* pf) { return pf ? pf->rows_received : 0; }
+
+int64_t slam_pf_frames_resampled(const slam_pf* pf) { return pf ? pf->frames_resampled : 0; }
 
 int slam_pf_device_view(slam_pf* pf, slam_pf_view* out)
 {

@@ -19,8 +19,9 @@
  * the number of GPUs (bit for bit: pose log and map file).
  *
  * usage: slam_pf_main dataset.csv frames beams map_out.csv particles [seed [mean|best]]
- *                     [--gpus N] [--transport rccl|local] [--same-device]
+ *                     [--gpus N] [--transport rccl|local] [--same-device] [--ess F]
  *   particles      the whole population (a multiple of N)
+ *   --ess F        ESS-gated resampling: resample only in frames whose effective sample size is below F * N
  *   --transport    rccl (default when N > 1): RCCL, one GPU per rank.  local: the in-process transport.
  *   --same-device  every rank on device 0 (only with the local transport; RCCL refuses two ranks on one GPU)
  */
@@ -46,6 +47,7 @@ typedef struct {
     const char *dataset, *map_out;
     int frames, beams, particles_total, use_mean;
     unsigned long long seed;
+    float ess_frac;        /* --ess F: resample only when the effective sample size is below F * N (0: every frame) */
     /* the ranks */
     int world, use_rccl, same_device;
     uint8_t comm_id[SLAM_COMM_ID_BYTES];
@@ -104,7 +106,7 @@ static void *rank_main(void *arg)
         }
     }
     /* motion noise of the order of the reference's fine lattice step (0.025 m, 0.004363 rad; main.c:833) */
-    const slam_pf_config cfg = { n, 0, { 0.01f, 0.01f, 0.002f }, 1.0f, 0.25f, run->seed };
+    const slam_pf_config cfg = { n, 0, { 0.01f, 0.01f, 0.002f }, 1.0f, 0.25f, run->seed, run->ess_frac };
     if (world > 1 || run->use_rccl || run->group) {
         if (run->group) CHECK(slam_comm_create_local(eng, run->group, rank, &comm));
         else CHECK(slam_comm_create_rccl(eng, rank, world, run->comm_id, &comm));
@@ -238,11 +240,12 @@ int main(int argc, char **argv)
         if (!strcmp(argv[a], "--gpus") && a + 1 < argc) run.world = atoi(argv[++a]);
         else if (!strcmp(argv[a], "--transport") && a + 1 < argc) { use_local = !strcmp(argv[++a], "local"); transport_given = 1; }
         else if (!strcmp(argv[a], "--same-device")) run.same_device = 1;
+        else if (!strcmp(argv[a], "--ess") && a + 1 < argc) run.ess_frac = (float)atof(argv[++a]);
         else if (npos < 8) pos[npos++] = argv[a];
     }
     if (npos < 5 || run.world < 1 || run.world > 16) {
         fprintf(stderr, "usage: %s dataset.csv frames beams map_out.csv particles [seed [mean|best]] [--gpus N] "
-                        "[--transport rccl|local] [--same-device]\n", argv[0]);
+                        "[--transport rccl|local] [--same-device] [--ess F]\n", argv[0]);
         return 2;
     }
     run.dataset = pos[0];

@@ -238,6 +238,25 @@ int slam_offspring_from_scan_dev(slam_engine *e, int n, const uint64_t *d_base, 
 int slam_offspring_from_scan_sharded_dev(slam_engine *e, int n, const uint64_t *d_shard_totals, int rank, int world,
                                          uint64_t seed, uint32_t frame, int64_t n_total, int32_t *d_first);
 
+/* Resample gate (ESS-gated resampling).  ess_frac in (0, 1): a frame resamples only when the effective sample size
+ * of its weights is below ess_frac * N; anything else (the initial state): every frame resamples.  The ESS is taken
+ * on 16-bit weights v = wq >> 16, ESS = (sum v)^2 / sum v^2, and compared in exact integer arithmetic
+ * ((sum v)^2 * 65536 < round(ess_frac * 65536) * N * sum v^2), so the verdict is the same for any sharding.
+ * With a gate set, on this engine:
+ *  - slam_quantise_scan_dev also keeps carry[i] = logw[i] - max inside the engine and, when d_sum != NULL, writes
+ *    THREE values there: shard total, sum v, sum v^2 (what the ranks all-gather);
+ *  - slam_ancestors_from_scan_dev and slam_offspring_from_scan_sharded_dev (whose d_shard_totals then holds such
+ *    triples, [world][3]) apply the gate on the device: a frame that keeps its population gets ancestor[j] = j
+ *    (first[i] = global index of i), so everything downstream — fused gathers, the exchange plan — works unchanged
+ *    and nothing moves;
+ *  - slam_logweight_dev / slam_logweight_ekf_dev add the carried weight of the previous frame when that frame did
+ *    not resample (a device-side flag; the first frame after slam_resample_gate_set carries nothing);
+ *  - slam_resample_happened_host tells the host whether the last gated resample stage did resample (it waits for a
+ *    flag in mapped memory — no copy, no stream synchronisation; without a gate the answer is always 1), so that it
+ *    can run the next EKF in place (map_in == map_out, no gather) instead of out of place. */
+int slam_resample_gate_set(slam_engine *e, float ess_frac);
+int slam_resample_happened_host(slam_engine *e, int *resampled);
+
 /* A12: systematic resampling on the exact integer CDF.
  *  step 1 (per shard): d_cdf[i] = inclusive prefix sum of wq within the shard.
  *  step 2 (per shard): d_first[i] = number of comb teeth below the start of particle i's CDF
@@ -330,6 +349,7 @@ typedef struct {
     float meas_var;        /* landmark observation variance */
     float score_gain;      /* logw = loglik - score_gain * score */
     uint64_t seed;
+    float resample_ess_frac;   /* in (0, 1): resample only when ESS < frac * N (slam_resample_gate_set); 0 = every frame */
 } slam_pf_config;
 
 int slam_pf_create(slam_engine *e, const slam_pf_config *cfg, slam_pf **out);
@@ -367,10 +387,12 @@ int slam_comm_destroy(slam_comm *c);
  * bit-identical to the same population on one GPU.  recv_capacity = rows of staging space for map rows / poses
  * that arrive from other ranks (<= 0: n_particles, which can never overflow; smaller values save memory and make
  * slam_pf_step fail with SLAM_ERR_CAPACITY — on every rank alike — in a frame whose exchange might not fit).
- * Per frame the engine issues, on the communicator's stream: all-reduce MAX of the weight normaliser, all-gather of
- * the shard totals, all-gather of the offspring offsets ("surviving indices"), an all-gather of the new poses that
- * runs beside the EKF, and ONE grouped send/recv carrying the map rows of ancestors that live on another rank
- * (each row once per destination rank).  Every slam_pf_* call on a sharded session is collective. */
+ * Per frame the engine issues, on its own stream and in program order with the kernels around them (no second stream,
+ * no event hand-overs): all-reduce MAX of the weight normaliser, all-gather of the shard totals, all-gather of the
+ * offspring offsets ("surviving indices"), an all-gather of the new poses (12 B per particle, so that the next frame's
+ * motion + score launch need not wait for the exchange), and ONE grouped send/recv carrying the map rows of ancestors
+ * that live on another rank (each row once per destination rank).  Every slam_pf_* call on a sharded session is
+ * collective. */
 int slam_pf_create_sharded(slam_engine *e, const slam_pf_config *cfg, slam_comm *comm, int recv_capacity,
                            slam_pf **out);
 int slam_pf_destroy(slam_pf *pf);
@@ -385,6 +407,9 @@ int slam_pf_step(slam_pf *pf, int slot, const float dp[3], int use_observations)
 int slam_pf_best(slam_pf *pf, float pose[3], float *logw, int32_t *index);
 /* rows this rank received in the exchange of the last completed frame (0 on a single GPU) */
 int slam_pf_rows_received(const slam_pf *pf);
+/* With cfg.resample_ess_frac in (0, 1): how many of the frames the host has looked at so far did resample (the
+ * verdict of a frame is read at the start of the next one).  Without a gate: 0 (every frame resamples). */
+int64_t slam_pf_frames_resampled(const slam_pf *pf);
 /* The session's CURRENT device buffers, for hosts that fill or inspect the population on the device instead of
  * through the *_host copies (a 52 GB map does not want to pass through host memory): pose = [x | y | theta] of
  * n_particles floats each; map = one row per particle, row_stride floats apart, five planes of plane_stride floats

@@ -86,6 +86,11 @@ def lib() -> C.CDLL:
                                  _f32p, _f32p, C.c_int, C.c_float, _f32p]
     L.orc_logweight.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_int, _f32p, P(C.c_float)]
     L.orc_quantise_weights.argtypes = [_f32p, C.c_float, C.c_int, _u64p, P(_u64)]
+    L.orc_ess_terms.argtypes = [_u64p, C.c_int, P(_u64), P(_u64)]
+    L.orc_ess_resample.argtypes = [_u64, _u64, _i64, _u32]
+    L.orc_ess_resample.restype = C.c_int
+    L.orc_logweight_carry.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int, _f32p, P(C.c_float)]
+    L.orc_weight_carry.argtypes = [_f32p, C.c_float, C.c_int, _f32p]
     L.orc_prefix_sum.argtypes = [_u64p, C.c_int, _u64p]
     L.orc_comb_offset.argtypes = [_u64, _u32, _u64]
     L.orc_comb_offset.restype = _u64
@@ -286,6 +291,38 @@ def logweight(score, loglik, gain):
     lib().orc_logweight(keep_s.ctypes.data_as(C.c_void_p) if keep_s is not None else None,
                         keep_l.ctypes.data_as(C.c_void_p) if keep_l is not None else None, gain, n, logw, C.byref(m))
     return logw, np.float32(m.value)
+
+
+def logweight_carry(score, loglik, gain, carry):
+    """logw = carry + (loglik - gain*score) (carry None: no carry term) and its maximum."""
+    n = len(score) if score is not None else len(loglik)
+    logw = np.empty(n, np.float32)
+    m = C.c_float(0)
+    keep = [(_f32(a) if a is not None else None) for a in (score, loglik, carry)]
+    ptr = [(a.ctypes.data_as(C.c_void_p) if a is not None else None) for a in keep]
+    lib().orc_logweight_carry(ptr[0], ptr[1], gain, ptr[2], n, logw, C.byref(m))
+    return logw, np.float32(m.value)
+
+
+def weight_carry(logw, m):
+    out = np.empty(len(logw), np.float32)
+    lib().orc_weight_carry(_f32(logw), m, len(logw), out)
+    return out
+
+
+def ess_terms(wq):
+    s, q = C.c_uint64(0), C.c_uint64(0)
+    lib().orc_ess_terms(np.ascontiguousarray(wq, np.uint64), len(wq), C.byref(s), C.byref(q))
+    return int(s.value), int(q.value)
+
+
+def ess_resample(s16, q16, n_total, frac_q16):
+    return bool(lib().orc_ess_resample(s16, q16, n_total, frac_q16))
+
+
+def ess_frac_q16(frac: float) -> int:
+    """The gate threshold as the engine quantises it: round(frac * 65536); 0 = resample every frame."""
+    return int(np.rint(np.float32(frac) * np.float32(65536.0))) if 0.0 < frac < 1.0 else 0
 
 
 def quantise_weights(logw, m):

@@ -306,6 +306,47 @@ void orc_quantise_weights(const float *logw, float max, int n, uint64_t *wq, uin
     *sum = s;
 }
 
+/* ------------------------------------------------------------------ resample gate */
+
+void orc_ess_terms(const uint64_t *wq, int n, uint64_t *s16, uint64_t *q16)
+{
+    uint64_t s = 0, q = 0;
+    for (int i = 0; i < n; ++i) {
+        const uint64_t v = wq[i] >> 16;
+        s += v;
+        q += v * v;
+    }
+    *s16 = s;
+    *q16 = q;
+}
+
+int orc_ess_resample(uint64_t s16, uint64_t q16, int64_t n_total, uint32_t frac_q16)
+{
+    const unsigned __int128 lhs = ((unsigned __int128)s16 * s16) << 16;
+    const unsigned __int128 rhs = (unsigned __int128)q16 * ((uint64_t)n_total * (uint64_t)frac_q16);
+    return lhs < rhs;
+}
+
+void orc_logweight_carry(const float *score, const float *loglik, float score_gain, const float *carry, int n,
+                         float *logw, float *max_out)
+{
+    float m = -INFINITY;
+    for (int i = 0; i < n; ++i) {
+        const float ll = loglik ? loglik[i] : 0.0f;
+        const float sc = score ? score[i] * score_gain : 0.0f;
+        float lw = ll - sc;
+        if (carry) lw = carry[i] + lw;
+        logw[i] = lw;
+        if (lw > m) m = lw;
+    }
+    *max_out = m;
+}
+
+void orc_weight_carry(const float *logw, float max, int n, float *carry)
+{
+    for (int i = 0; i < n; ++i) carry[i] = logw[i] - max;
+}
+
 /* ------------------------------------------------------------------ A12 */
 
 void orc_prefix_sum(const uint64_t *wq, int n, uint64_t *cdf)

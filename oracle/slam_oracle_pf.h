@@ -62,6 +62,20 @@ void orc_ekf_update(const float *map_in, float *map_out, int64_t row_stride, int
 void orc_logweight(const float *score, const float *loglik, float score_gain, int n, float *logw, float *max_out);
 void orc_quantise_weights(const float *logw, float max, int n, uint64_t *wq, uint64_t *sum);
 
+/* ---- A11/A12 resample gate (ESS-gated resampling).  The effective sample size is taken on 16-bit weights
+ * v_i = wq_i >> 16 (so that every sum fits 64 bits for up to 2^31 particles):  S = sum v_i,  Q = sum v_i^2,
+ * ESS = S^2 / Q.  The population is resampled in a frame iff  ESS < frac * N  with frac = frac_q16 / 65536, decided in
+ * exact integer arithmetic:  S^2 * 65536 < frac_q16 * N * Q  (128-bit products).  Both sums are plain integer sums,
+ * hence independent of summation order and of how the particles are sharded.
+ * A frame that does NOT resample keeps every particle in its slot (ancestor = itself) and carries its weight into
+ * the next frame: carry_i = logw_i - max (one float subtraction), and that frame's log-weight is
+ * carry_i + (loglik_i - gain*score_i) (one more float addition). */
+void orc_ess_terms(const uint64_t *wq, int n, uint64_t *s16, uint64_t *q16);
+int orc_ess_resample(uint64_t s16, uint64_t q16, int64_t n_total, uint32_t frac_q16);
+void orc_logweight_carry(const float *score, const float *loglik, float score_gain, const float *carry, int n,
+                         float *logw, float *max_out);
+void orc_weight_carry(const float *logw, float max, int n, float *carry);
+
 /* ---- A12 systematic resample on the integer CDF */
 void orc_prefix_sum(const uint64_t *wq, int n, uint64_t *cdf);
 uint64_t orc_comb_offset(uint64_t seed, uint32_t frame, uint64_t total);

@@ -161,7 +161,7 @@ def test_ekf_long_rows_small_n(eng, orc, L, Lp):
 
 
 # ------------------------------------------------------------------ the sharded C session (slam_pf_create_sharded)
-def _run_c_session_ranks(world, n_total, L, frames, transport="local", recv_capacity=0):
+def _run_c_session_ranks(world, n_total, L, frames, transport="local", recv_capacity=0, ess=0.0):
     """`world` ranks of the C-level sharded session in THIS process, one host thread per rank, all on cuda:0
     (in-process transport), or a one-rank RCCL communicator.  Returns the concatenated population."""
     import threading
@@ -190,7 +190,8 @@ def _run_c_session_ranks(world, n_total, L, frames, transport="local", recv_capa
             elif transport == "rccl":
                 comm = pkg.Comm.rccl(eng, r, world, uid)
             ses = pkg.PfSession(eng, n, L, seed=77, sigma=(0.02, 0.02, 0.004), meas_var=0.02,
-                                score_gain=0.05 if L else 1.0, comm=comm, recv_capacity=recv_capacity)
+                                score_gain=0.05 if L else 1.0, comm=comm, recv_capacity=recv_capacity,
+                                resample_ess_frac=ess)
             sl = slice(r * n, (r + 1) * n)
             ses.set_poses(x[sl], y[sl], th[sl])
             if L:
@@ -204,7 +205,7 @@ def _run_c_session_ranks(world, n_total, L, frames, transport="local", recv_capa
                 rows.append(ses.rows_received())
                 if f % 3 == 1:
                     bests.append(ses.best())                 # collective; must not disturb the pending exchange
-            res = {"pose": ses.poses(), "best": ses.best(), "rows": rows, "bests": bests}
+            res = {"pose": ses.poses(), "best": ses.best(), "rows": rows, "bests": bests, "resampled": ses.frames_resampled()}
             if L:
                 res["map"] = ses.maps()
             out[r] = res
@@ -289,3 +290,68 @@ def test_slam_pf_main_several_ranks_identical_output(orc, tmp_path):
         print(tag, r.stderr.strip())
     assert len(outs["one"][0]) == 299
     assert outs["four"] == outs["one"] and outs["rccl1"] == outs["one"]
+
+
+# ------------------------------------------------------------------ ESS-gated resampling
+def _gated_reference(orc, n, L, frames, ess):
+    """The gated frame loop written with the CPU specification's functions (oracle/): the executable statement of
+    DESIGN.md §7 "resample gate".  Returns final poses / maps with the pending gather applied, and the per-frame verdicts."""
+    import _shard_worker as W
+
+    meta, edt, bx, by, lm = W.make_world(L=max(L, 1))
+    lm = lm[:L]
+    x, y, th, mp = W.init_state(n, L, lm)
+    fq = orc.ess_frac_q16(ess)
+    anc, carry, prev_resampled, verdicts = None, None, True, []
+    seed, sigma, gain, mvar = 77, (0.02, 0.02, 0.004), (0.05 if L else 1.0), 0.02
+    for f in range(frames):
+        x, y, th = orc.motion_sample(x, y, th, anc, n, 0, [0.01, -0.005, 0.002], sigma, seed, f)
+        score, _ = orc.score_poses_det(meta, edt, bx, by, x, y, th)
+        ll = None
+        use = L > 0 and f != 2
+        if use:
+            ids, zx, zy = W.observations(lm, f)
+            mp, ll = orc.ekf_update(mp, x, y, th, anc, ids, zx, zy, mvar)
+        elif L and anc is not None:
+            mp = mp[anc]
+        logw, m = orc.logweight_carry(score, ll, gain, None if prev_resampled else carry)
+        wq, _ = orc.quantise_weights(logw, m)
+        s16, q16 = orc.ess_terms(wq)
+        prev_resampled = orc.ess_resample(s16, q16, n, fq) if fq else True
+        carry = orc.weight_carry(logw, m)
+        anc = orc.resample(wq, seed, f) if prev_resampled else np.arange(n, dtype=np.int32)
+        verdicts.append(prev_resampled)
+    return np.stack([x[anc], y[anc], th[anc]]), (mp[anc] if L else None), verdicts
+
+
+@pytest.mark.parametrize("L,ess", [(6, 0.5), (0, 0.1), (6, 0.2), (6, 0.05), (6, 0.9)])
+def test_ess_gated_session_matches_specification(orc, L, ess):
+    """slam_pf_config.resample_ess_frac: frames whose effective sample size stays above the threshold keep their
+    population (ancestor = itself, EKF in place on the observed landmarks, weights carried into the next frame); the
+    verdict is integer arithmetic on the device.  Poses and maps after 9 frames equal the CPU specification bit for bit,
+    and the scenario contains frames of both kinds."""
+    n, frames = 4096, 9
+    want_pose, want_map, verdicts = _gated_reference(orc, n, L, frames, ess)
+    got = _run_c_session_ranks(1, n, L, frames, transport=None, ess=ess)[0]
+    assert np.array_equal(bits(got["pose"]), bits(want_pose))
+    if L:
+        assert np.array_equal(bits(got["map"]), bits(want_map))
+    assert got["resampled"] == sum(verdicts[:-1])          # the host has looked at every frame but the last
+    if ess < 0.9:
+        assert any(verdicts) and not all(verdicts), verdicts
+
+
+@pytest.mark.parametrize("world,L", [(4, 6), (2, 0), (8, 6)])
+def test_ess_gated_sharded_session_equals_one_rank(orc, world, L):
+    """The gate is decided from integer sums over the WHOLE population (all-gathered shard sums), so every rank reaches
+    the same verdict and the sharded run equals the single-GPU run bit for bit; frames that keep their population
+    exchange nothing."""
+    n_total, frames, ess = 4096, 9, (0.5 if L else 0.1)
+    one = _run_c_session_ranks(1, n_total, L, frames, transport=None, ess=ess)[0]
+    many = _run_c_session_ranks(world, n_total, L, frames, ess=ess)
+    assert np.array_equal(bits(np.concatenate([p["pose"] for p in many], axis=1)), bits(one["pose"]))
+    if L:
+        assert np.array_equal(bits(np.concatenate([p["map"] for p in many], axis=0)), bits(one["map"]))
+    for p in many:
+        assert p["resampled"] == one["resampled"] and 0 < p["resampled"] < frames - 1
+        assert p["best"][2] == one["best"][2]
