@@ -89,6 +89,15 @@ def occupancy(grid, pixel, min_x, min_y):
     return occ
 
 
+def morton(points, bits=10):
+    """Z-order key of 2-D points inside the room (ids assigned along a space-filling sweep)."""
+    q = np.clip(((points - [ROOM[0], ROOM[1]]) / [ROOM[2] - ROOM[0], ROOM[3] - ROOM[1]] * (1 << bits)).astype(np.int64), 0, (1 << bits) - 1)
+    key = np.zeros(len(points), np.int64)
+    for b in range(bits):
+        key |= ((q[:, 0] >> b) & 1) << (2 * b) | ((q[:, 1] >> b) & 1) << (2 * b + 1)
+    return key
+
+
 def true_pose(f):
     """Robot truth at frame f: 4 mm and 0.6 mrad per frame on an arc (theta in the reference's sign)."""
     th = -0.0006 * f
@@ -218,6 +227,12 @@ def main():
                     help="kernels bracketed by HIP events inside the timed region (a pair costs a few us of stream time)")
     ap.add_argument("--observed", type=int, default=0,
                     help="landmarks seen per frame: 0 = all (default, the roofline workload), K = the K nearest")
+    ap.add_argument("--ess", type=float, default=0.0,
+                    help="ESS-gated resampling: resample only in frames whose effective sample size is below ESS * N "
+                         "(0 = every frame, the default and the headline workload); --driver c")
+    ap.add_argument("--presort-poses", action="store_true",
+                    help="experiment, --mode score: upload the poses grouped by 4-pixel / matching-heading cells (what a "
+                         "spatial ordering of the lanes would buy the scorer)")
     ap.add_argument("--force-collectives", action="store_true",
                     help="diagnostics, --gpus 1 only: run the multi-GPU code path (every RCCL collective, the sharded index "
                          "kernels, the plan read-back) on a one-rank group to price its control overhead")
@@ -279,6 +294,8 @@ def main():
     rng = np.random.default_rng(4321)
     L = 0 if args.mode == "score" else args.landmarks
     landmarks = np.stack([rng.uniform(ROOM[0] + 0.5, ROOM[2] - 0.5, L), rng.uniform(ROOM[1] + 0.5, ROOM[3] - 0.5, L)], 1)
+    if L:   # landmark ids in discovery order along a sweep of the room: neighbours in space are neighbours in the map rows
+        landmarks = landmarks[np.argsort(morton(landmarks), kind="stable")]
     pixel = np.float32(20.48 / args.grid)
     min_x, min_y = np.float32(-4.24), np.float32(-10.24)
     occ = occupancy(args.grid, float(pixel), float(min_x), float(min_y))
@@ -306,7 +323,8 @@ def main():
                 dist.broadcast(uid, src=0)
             with stdout_to_stderr():   # RCCL prints its version banner to stdout; stdout carries ONE JSON line
                 comm = pkg.Comm.rccl(eng, rank, world, bytes(uid.cpu().tolist()))
-        pf = pkg.PfSession(eng, n, L, sigma=args.sigma, meas_var=args.meas_var, score_gain=args.score_gain, seed=1234, comm=comm)
+        pf = pkg.PfSession(eng, n, L, sigma=args.sigma, meas_var=args.meas_var, score_gain=args.score_gain, seed=1234, comm=comm,
+                           resample_ess_frac=args.ess)
         Lp = (L + 31) // 32 * 32
     else:
         pf = ParticleFilter(ops, n, L, device=dev, rank=rank, world=world, seed=1234, sigma=args.sigma,
@@ -324,7 +342,12 @@ def main():
 
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
     p0 = true_pose(0)
-    pf.set_poses(*((p0[k] + s * torch.randn(n, generator=g)).numpy() for k, s in ((0, 0.05), (1, 0.05), (2, 0.01))))
+    init = [(p0[k] + s * torch.randn(n, generator=g)).numpy() for k, s in ((0, 0.05), (1, 0.05), (2, 0.01))]
+    if args.presort_poses:
+        cell = 4.0 * float(pixel)
+        key = np.lexsort((np.floor(init[0] / cell), np.floor(init[1] / cell), np.floor(init[2] / (cell / 8.0))))
+        init = [a[key] for a in init]
+    pf.set_poses(*init)
     if L:
         lm = torch.from_numpy(landmarks.astype(np.float32)).to(dev)
         m0 = views()[1]                                   # [particle][plane][Lp]
@@ -513,7 +536,9 @@ def main():
                    "landmarks": L, "landmarks_observed_per_frame": L_obs,
                    "edt_grid": f"{args.grid}x{args.grid}", "parallelism": f"particle-shard x{world}" + (" (multi-GPU code path forced)" if args.force_collectives else ""),
                    "rows_received_per_frame_max_rank": migrated if world > 1 else 0,
-                   "distinct_ancestor_frac": distinct_frac},
+                   "distinct_ancestor_frac": distinct_frac,
+                   "resample_ess_frac": args.ess if use_c else 0.0,
+                   "frames_resampled": (pf.frames_resampled() if use_c and 0 < args.ess < 1 else None)},
         "roofline": {"bound": "hbm", "kernel": kern, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "achieved_basis": basis,
                      "algorithmic_bytes_per_launch": alg, "logical_rate_gbs": logical,

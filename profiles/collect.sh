@@ -23,4 +23,7 @@ for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --output-format csv -d "$OUT/${TAG}_pmc_${C}_pfobs32" -- $B --mode pf --observed 32 --steps 8 --warmup 2 --events none > /dev/null 2> "$OUT/${TAG}_pmc_${C}_pfobs32.err"
   rocprofv3 --pmc $C --output-format csv -d "$OUT/${TAG}_pmc_${C}_ekf" -- $B --mode ekf --steps 8 --warmup 2 --events none > /dev/null 2> "$OUT/${TAG}_pmc_${C}_ekf.err"
 done
+step "copy ceiling of the EKF access shape (pure copy, no arithmetic)"
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -o /tmp/copy_ceiling "$ROOT/profiles/copy_ceiling.hip"
+{ /tmp/copy_ceiling 65536 512; /tmp/copy_ceiling 1048576 1024; } > "$OUT/${TAG}_copy_ceiling.txt" 2>&1
 step done

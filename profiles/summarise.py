@@ -37,6 +37,8 @@ for mode, out in (("pf", "bench_pf"), ("score", "bench_score")):
     if f:
         shutil.copy(f[0], here / f"{tag}_{out}_kernel_stats.csv")
 
+if (src / f"{tag}_copy_ceiling.txt").exists():
+    shutil.copy(src / f"{tag}_copy_ceiling.txt", here / f"{tag}_copy_ceiling.txt")
 cal = counter("ekf", "FETCH_SIZE")
 factor = 20 * n * Lp / (sum(cal[2:]) / len(cal[2:]))
 traffic = {}
