@@ -761,11 +761,28 @@ __global__ __launch_bounds__(kBlock) void ancestors_from_scan_kernel(const uint6
     t_hi += t_lo < comb_u ? 1ull : 0ull;
     const uint64_t N = (uint64_t)n;
     int lo = 0, hi = n - 1;   // number of k in [0, n-1) with N*C_incl(k) <= T
+    // The search is a chain of dependent L2 round trips, so it is cut 8 ways per step instead of 2: seven pivots are
+    // loaded side by side (log8 n steps instead of log2 n: 48 -> ~20 us at 1M slots).  The predicate is monotone in k,
+    // so the new bounds are the largest pivot that satisfies it and the smallest that does not.
     while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        const uint64_t c = cdf_local[mid] + s_off[mid / kScanTile];
-        const uint64_t x_lo = c * N, x_hi = __umul64hi(c, N);
-        if (x_hi < t_hi || (x_hi == t_hi && x_lo <= t_lo)) lo = mid + 1; else hi = mid;
+        const int64_t span = hi - lo;
+        int mid[7];
+        uint64_t c[7];
+#pragma unroll
+        for (int t = 0; t < 7; ++t) {
+            mid[t] = lo + (int)((span * (t + 1)) >> 3);   // in [lo, hi)
+            c[t] = cdf_local[mid[t]] + s_off[mid[t] / kScanTile];
+        }
+        int nlo = lo, nhi = hi;
+#pragma unroll
+        for (int t = 0; t < 7; ++t) {
+            const uint64_t x_lo = c[t] * N, x_hi = __umul64hi(c[t], N);
+            const bool le = x_hi < t_hi || (x_hi == t_hi && x_lo <= t_lo);
+            nlo = le && mid[t] + 1 > nlo ? mid[t] + 1 : nlo;
+            nhi = !le && mid[t] < nhi ? mid[t] : nhi;
+        }
+        lo = nlo;
+        hi = nhi;
     }
     anc[j] = lo;
 }

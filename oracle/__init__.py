@@ -86,6 +86,8 @@ def lib() -> C.CDLL:
                                  _f32p, _f32p, C.c_int, C.c_float, _f32p]
     L.orc_logweight.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_int, _f32p, P(C.c_float)]
     L.orc_quantise_weights.argtypes = [_f32p, C.c_float, C.c_int, _u64p, P(_u64)]
+    L.orc_round_trick_mismatches.argtypes = [_u32, _u32, _u32]
+    L.orc_round_trick_mismatches.restype = _u64
     L.orc_ess_terms.argtypes = [_u64p, C.c_int, P(_u64), P(_u64)]
     L.orc_ess_resample.argtypes = [_u64, _u64, _i64, _u32]
     L.orc_ess_resample.restype = C.c_int

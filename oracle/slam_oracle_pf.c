@@ -394,3 +394,19 @@ void orc_ancestors(const int32_t *first_all, int64_t n_total, int64_t slot0, int
         anc[s] = (int32_t)(lo - 1);
     }
 }
+
+/* ------------------------------------------------------------------ test helper: the scorer's cell rounding
+ * The HIP scorer computes (int)roundf(v) as trunc(v + copysignf(0.5f - 1 ulp, v)).  This walks float bit patterns
+ * [lo, hi] (step `step`) and counts where that differs from libm's roundf — it must be 0 over all 2^32 patterns. */
+uint64_t orc_round_trick_mismatches(uint32_t lo, uint32_t hi, uint32_t step)
+{
+    uint64_t bad = 0;
+    for (uint64_t u = lo; u <= hi; u += step) {
+        const float v = f_from_bits((uint32_t)u);
+        if (v != v) continue;   /* NaN: both forms convert to 0 on the device */
+        const float a = truncf(v + copysignf(0x1.fffffep-2f, v));
+        const float b = roundf(v);
+        if (a != b) ++bad;
+    }
+    return bad;
+}

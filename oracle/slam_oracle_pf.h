@@ -83,6 +83,9 @@ void orc_offspring_offsets(const uint64_t *cdf, int n, uint64_t base, uint64_t t
                            int64_t n_total, int32_t *first);
 void orc_ancestors(const int32_t *first_all, int64_t n_total, int64_t slot0, int nslots, int32_t *anc);
 
+/* test helper for the scorer's rounding identity (see slam_oracle_pf.c) */
+uint64_t orc_round_trick_mismatches(uint32_t lo, uint32_t hi, uint32_t step);
+
 #ifdef __cplusplus
 }
 #endif

@@ -256,3 +256,9 @@ def test_resample_large_population_no_overflow(orc):
     first = orc.offspring_offsets(cdf, 0, big_total, u, n_total)
     assert first[0] == 0 and np.array_equal(first[1:], np.arange(1, n))   # equal weights: one tooth each
     assert total == (1 << 32) * n
+
+
+def test_scorer_rounding_identity_holds_for_every_float(orc):
+    """The HIP scorer selects cells with trunc(v + copysign(0.5 - 1 ulp, v)) instead of roundf(v) (main.c:483, 501):
+    the two agree on ALL 2^32 float bit patterns (NaN aside: both convert to cell 0 on the device)."""
+    assert orc.lib().orc_round_trick_mismatches(0, 0xFFFFFFFF, 1) == 0
