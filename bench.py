@@ -510,7 +510,8 @@ def main():
     traffic, traffic_src = None, None
     tfile = ROOT / "profiles" / "traffic.json"   # HBM bytes per launch from rocprofv3 --pmc runs of this same command
     if tfile.exists():
-        key = f"{args.mode}:{n}:{args.beams}:{L}:{args.grid}" + (f":obs{L_obs}" if L_obs != L else "")
+        key = (f"{args.mode}:{n}:{args.beams}:{L}:{args.grid}" + (f":obs{L_obs}" if L_obs != L else "")
+               + (f":ess{args.ess}" if 0 < args.ess < 1 else ""))   # a gated run has its own traffic (none on file: falls back)
         rec = json.loads(tfile.read_text()).get(key, {})
         traffic, traffic_src = rec.get(kern), rec.get("source")
     # `achieved`: the rate at which HBM itself was driven when the PMC traffic of this workload is on file; else the

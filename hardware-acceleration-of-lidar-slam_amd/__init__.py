@@ -111,6 +111,7 @@ SIGNATURES = {
     "slam_comm_world": (_i, [_vp]),
     "slam_comm_destroy": (_i, [_vp]),
     "slam_pf_create_sharded": (_i, [_vp, _vp, _vp, _i, C.POINTER(_vp)]),
+    "slam_pf_mean": (_i, [_vp, _f, _fp]),
     "slam_pf_rows_received": (_i, [_vp]),
     "slam_pf_device_view": (_i, [_vp, _vp]),
     "slam_pf_frames_resampled": (_i64, [_vp]),
@@ -559,6 +560,12 @@ class PfSession:
         lw, idx = C.c_float(0), C.c_int32(0)
         self.e._ck(self.e.lib.slam_pf_best(self.h, pose, C.byref(lw), C.byref(idx)), "pf_best")
         return np.array(list(pose), np.float32), np.float32(lw.value), idx.value
+
+    def mean(self, ref_theta: float):
+        """``slam_pf_mean``: posterior mean of the current population (heading averaged on the circle around ref_theta)."""
+        pose = (C.c_float * 3)()
+        self.e._ck(self.e.lib.slam_pf_mean(self.h, float(ref_theta), pose), "pf_mean")
+        return np.array(list(pose), np.float32)
 
     def poses(self):
         x, y, th = (np.empty(self.n, np.float32) for _ in range(3))

@@ -147,6 +147,15 @@ hipError_t launch_migrate_pack(hipStream_t stream, const int32_t* scratch, int n
 hipError_t launch_migrate_unpack(hipStream_t stream, const float* in, const MigratePlan& plan, int n, float* pose,
                                  int64_t pose_ld, float* map, int64_t row_stride, int plane_stride, int nlandmarks);
 hipError_t launch_argmax(hipStream_t stream, const float* v, int n, int32_t* idx_out, float* val_out);
+// heaviest particle {logw, global id (int bits), x, y, theta} -> out5 (device) and optionally mapped host memory + seq
+hipError_t launch_best_particle(hipStream_t stream, const float* v, int n, const float* px, const float* py,
+                                const float* pth, int64_t first_id, float* out5, float* h_out5, uint32_t* h_seq,
+                                uint32_t seq);
+// exact fixed-point sums of the population {x, y: 2^-32; sin, cos of (theta - ref): 2^-30} -> out4 (device), optionally
+// mapped host memory + seq; acc[4] / ticket: zero-initialised device scratch the kernel leaves zeroed
+hipError_t launch_pose_sums(hipStream_t stream, const float* x, const float* y, const float* th, const int32_t* idx,
+                            int n, float ref_th, unsigned long long* acc, unsigned int* ticket, long long* out4,
+                            long long* h_out4, uint32_t* h_seq, uint32_t seq);
 hipError_t launch_gather_f32(hipStream_t stream, const float* src, const int32_t* idx, int n, float* dst);
 hipError_t launch_gather_map(hipStream_t stream, const float* in, float* out, int64_t in_row_stride,
                              int64_t out_row_stride, int in_plane_stride, int out_plane_stride, int nlandmarks,

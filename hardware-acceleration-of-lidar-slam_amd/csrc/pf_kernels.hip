@@ -1112,6 +1112,89 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ 
     }
 }
 
+// The heaviest particle with its pose, in one launch: {logw, global id, x, y, theta} to device memory and, optionally,
+// to mapped host memory behind a sequence number (a plain C host then needs no copy and no stream synchronisation).
+__global__ __launch_bounds__(1024) void best_particle_kernel(const float* __restrict__ v, int n,
+                                                             const float* __restrict__ px, const float* __restrict__ py,
+                                                             const float* __restrict__ pth, int64_t first_id,
+                                                             float* __restrict__ out5, float* __restrict__ h_out5,
+                                                             uint32_t* __restrict__ h_seq, uint32_t seq)
+{
+    __shared__ float s_v[16];
+    __shared__ int s_i[16];
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        const float x = v[i];
+        if (x > bv || (x == bv && i < bi)) { bv = x; bi = i; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(bv, o);
+        const int oi = __shfl_xor(bi, o);
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if ((threadIdx.x & 63) == 0) { s_v[threadIdx.x >> 6] = bv; s_i[threadIdx.x >> 6] = bi; }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    for (int w = 1; w < 16; ++w)
+        if (s_v[w] > bv || (s_v[w] == bv && s_i[w] < bi)) { bv = s_v[w]; bi = s_i[w]; }
+    if (bi == 0x7fffffff) bi = 0;
+    const float r[5] = { bv, __int_as_float((int32_t)(first_id + bi)), px[bi], py[bi], pth[bi] };
+    for (int k = 0; k < 5; ++k) out5[k] = r[k];
+    if (h_out5) {
+        for (int k = 0; k < 5; ++k) h_out5[k] = r[k];
+        __threadfence_system();
+        __hip_atomic_store(h_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+// Exact, order-independent sums over the population for the posterior mean: x and y as 2^-32 fixed point, the heading
+// as sin / cos of (theta - ref) in 2^-30 fixed point (det_sincosf: the specified polynomial), accumulated with 64-bit
+// integer atomics — the same bits for any summation order, workgroup count or sharding.  idx (optional): the pending
+// resample gather.  The last workgroup to finish (a ticket) hands the four sums over — to device memory and,
+// optionally, mapped host memory behind a sequence number — and clears the accumulators for the next call.
+__global__ __launch_bounds__(kBlock) void pose_sums_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                           const float* __restrict__ th, const int32_t* __restrict__ idx,
+                                                           int n, float ref_th, unsigned long long* __restrict__ acc,
+                                                           unsigned int* __restrict__ ticket, long long* __restrict__ out4,
+                                                           long long* __restrict__ h_out4, uint32_t* __restrict__ h_seq,
+                                                           uint32_t seq)
+{
+    __shared__ uint64_t s_red[kBlock / 64];
+    uint64_t sx = 0, sy = 0, ss = 0, sc = 0;   // two's complement: signed sums through unsigned adds
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        const int j = idx ? idx[i] : i;
+        float s, c;
+        det_sincosf(th[j] - ref_th, s, c);
+        sx += (uint64_t)(long long)(x[j] * 4294967296.0f);
+        sy += (uint64_t)(long long)(y[j] * 4294967296.0f);
+        ss += (uint64_t)(long long)(s * 1073741824.0f);
+        sc += (uint64_t)(long long)(c * 1073741824.0f);
+    }
+    sx = block_sum_u64(sx, s_red);
+    sy = block_sum_u64(sy, s_red);
+    ss = block_sum_u64(ss, s_red);
+    sc = block_sum_u64(sc, s_red);
+    if (threadIdx.x != 0) return;
+    atomicAdd(&acc[0], (unsigned long long)sx);
+    atomicAdd(&acc[1], (unsigned long long)sy);
+    atomicAdd(&acc[2], (unsigned long long)ss);
+    atomicAdd(&acc[3], (unsigned long long)sc);
+    __threadfence();
+    if (atomicAdd(ticket, 1u) != gridDim.x - 1) return;
+    __threadfence();
+    long long r[4];
+    for (int k = 0; k < 4; ++k) r[k] = (long long)atomicExch(&acc[k], 0ull);   // read and clear for the next call
+    *ticket = 0;
+    for (int k = 0; k < 4; ++k) out4[k] = r[k];
+    if (h_out4) {
+        for (int k = 0; k < 4; ++k) h_out4[k] = r[k];
+        __threadfence_system();
+        __hip_atomic_store(h_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 inline int blocks_for(int n) { return (n + kBlock - 1) / kBlock; }
 
 }  // namespace
@@ -1309,6 +1392,25 @@ hipError_t launch_argmax(hipStream_t stream, const float* v, int n, int32_t* idx
 {
     if (n <= 0) return hipSuccess;
     argmax_kernel<<<1, 1024, 0, stream>>>(v, n, idx_out, val_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_best_particle(hipStream_t stream, const float* v, int n, const float* px, const float* py,
+                                const float* pth, int64_t first_id, float* out5, float* h_out5, uint32_t* h_seq,
+                                uint32_t seq)
+{
+    if (n <= 0) return hipSuccess;
+    best_particle_kernel<<<1, 1024, 0, stream>>>(v, n, px, py, pth, first_id, out5, h_out5, h_seq, seq);
+    return hipGetLastError();
+}
+
+hipError_t launch_pose_sums(hipStream_t stream, const float* x, const float* y, const float* th, const int32_t* idx,
+                            int n, float ref_th, unsigned long long* acc, unsigned int* ticket, long long* out4,
+                            long long* h_out4, uint32_t* h_seq, uint32_t seq)
+{
+    if (n <= 0) return hipSuccess;
+    const int nb = blocks_for(n) < 256 ? blocks_for(n) : 256;
+    pose_sums_kernel<<<nb, kBlock, 0, stream>>>(x, y, th, idx, n, ref_th, acc, ticket, out4, h_out4, h_seq, seq);
     return hipGetLastError();
 }
 

@@ -7,6 +7,7 @@
 // "handle created once in main and threaded through" is the reference's (Hadrware_acclereated.cpp:842-845, 284).
 
 #include <hip/hip_runtime.h>
+#include <math.h>
 #include <stdio.h>
 #include <string.h>
 
@@ -51,6 +52,14 @@ struct slam_pf {
     float* cand = nullptr;          // [world][5] best-particle candidates
     bool exchange_pending = false;  // resample done, map rows not exchanged yet
     int rows_received = 0;
+    // results a host asks for every frame (heaviest particle, posterior mean): written by ONE kernel to mapped host
+    // memory behind a sequence number — no device-to-host copies, no stream synchronisation
+    float* h_res = nullptr;         // pinned + mapped: 8 x 8 bytes of payload, then the sequence number
+    float* d_hres = nullptr;        // the same memory as the device sees it
+    uint32_t res_seq = 0;
+    float* res_dev = nullptr;       // device copy of the payload (what the ranks all-gather)
+    unsigned long long* sums_acc = nullptr;   // 4 accumulators + ticket of pose_sums_kernel (kept zeroed by the kernel)
+    void* res_all = nullptr;        // [world] payloads
     bool gated = false;             // cfg.resample_ess_frac in (0, 1): a frame resamples only when its ESS is low
     int64_t frames_resampled = 0;   // (as far as the host has looked: one frame behind)
 };
@@ -133,6 +142,18 @@ int drop_resample(slam_pf* pf)
     return SLAM_OK;
 }
 
+// wait for a result kernel's sequence number in mapped host memory (bounded spin, then let the runtime tell us)
+int wait_result(slam_pf* pf, uint32_t seq)
+{
+    slam_engine* e = pf->e;
+    volatile uint32_t* h_seq = reinterpret_cast<volatile uint32_t*>(pf->h_res + 16);
+    for (long spin = 0; spin < 400000000L; ++spin)
+        if (__atomic_load_n(h_seq, __ATOMIC_ACQUIRE) == seq) return SLAM_OK;
+    SLAM_HIP_TRY(e, hipStreamSynchronize(e->stream));
+    if (__atomic_load_n(h_seq, __ATOMIC_ACQUIRE) != seq) return slam_engine_fail_hip(e, hipErrorUnknown, "result flag");
+    return SLAM_OK;
+}
+
 int gathered_copy_out(slam_pf* pf, const float* d_src, const int32_t* idx, float* h_dst, float* d_tmp)
 {
     // d_src gathered through idx on the device (idx == nullptr: as is), then copied back
@@ -183,7 +204,13 @@ int create_common(slam_engine* e, const slam_pf_config* cfg, slam_comm* comm, in
     }
     ok = ok && dev_alloc((void**)&pf->score, n * 4) == hipSuccess && dev_alloc((void**)&pf->logw, n * 4) == hipSuccess &&
          dev_alloc((void**)&pf->count, n * 4) == hipSuccess && dev_alloc((void**)&pf->first, n * 4) == hipSuccess &&
-         dev_alloc((void**)&pf->best_idx, 4) == hipSuccess && dev_alloc((void**)&pf->best_val, 4) == hipSuccess;
+         dev_alloc((void**)&pf->best_idx, 4) == hipSuccess && dev_alloc((void**)&pf->best_val, 4) == hipSuccess &&
+         dev_alloc((void**)&pf->res_dev, 64) == hipSuccess && dev_alloc((void**)&pf->sums_acc, 64) == hipSuccess &&
+         dev_alloc(&pf->res_all, 64 * G) == hipSuccess &&
+         hipMemset(pf->sums_acc, 0, 64) == hipSuccess &&
+         hipHostMalloc((void**)&pf->h_res, 128, hipHostMallocMapped) == hipSuccess &&
+         hipHostGetDevicePointer((void**)&pf->d_hres, pf->h_res, 0) == hipSuccess;
+    if (ok) memset(pf->h_res, 0, 128);
     if (comm)
         ok = ok && dev_alloc((void**)&pf->pose_all, 3 * n * G * 4) == hipSuccess &&
              dev_alloc((void**)&pf->pose_stage, 3 * cap * 4) == hipSuccess &&
@@ -249,8 +276,9 @@ int slam_pf_destroy(slam_pf* pf)
     for (void* p : { (void*)pf->score, (void*)pf->logw, (void*)pf->count, (void*)pf->first, (void*)pf->best_idx,
                      (void*)pf->best_val, (void*)pf->pose_all, (void*)pf->pose_stage, (void*)pf->first_all,
                      (void*)pf->d_max, (void*)pf->d_sum, (void*)pf->totals, (void*)pf->d_plan, (void*)pf->sbuf,
-                     (void*)pf->rbuf, (void*)pf->cand })
+                     (void*)pf->rbuf, (void*)pf->cand, (void*)pf->res_dev, (void*)pf->sums_acc, pf->res_all })
         (void)hipFree(p);
+    if (pf->h_res) (void)hipHostFree(pf->h_res);
     delete pf;
     return SLAM_OK;
 }
@@ -424,38 +452,75 @@ int slam_pf_best(slam_pf* pf, float pose[3], float* logw, int32_t* index)
 {
     if (!pf || !pose) return SLAM_ERR_INVALID_ARG;
     slam_engine* e = pf->e;
+    SLAM_HIP_TRY(e, hipSetDevice(e->device));
     // the log-weights of the last frame belong to pose[cur] BEFORE the pending gather
-    int rc = slam_argmax_dev(e, pf->logw, pf->n, pf->best_idx, pf->best_val);
-    if (rc != SLAM_OK) return rc;
-    if ((rc = slam_engine_sync(e)) != SLAM_OK) return rc;
-    int32_t idx = 0;
-    float val = 0;
-    if (hipMemcpy(&idx, pf->best_idx, 4, hipMemcpyDeviceToHost) != hipSuccess ||
-        hipMemcpy(&val, pf->best_val, 4, hipMemcpyDeviceToHost) != hipSuccess)
-        return SLAM_ERR_HIP;
     const float* p = pf->pose[pf->cur];
-    float mine[5] = { val, 0, 0, 0, 0 };
-    for (int k = 0; k < 3; ++k)
-        if (hipMemcpy(&mine[2 + k], p + (size_t)k * pf->n + idx, 4, hipMemcpyDeviceToHost) != hipSuccess) return SLAM_ERR_HIP;
-    int32_t gid = (int32_t)((int64_t)pf->rank * pf->n + idx);
-    if (pf->comm) {   // every rank's candidate to every rank; the first maximum = the lowest rank = the lowest id
-        memcpy(&mine[1], &gid, 4);
-        float* mine_dev = pf->pose_stage;   // scratch
-        SLAM_HIP_TRY(e, hipMemcpyAsync(mine_dev, mine, sizeof mine, hipMemcpyHostToDevice, e->stream));
-        SLAM_HIP_TRY(e, hipStreamSynchronize(e->stream));
-        if ((rc = comm_all_gather(pf->comm, mine_dev, pf->cand, sizeof mine)) != SLAM_OK) return rc;
+    const size_t sn = (size_t)pf->n;
+    float r[5];
+    if (!pf->comm) {   // one launch, the result lands in mapped host memory: no copy, no stream synchronisation
+        const uint32_t seq = ++pf->res_seq;
+        SLAM_HIP_TRY(e, launch_best_particle(e->stream, pf->logw, pf->n, p, p + sn, p + 2 * sn, 0, pf->res_dev, pf->d_hres,
+                                             reinterpret_cast<uint32_t*>(pf->d_hres + 16), seq));
+        if (int rc = wait_result(pf, seq)) return rc;
+        memcpy(r, pf->h_res, sizeof r);
+    } else {   // every rank's candidate to every rank; the first maximum = the lowest rank = the lowest id
+        SLAM_HIP_TRY(e, launch_best_particle(e->stream, pf->logw, pf->n, p, p + sn, p + 2 * sn, (int64_t)pf->rank * pf->n,
+                                             pf->res_dev, nullptr, nullptr, 0));
+        if (int rc = comm_all_gather(pf->comm, pf->res_dev, pf->res_all, 5 * sizeof(float))) return rc;
         std::vector<float> all(5 * (size_t)pf->world);
-        SLAM_HIP_TRY(e, hipMemcpyAsync(all.data(), pf->cand, all.size() * 4, hipMemcpyDeviceToHost, e->stream));
+        SLAM_HIP_TRY(e, hipMemcpyAsync(all.data(), pf->res_all, all.size() * 4, hipMemcpyDeviceToHost, e->stream));
         SLAM_HIP_TRY(e, hipStreamSynchronize(e->stream));
         int best = 0;
         for (int q = 1; q < pf->world; ++q)
             if (all[5 * q] > all[5 * best]) best = q;
-        memcpy(mine, &all[5 * best], sizeof mine);
-        memcpy(&gid, &mine[1], 4);
+        memcpy(r, &all[5 * best], sizeof r);
     }
-    for (int k = 0; k < 3; ++k) pose[k] = mine[2 + k];
-    if (logw) *logw = mine[0];
+    int32_t gid;
+    memcpy(&gid, &r[1], 4);
+    for (int k = 0; k < 3; ++k) pose[k] = r[2 + k];
+    if (logw) *logw = r[0];
     if (index) *index = gid;
+    return SLAM_OK;
+}
+
+int slam_pf_mean(slam_pf* pf, float ref_theta, float pose[3])
+{
+    if (!pf || !pose) return SLAM_ERR_INVALID_ARG;
+    slam_engine* e = pf->e;
+    SLAM_HIP_TRY(e, hipSetDevice(e->device));
+    const size_t sn = (size_t)pf->n;
+    const float *x = pf->pose[pf->cur], *y = x + sn, *th = x + 2 * sn;
+    const int32_t* idx = pf->has_anc ? pf->anc[pf->cur] : nullptr;
+    if (pf->comm && pf->has_anc) {   // the ancestors' poses are in the all-gathered array
+        if (int rc = comm_all_gather_finish(pf->comm)) return rc;
+        x = pf->pose_all;
+        y = x + sn;
+        th = x + 2 * sn;
+        idx = pf->pose_idx[pf->cur];
+    }
+    unsigned int* ticket = reinterpret_cast<unsigned int*>(pf->sums_acc + 4);
+    long long sums[4] = { 0, 0, 0, 0 };
+    if (!pf->comm) {
+        const uint32_t seq = ++pf->res_seq;
+        SLAM_HIP_TRY(e, launch_pose_sums(e->stream, x, y, th, idx, pf->n, ref_theta, pf->sums_acc, ticket,
+                                         reinterpret_cast<long long*>(pf->res_dev), reinterpret_cast<long long*>(pf->d_hres),
+                                         reinterpret_cast<uint32_t*>(pf->d_hres + 16), seq));
+        if (int rc = wait_result(pf, seq)) return rc;
+        memcpy(sums, pf->h_res, sizeof sums);
+    } else {   // integer sums: adding the ranks' shares in any order gives the single-GPU bits
+        SLAM_HIP_TRY(e, launch_pose_sums(e->stream, x, y, th, idx, pf->n, ref_theta, pf->sums_acc, ticket,
+                                         reinterpret_cast<long long*>(pf->res_dev), nullptr, nullptr, 0));
+        if (int rc = comm_all_gather(pf->comm, pf->res_dev, pf->res_all, 4 * sizeof(long long))) return rc;
+        std::vector<long long> all(4 * (size_t)pf->world);
+        SLAM_HIP_TRY(e, hipMemcpyAsync(all.data(), pf->res_all, all.size() * 8, hipMemcpyDeviceToHost, e->stream));
+        SLAM_HIP_TRY(e, hipStreamSynchronize(e->stream));
+        for (int q = 0; q < pf->world; ++q)
+            for (int k = 0; k < 4; ++k) sums[k] += all[4 * (size_t)q + k];
+    }
+    const double nt = (double)pf->n_total;
+    pose[0] = (float)((double)sums[0] / 4294967296.0 / nt);
+    pose[1] = (float)((double)sums[1] / 4294967296.0 / nt);
+    pose[2] = (float)((double)ref_theta + atan2((double)sums[2], (double)sums[3]));
     return SLAM_OK;
 }
 

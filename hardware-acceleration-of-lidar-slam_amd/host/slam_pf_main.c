@@ -8,7 +8,7 @@
  * runs one particle-filter step on the GPU — N particles are moved by the constant-velocity increment of
  * main.c:875-898 plus noise, each is scored against the fine EDT with the reference's own score function,
  * weights are normalised and the population is resampled; the frame's pose is the mean of the resampled
- * (hence equally weighted) population, accumulated in double in index order — or, with estimator "best", the
+ * (hence equally weighted) population (exact fixed-point sums on the device) — or, with estimator "best", the
  * heaviest particle.
  * All of it goes through the C ABI (slam_pf_* in include/slam_hip.h); no HIP or RCCL type appears here.
  *
@@ -52,8 +52,6 @@ typedef struct {
     int world, use_rccl, same_device;
     uint8_t comm_id[SLAM_COMM_ID_BYTES];
     slam_local_group *group;
-    pthread_barrier_t barrier;
-    float *px, *py, *pt;   /* [particles_total] host copies of the population, one block per rank (mean estimator) */
 } run_t;
 
 typedef struct {
@@ -70,11 +68,6 @@ typedef struct {
             goto fail;                                                                                            \
         }                                                                                                         \
     } while (0)
-
-static void rendezvous(run_t *run)
-{
-    if (run->world > 1) pthread_barrier_wait(&run->barrier);
-}
 
 static void *rank_main(void *arg)
 {
@@ -159,24 +152,11 @@ static void *rank_main(void *arg)
         CHECK(slam_pf_step(pf, 1, dp, 0));
         float best[3];
         if (run->use_mean) {
-            /* posterior mean = plain mean of the resampled population, over ALL ranks' particles in index order (so the
-             * result does not depend on the number of GPUs).  Headings are averaged on the circle, around the predicted
-             * heading, so that a population straddling +-pi does not average to nonsense and theta stays unwrapped
-             * (the reference never normalises angles). */
-            CHECK(slam_pf_get_poses_host(pf, run->px + (size_t)rank * n, run->py + (size_t)rank * n, run->pt + (size_t)rank * n));
-            rendezvous(run);
-            const double ref = (double)pose[2] + (double)dp[2];
-            double sx = 0, sy = 0, ss = 0, sc = 0;
-            for (int i = 0; i < n_total; ++i) {
-                sx += run->px[i];
-                sy += run->py[i];
-                ss += sin((double)run->pt[i] - ref);
-                sc += cos((double)run->pt[i] - ref);
-            }
-            best[0] = (float)(sx / n_total);
-            best[1] = (float)(sy / n_total);
-            best[2] = (float)(ref + atan2(ss, sc));
-            rendezvous(run);   /* nobody overwrites the shared arrays before everyone has summed them */
+            /* posterior mean = plain mean of the resampled population, over ALL ranks' particles: exact integer sums made on
+             * the device (slam_pf_mean), so the result does not depend on the number of GPUs.  Headings are averaged on the
+             * circle, around the predicted heading, so that a population straddling +-pi does not average to nonsense and
+             * theta stays unwrapped (the reference never normalises angles). */
+            CHECK(slam_pf_mean(pf, pose[2] + dp[2], best));
         } else {
             CHECK(slam_pf_best(pf, best, NULL, NULL));   /* sharded: the heaviest of the whole population, on every rank */
         }
@@ -272,12 +252,6 @@ int main(int argc, char **argv)
             return 1;
         }
     }
-    const size_t nt = (size_t)run.particles_total;
-    run.px = (float *)calloc(nt, sizeof(float));
-    run.py = (float *)calloc(nt, sizeof(float));
-    run.pt = (float *)calloc(nt, sizeof(float));
-    if (!run.px || !run.py || !run.pt) { fprintf(stderr, "out of memory\n"); return 1; }
-    if (run.world > 1) pthread_barrier_init(&run.barrier, NULL, (unsigned)run.world);
 
     rank_t ranks[16];
     pthread_t th[16];
@@ -287,11 +261,9 @@ int main(int argc, char **argv)
     } else {
         for (int r = 0; r < run.world; ++r) pthread_create(&th[r], NULL, rank_main, &ranks[r]);
         for (int r = 0; r < run.world; ++r) pthread_join(th[r], NULL);
-        pthread_barrier_destroy(&run.barrier);
     }
     int rc = 0;
     for (int r = 0; r < run.world; ++r) rc |= ranks[r].rc;
     slam_local_group_destroy(run.group);
-    free(run.px); free(run.py); free(run.pt);
     return rc;
 }

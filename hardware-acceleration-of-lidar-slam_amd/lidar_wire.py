@@ -49,8 +49,14 @@ class ScanServer:
 
             def do_GET(self):
                 q = parse_qs(self.path[2:], keep_blank_values=False)
-                row = int(q.get("param", ["0"])[0])
+                try:
+                    row = int(q.get("param", ["0"])[0])
+                except ValueError:
+                    row = -1
                 log.append((row, q.get("pose_x", [None])[0], q.get("pose_y", [None])[0]))
+                if not 0 <= row < len(rows):   # the reference would raise inside the handler; answer like a server
+                    self.send_error(404, "no such scan row")
+                    return
                 body = json.dumps(rows[row]).encode()
                 self.send_response(200)
                 self.send_header("Content-type", "application/json")
@@ -69,17 +75,25 @@ class ScanServer:
         self.httpd.server_close()
 
 
-def fetch_scan(host, port, row, pose_x=0.0, pose_y=0.0, conn=None):
-    """One scan frame as float32, requested exactly like esp32_edge.c:59 does."""
+def fetch_scan(host, port, row, pose_x=0.0, pose_y=0.0, conn=None, nbeams=None):
+    """One scan frame as float32, requested exactly like esp32_edge.c:59 does.  The peer is untrusted: with `nbeams`
+    given, anything but a flat array of exactly that many numbers raises ValueError (the C side reads exactly
+    nbeams floats from the buffer it is handed)."""
     own = conn is None
     if own:
         conn = http.client.HTTPConnection(host, port, timeout=10)
     conn.request("GET", "/?param=&param=%d&pose_x=%f&pose_y=%f" % (row, pose_x, pose_y))
     resp = conn.getresponse()
-    data = json.loads(resp.read())   # http.client undoes the chunked framing
+    raw = resp.read()   # http.client undoes the chunked framing
     if own:
         conn.close()
-    return np.asarray(data, np.float64).astype(np.float32)   # (float)valuedouble, esp32_edge.c:86
+    if resp.status != 200:
+        raise ValueError(f"scan row {row}: HTTP {resp.status}")
+    data = json.loads(raw)
+    r = np.asarray(data, np.float64).astype(np.float32)   # (float)valuedouble, esp32_edge.c:86
+    if nbeams is not None and (r.ndim != 1 or r.size != nbeams):
+        raise ValueError(f"scan row {row}: expected {nbeams} ranges, got an array of shape {r.shape}")
+    return r
 
 
 def run_mapper_over_http(pkg, engine, host, port, frames, nbeams=1079, angle_min=-2.351831, angle_inc=0.004363,
@@ -93,10 +107,10 @@ def run_mapper_over_http(pkg, engine, host, port, frames, nbeams=1079, angle_min
     engine._ck(lib.slam_mapper_create(engine.h, nbeams, angle_min, angle_inc, C.byref(mp)), "mapper_create")
     poses, pose = [], (C.c_float * 3)(0, 0, 0)
     try:
-        r = np.ascontiguousarray(fetch_scan(host, port, first_row, conn=conn))
+        r = np.ascontiguousarray(fetch_scan(host, port, first_row, conn=conn, nbeams=nbeams))
         engine._ck(lib.slam_mapper_first_frame(mp, r.ctypes.data_as(C.c_void_p)), "mapper_first_frame")
         for k in range(1, frames):
-            r = np.ascontiguousarray(fetch_scan(host, port, first_row + k, pose[0], pose[1], conn=conn))
+            r = np.ascontiguousarray(fetch_scan(host, port, first_row + k, pose[0], pose[1], conn=conn, nbeams=nbeams))
             engine._ck(lib.slam_mapper_next_frame(mp, r.ctypes.data_as(C.c_void_p), pose), "mapper_next_frame")
             poses.append([pose[0], pose[1], pose[2]])
     finally:

@@ -405,6 +405,14 @@ int slam_pf_step(slam_pf *pf, int slot, const float dp[3], int use_observations)
 /* heaviest particle of the last frame (lowest index on ties): its pose, log-weight and index; synchronises.
  * Sharded: the heaviest of the whole population (the same answer on every rank), `index` is its global id. */
 int slam_pf_best(slam_pf *pf, float pose[3], float *logw, int32_t *index);
+/* Posterior mean of the current (resampled, hence equally weighted) population: x and y are averaged, the heading is
+ * averaged on the circle around `ref_theta` (theta = ref + atan2(sum sin(theta_i - ref), sum cos(theta_i - ref)), so a
+ * population straddling +-pi does not average to nonsense and theta stays unwrapped — the reference never normalises
+ * angles; pass the predicted heading).  The sums are exact fixed-point integer sums made on the device (x, y
+ * in 2^-32, sin / cos in 2^-30 units), so the result is bit-identical for any workgroup count and any number of GPUs;
+ * one launch, the four sums land in mapped host memory (no copy of the population, no stream synchronisation).
+ * Sharded: collective, the same answer on every rank. */
+int slam_pf_mean(slam_pf *pf, float ref_theta, float pose[3]);
 /* rows this rank received in the exchange of the last completed frame (0 on a single GPU) */
 int slam_pf_rows_received(const slam_pf *pf);
 /* With cfg.resample_ess_frac in (0, 1): how many of the frames the host has looked at so far did resample (the

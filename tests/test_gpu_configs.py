@@ -205,7 +205,8 @@ def _run_c_session_ranks(world, n_total, L, frames, transport="local", recv_capa
                 rows.append(ses.rows_received())
                 if f % 3 == 1:
                     bests.append(ses.best())                 # collective; must not disturb the pending exchange
-            res = {"pose": ses.poses(), "best": ses.best(), "rows": rows, "bests": bests, "resampled": ses.frames_resampled()}
+            res = {"pose": ses.poses(), "best": ses.best(), "rows": rows, "bests": bests, "resampled": ses.frames_resampled(),
+                   "mean": ses.mean(0.07)}
             if L:
                 res["map"] = ses.maps()
             out[r] = res
@@ -246,6 +247,16 @@ def test_c_sharded_session_ranks_on_one_card_equal_one_rank(orc, world, n_total,
         for a, b in zip(p["bests"], one["bests"]):
             assert a[2] == b[2] and a[1] == b[1] and np.array_equal(bits(a[0]), bits(b[0]))
     assert max(max(p["rows"]) for p in many) > 10      # rows really travelled between the ranks
+    # posterior mean (slam_pf_mean): exact integer sums on the device -> the same bits on every rank and for one GPU,
+    # and equal to the same fixed-point sums made with numpy from the population itself
+    for p in many:
+        assert np.array_equal(bits(p["mean"]), bits(one["mean"]))
+    x, y, th = one["pose"]
+    s, c = orc.det_sincos((th - np.float32(0.07)).astype(np.float32))
+    fx = lambda a, sh: int(np.trunc(a.astype(np.float64) * 2.0 ** sh).astype(np.int64).sum())
+    n = x.size
+    assert one["mean"][0] == np.float32(fx(x, 32) / 2.0 ** 32 / n) and one["mean"][1] == np.float32(fx(y, 32) / 2.0 ** 32 / n)
+    assert abs(float(one["mean"][2]) - (0.07 + np.arctan2(float(fx(s, 30)), float(fx(c, 30))))) < 1e-6
 
 
 def test_c_sharded_session_over_rccl_one_rank(orc):

@@ -67,3 +67,22 @@ def test_mapper_fed_over_http_matches_reference_poses(orc, tmp_path):
             (GOLDEN / "parity_pose.txt").read_text().splitlines()[:59]]
     got = [[float("%f" % v) for v in p] for p in poses]
     assert got == want
+
+
+def test_untrusted_peer_is_validated(golden):
+    """The scan length comes from the network: a short or long row must not reach the C side (which reads exactly nbeams
+    floats from the buffer), and an out-of-range row index is answered with 404, not an exception in the handler."""
+    wire = _wire()
+    srv = wire.ScanServer(GOLDEN / "frames_head.csv", pandas_header=False)
+    try:
+        assert wire.fetch_scan("127.0.0.1", srv.port, 0, nbeams=1079).shape == (1079,)
+        with pytest.raises(ValueError):
+            wire.fetch_scan("127.0.0.1", srv.port, 0, nbeams=360)        # longer than expected: not silently truncated
+        with pytest.raises(ValueError):
+            wire.fetch_scan("127.0.0.1", srv.port, 0, nbeams=2000)       # shorter than expected
+        for bad in (3, 9000, -1):
+            with pytest.raises(ValueError):
+                wire.fetch_scan("127.0.0.1", srv.port, bad, nbeams=1079)  # 404 from the server
+        assert wire.fetch_scan("127.0.0.1", srv.port, 2, nbeams=1079).shape == (1079,)   # the server survived
+    finally:
+        srv.close()
