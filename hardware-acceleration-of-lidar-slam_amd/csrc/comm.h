@@ -28,6 +28,9 @@ slam_engine* comm_engine(const slam_comm* c);
 int comm_all_reduce_max_f32(slam_comm* c, float* d_buf, int count);
 // d_recv[q * bytes .. ) = rank q's d_send[0 .. bytes)
 int comm_all_gather(slam_comm* c, const void* d_send, void* d_recv, size_t bytes);
+// two all-gathers as one grouped operation (one launch, one latency)
+int comm_all_gather2(slam_comm* c, const void* d_send_a, void* d_recv_a, size_t bytes_a, const void* d_send_b,
+                     void* d_recv_b, size_t bytes_b);
 // begin / finish form: the result may be used only after comm_all_gather_finish (today both are stream-ordered, so
 // finish has nothing to wait for; the pair marks where a transport with overlap would hand over)
 int comm_all_gather_begin(slam_comm* c, const void* d_send, void* d_recv, size_t bytes);

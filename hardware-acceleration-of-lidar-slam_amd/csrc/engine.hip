@@ -129,7 +129,7 @@ int slam_engine_create(int device, slam_engine** out)
         hipHostGetDevicePointer((void**)&e->d_hplan, e->h_plan, 0) != hipSuccess ||
         hipHostMalloc((void**)&e->h_gate, sizeof(int32_t) * 2, hipHostMallocMapped) != hipSuccess ||
         hipHostGetDevicePointer((void**)&e->d_hgate, e->h_gate, 0) != hipSuccess ||
-        e->gate_buf.ensure(sizeof(int32_t)) != hipSuccess ||
+        e->gate_buf.ensure(2 * sizeof(int32_t)) != hipSuccess ||   // the gate's flag + the ticket word of quantise_scan_kernel
         e->scan_buf.ensure(sizeof(float) * 2 * SLAM_MAX_BEAMS) != hipSuccess ||
         hipHostMalloc((void**)&e->h_stage, sizeof(float) * kStageSlots * kStageFloats, hipHostMallocDefault) !=
             hipSuccess) {
@@ -142,8 +142,8 @@ int slam_engine_create(int device, slam_engine** out)
     e->h_gate[0] = 1;
     e->h_gate[1] = 0;
     {
-        const int32_t one = 1;   // "the previous frame resampled": nothing is carried into the first frame
-        if (hipMemcpy(e->gate_buf.p, &one, sizeof one, hipMemcpyHostToDevice) != hipSuccess) {
+        const int32_t one[2] = { 1, 0 };   // "the previous frame resampled": nothing is carried into the first frame; ticket = 0
+        if (hipMemcpy(e->gate_buf.p, one, sizeof one, hipMemcpyHostToDevice) != hipSuccess) {
             (void)hipGetLastError();
             slam_engine_destroy(e);
             return SLAM_ERR_NO_DEVICE;
@@ -661,7 +661,10 @@ static int logweight_common(slam_engine* e, const float* d_score, const float* d
                             float* d_logw, float* d_max)
 {
     if (n <= 0 || !d_logw) return SLAM_ERR_INVALID_ARG;
-    HIP_TRY(e->bmax_buf.ensure(sizeof(float) * (size_t)logweight_scratch_elems(n)));
+    if (e->bmax_buf.cap < sizeof(float) * (size_t)logweight_scratch_floats()) {   // block maxima + a ticket word kept at zero
+        HIP_TRY(e->bmax_buf.ensure(sizeof(float) * (size_t)logweight_scratch_floats()));
+        HIP_TRY(hipMemsetAsync(e->bmax_buf.p, 0, e->bmax_buf.cap, e->stream));
+    }
     // with a resample gate: the weights of a frame that did not resample carry into this one (device-side decision)
     const bool carry = e->gate_frac_q16 != 0 && e->carry_n == n;
     HIP_TRY(launch_logweight(e->stream, d_score, d_loglik, score_gain, n, d_logw, e->bmax_buf.as<float>(), d_max,
@@ -700,7 +703,7 @@ int slam_quantise_scan_dev(slam_engine* e, const float* d_logw, const float* d_m
         carry = e->carry_buf.as<float>();
     }
     HIP_TRY(launch_quantise_scan(e->stream, d_logw, d_max, e->bmax_buf.as<float>(), e->bmax_count, n, cdf, tiles, d_sum,
-                                 carry, tiles + ntiles, tiles + 2 * ntiles));
+                                 carry, tiles + ntiles, tiles + 2 * ntiles, e->gate_buf.as<unsigned int>() + 1));
     e->scan_n = n;
     e->carry_n = carry ? n : -1;
     return SLAM_OK;

@@ -95,6 +95,7 @@ hipError_t launch_logweight(hipStream_t stream, const float* score, const float*
                             float* logw, float* block_max_scratch, float* d_max, const float* carry = nullptr,
                             const int32_t* prev_resampled = nullptr);
 int logweight_scratch_elems(int n);
+int logweight_scratch_floats();   // size of block_max_scratch: block maxima + one ticket word, zero-initialised once
 hipError_t launch_quantise_weights(hipStream_t stream, const float* logw, const float* d_max, int n, uint64_t* wq,
                                    uint64_t* d_sum);
 
@@ -111,7 +112,8 @@ struct GateOut {
 // carry != nullptr).  With a gate d_sum receives three values (total, S, Q) and d_shard_totals holds such triples.
 hipError_t launch_quantise_scan(hipStream_t stream, const float* logw, const float* d_max, const float* block_max,
                                 int nblock_max, int n, uint64_t* cdf_local, uint64_t* tile_total, uint64_t* d_sum,
-                                float* carry = nullptr, uint64_t* tile_s16 = nullptr, uint64_t* tile_q16 = nullptr);
+                                float* carry = nullptr, uint64_t* tile_s16 = nullptr, uint64_t* tile_q16 = nullptr,
+                                unsigned int* ticket = nullptr);
 hipError_t launch_offspring_from_scan(hipStream_t stream, const uint64_t* cdf_local, const uint64_t* tile_total, int n,
                                       const uint64_t* d_base, const uint64_t* d_total, const uint64_t* d_shard_totals,
                                       int rank, int world, uint64_t seed, uint32_t frame, int64_t n_total,

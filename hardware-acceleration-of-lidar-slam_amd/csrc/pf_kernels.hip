@@ -290,7 +290,8 @@ __global__ __launch_bounds__(kBlock) void logweight_kernel(const float* __restri
                                                            const float* __restrict__ loglik, float gain, int n,
                                                            const float* __restrict__ carry,
                                                            const int32_t* __restrict__ prev_resampled,
-                                                           float* __restrict__ logw, float* __restrict__ block_max)
+                                                           float* __restrict__ logw, float* __restrict__ block_max,
+                                                           float* __restrict__ d_max, unsigned int* __restrict__ ticket)
 {
     __shared__ float s_max[kBlock / 64];
     float m = -INFINITY;
@@ -306,24 +307,29 @@ __global__ __launch_bounds__(kBlock) void logweight_kernel(const float* __restri
     m = wave_max(m);
     if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = m;
     __syncthreads();
+    __shared__ bool s_last;
     if (threadIdx.x == 0) {
         for (int w = 1; w < kBlock / 64; ++w) m = fmaxf(m, s_max[w]);
         block_max[blockIdx.x] = m;
+        s_last = false;
+        if (d_max) {   // the workgroup that finishes last reduces the block maxima (saves the 1-workgroup launch behind this one)
+            __threadfence();
+            s_last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+        }
     }
-}
-
-__global__ __launch_bounds__(kBlock) void max_finalize_kernel(const float* __restrict__ block_max, int nblocks,
-                                                              float* __restrict__ d_max)
-{
-    __shared__ float s_max[kBlock / 64];
-    float m = -INFINITY;
-    for (int i = threadIdx.x; i < nblocks; i += kBlock) m = fmaxf(m, block_max[i]);
-    m = wave_max(m);
-    if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    float g = -INFINITY;
+    for (int i = threadIdx.x; i < (int)gridDim.x; i += kBlock) g = fmaxf(g, __hip_atomic_load(&block_max[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    g = wave_max(g);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = g;
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int w = 1; w < kBlock / 64; ++w) m = fmaxf(m, s_max[w]);
-        *d_max = m;
+        for (int w = 1; w < kBlock / 64; ++w) g = fmaxf(g, s_max[w]);
+        *d_max = g;
+        *ticket = 0;
     }
 }
 
@@ -460,6 +466,18 @@ __device__ __forceinline__ float block_max_of(const float* __restrict__ v, int c
     return r;
 }
 
+__device__ __forceinline__ uint64_t block_sum_u64(uint64_t v, uint64_t* s_red /*[kBlock/64]*/)
+{
+    v = wave_sum_u64(v);
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    uint64_t r = 0;
+#pragma unroll
+    for (int w = 0; w < kBlock / 64; ++w) r += s_red[w];
+    __syncthreads();
+    return r;
+}
+
 // GATED: also what the resample gate needs — the 16-bit weight sums S = sum(wq >> 16), Q = sum((wq >> 16)^2) of the
 // tile (exact integers, hence independent of order and sharding) and carry[i] = logw[i] - max, the weight a particle
 // takes into the next frame when this one does not resample (oracle: orc_ess_terms / orc_weight_carry).
@@ -471,7 +489,9 @@ __global__ __launch_bounds__(kBlock) void quantise_scan_kernel(const float* __re
                                                                uint64_t* __restrict__ tile_total,
                                                                float* __restrict__ carry,
                                                                uint64_t* __restrict__ tile_s16,
-                                                               uint64_t* __restrict__ tile_q16)
+                                                               uint64_t* __restrict__ tile_q16,
+                                                               uint64_t* __restrict__ d_sum,
+                                                               unsigned int* __restrict__ ticket)
 {
     __shared__ uint64_t s_wave[kBlock / 64];
     __shared__ float s_red[kBlock / 64];
@@ -525,34 +545,26 @@ __global__ __launch_bounds__(kBlock) void quantise_scan_kernel(const float* __re
             tile_q16[blockIdx.x] = b;
         }
     }
-}
-
-__device__ __forceinline__ uint64_t block_sum_u64(uint64_t v, uint64_t* s_red /*[kBlock/64]*/)
-{
-    v = wave_sum_u64(v);
-    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+    if (!d_sum) return;
+    // several GPUs: the shard's sums (what the ranks all-gather), by the workgroup that finishes last
+    __shared__ bool s_last;
     __syncthreads();
-    uint64_t r = 0;
-#pragma unroll
-    for (int w = 0; w < kBlock / 64; ++w) r += s_red[w];
+    if (threadIdx.x == 0) {
+        __threadfence();
+        s_last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+    }
     __syncthreads();
-    return r;
-}
-
-// d_sum[0] = shard total; with the gate also d_sum[1] = S, d_sum[2] = Q of the shard (what the ranks all-gather)
-__global__ __launch_bounds__(kBlock) void sum_tiles_kernel(const uint64_t* __restrict__ tile_total,
-                                                           const uint64_t* __restrict__ tile_s16,
-                                                           const uint64_t* __restrict__ tile_q16, int ntiles,
-                                                           uint64_t* __restrict__ d_sum)
-{
-    __shared__ uint64_t s_red[kBlock / 64];
+    if (!s_last) return;
+    __threadfence();
     const uint64_t* src[3] = { tile_total, tile_s16, tile_q16 };
-    for (int a = 0; a < (tile_s16 ? 3 : 1); ++a) {
+    for (int a = 0; a < (GATED ? 3 : 1); ++a) {
         uint64_t acc = 0;
-        for (int t = threadIdx.x; t < ntiles; t += kBlock) acc += src[a][t];
-        acc = block_sum_u64(acc, s_red);
+        for (int t = threadIdx.x; t < (int)gridDim.x; t += kBlock)
+            acc += __hip_atomic_load(&src[a][t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        acc = block_sum_u64(acc, s_wave);
         if (threadIdx.x == 0) d_sum[a] = acc;
     }
+    if (threadIdx.x == 0) *ticket = 0;
 }
 
 // The resample gate (oracle: orc_ess_resample): resample iff ESS < frac * N, i.e. S^2 * 65536 < frac_q16 * N * Q, in
@@ -1233,8 +1245,10 @@ hipError_t launch_ekf_update(hipStream_t stream, const EkfArgs& a_in, const Even
     return hipGetLastError();
 }
 
-static int capped_blocks(int n) { const int b = blocks_for(n); return b < 2048 ? b : 2048; }
+constexpr int kMaxWeightBlocks = 2048;
+static int capped_blocks(int n) { const int b = blocks_for(n); return b < kMaxWeightBlocks ? b : kMaxWeightBlocks; }
 int logweight_scratch_elems(int n) { return capped_blocks(n > 0 ? n : 1); }
+int logweight_scratch_floats() { return kMaxWeightBlocks + 1; }   // block maxima + the ticket word (zero-initialise once)
 
 hipError_t launch_logweight(hipStream_t stream, const float* score, const float* loglik, float gain, int n,
                             float* logw, float* block_max_scratch, float* d_max, const float* carry,
@@ -1242,8 +1256,9 @@ hipError_t launch_logweight(hipStream_t stream, const float* score, const float*
 {
     if (n <= 0) return hipSuccess;
     const int nb = capped_blocks(n);
-    logweight_kernel<<<nb, kBlock, 0, stream>>>(score, loglik, gain, n, carry, prev_resampled, logw, block_max_scratch);
-    if (d_max) max_finalize_kernel<<<1, kBlock, 0, stream>>>(block_max_scratch, nb, d_max);
+    // block_max_scratch[nb] is followed by the ticket word of the in-kernel final reduction (kept zero by the kernel)
+    logweight_kernel<<<nb, kBlock, 0, stream>>>(score, loglik, gain, n, carry, prev_resampled, logw, block_max_scratch, d_max,
+                                                reinterpret_cast<unsigned int*>(block_max_scratch + kMaxWeightBlocks));
     return hipGetLastError();
 }
 
@@ -1275,17 +1290,17 @@ hipError_t launch_prefix_sum(hipStream_t stream, const uint64_t* in, int n, uint
 
 hipError_t launch_quantise_scan(hipStream_t stream, const float* logw, const float* d_max, const float* block_max,
                                 int nblock_max, int n, uint64_t* cdf_local, uint64_t* tile_total, uint64_t* d_sum,
-                                float* carry, uint64_t* tile_s16, uint64_t* tile_q16)
+                                float* carry, uint64_t* tile_s16, uint64_t* tile_q16, unsigned int* ticket)
 {
     if (n <= 0) return hipSuccess;
     const int ntiles = (n + kScanTile - 1) / kScanTile;
+    // `ticket`: one zero-initialised word the kernel leaves zeroed (the in-kernel final sums for d_sum)
     if (carry)
         quantise_scan_kernel<true><<<ntiles, kBlock, 0, stream>>>(logw, d_max, block_max, nblock_max, n, cdf_local, tile_total,
-                                                                  carry, tile_s16, tile_q16);
+                                                                  carry, tile_s16, tile_q16, d_sum, ticket);
     else
         quantise_scan_kernel<false><<<ntiles, kBlock, 0, stream>>>(logw, d_max, block_max, nblock_max, n, cdf_local,
-                                                                   tile_total, nullptr, nullptr, nullptr);
-    if (d_sum) sum_tiles_kernel<<<1, kBlock, 0, stream>>>(tile_total, carry ? tile_s16 : nullptr, tile_q16, ntiles, d_sum);
+                                                                   tile_total, nullptr, nullptr, nullptr, d_sum, ticket);
     return hipGetLastError();
 }
 

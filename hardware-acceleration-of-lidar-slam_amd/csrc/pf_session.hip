@@ -375,9 +375,6 @@ int slam_pf_step(slam_pf* pf, int slot, const float dp[3], int use_observations)
     if (comm) {
         // map rows of remote ancestors -> staging tail; issued behind the launch above, which does not need them
         if ((rc = finish_exchange(pf)) != SLAM_OK) return rc;
-        // this frame's poses to every rank, for the next frame's motion + score: runs beside the EKF.  Collectives of a
-        // communicator run in issue order: after the exchange (the EKF waits for that one), before the all-reduce.
-        if ((rc = comm_all_gather_begin(comm, dst, pf->pose_all, 3 * sn * sizeof(float))) != SLAM_OK) return rc;
     }
     // 3. per-landmark EKF (+ fused gather); the log-likelihood stays inside the engine for step 4
     const bool ekf = L > 0 && use_observations;
@@ -416,8 +413,11 @@ int slam_pf_step(slam_pf* pf, int slot, const float dp[3], int use_observations)
         if ((rc = slam_offspring_from_scan_sharded_dev(e, n, pf->totals, pf->rank, pf->world, pf->cfg.seed, pf->frame,
                                                        pf->n_total, pf->first)) != SLAM_OK)
             return rc;
-        // the "all-gather of surviving indices": 4 B x N_total
-        if ((rc = comm_all_gather(comm, pf->first, pf->first_all, sn * sizeof(int32_t))) != SLAM_OK) return rc;
+        // the "all-gather of surviving indices" (4 B x N_total) and, grouped into the same RCCL launch, this frame's poses
+        // to every rank (12 B x N_total) for the next frame's motion + score — that launch then needs nothing from the exchange
+        if ((rc = comm_all_gather2(comm, pf->first, pf->first_all, sn * sizeof(int32_t), dst, pf->pose_all,
+                                   3 * sn * sizeof(float))) != SLAM_OK)
+            return rc;
         // 6. gather index of every slot (remote ancestors -> rows of the staging tail) and the exchange plan, on the
         // device; the exchange itself happens at the start of the next frame, behind its motion + score launch
         if ((rc = slam_ancestors_sharded_dev(e, pf->first_all, pf->n_total, n, pf->rank, pf->world, pf->anc[nxt], pf->d_plan,
