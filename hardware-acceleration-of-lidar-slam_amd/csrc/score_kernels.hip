@@ -18,6 +18,8 @@
 // (particles are sorted by ancestor after resampling) so one wave's 64 gathers fall in a few lines.
 // Compiled with -ffp-contract=off: every multiply and add below is rounded separately.
 
+#include <stdlib.h>
+
 #include "det_math.h"
 #include "kernels.h"
 
@@ -435,12 +437,13 @@ hipError_t launch_lattice(hipStream_t stream, const ScoreGrid& g, const float* b
 }
 
 namespace {
-// Pose-count threshold below which the 4-lanes-per-pose form wins (measured on MI355X, 360 beams:
-// 64k poses 43 vs 64 us; 128k poses equal; 256k poses 154 vs 125 us).
+// Pose-count threshold below which the 4-lanes-per-pose form wins (measured on MI355X, 360 beams, pipelined kernels of
+// round 2: 64k poses 28.5 vs 30.1 us; 128k poses 55.4 vs 53.2 us; 256k poses 109 vs 104 us).
 constexpr int kQuadMaxPoses = 131072;
-// ... and below which one wavefront per pose wins over the quad form (1k poses 19 vs 45 us, 4k 30 vs 45 us,
-// 16k 74 vs 46 us at 1024 beams).
-constexpr int kWaveMaxPoses = 8192;
+// ... and below which one wavefront per pose wins over the quad form (360 / 1079 beams: 2k poses 6.1 vs 7.9 us / 18.3 vs
+// 24.4 us; 4k poses 9.2 vs 8.0 us / 27.8 vs 24.6 us; 8k poses 14.9 vs 8.0 us / 44.1 vs 25.1 us).  The quad form is flat
+// up to 8k poses: there its time is the chain of beam steps, not the work.
+constexpr int kWaveMaxPoses = 3072;
 
 template <bool MOTION>
 hipError_t launch_score_any(hipStream_t stream, const ScoreGrid& g, const float* bx, const float* by, int nbeams,
@@ -448,7 +451,10 @@ hipError_t launch_score_any(hipStream_t stream, const ScoreGrid& g, const float*
                             int32_t* count, const MotionIO& mio, const MotionParams& mpar, const EventPair* ev)
 {
     if (nposes <= 0) return hipSuccess;
-    if (nposes < kWaveMaxPoses) {   // one wavefront per pose
+    // tuning knobs for measurements (pose counts below which the wave / quad lane mappings are used)
+    static const int wave_max = getenv("SLAM_SCORE_WAVE_MAX") ? atoi(getenv("SLAM_SCORE_WAVE_MAX")) : kWaveMaxPoses;
+    static const int quad_max = getenv("SLAM_SCORE_QUAD_MAX") ? atoi(getenv("SLAM_SCORE_QUAD_MAX")) : kQuadMaxPoses;
+    if (nposes < wave_max) {   // one wavefront per pose
         const int blocks = (nposes + kScoreBlock / 64 - 1) / (kScoreBlock / 64);
         const size_t lds = sizeof(float) * (size_t)(kScoreBlock / 64) * (size_t)(nbeams > 0 ? nbeams : 1);
         if (ev) (void)hipEventRecord(ev->start, stream);
@@ -461,7 +467,7 @@ hipError_t launch_score_any(hipStream_t stream, const ScoreGrid& g, const float*
         if (ev) (void)hipEventRecord(ev->stop, stream);
         return hipGetLastError();
     }
-    const bool quad = nposes < kQuadMaxPoses;
+    const bool quad = nposes < quad_max;
     const long threads = quad ? 4L * nposes : nposes;
     const int blocks = (int)((threads + kScoreBlock - 1) / kScoreBlock);
     const size_t lds = sizeof(float2) * (size_t)(nbeams + (quad ? 4 * kQuadDepth : kLaneDepth));
