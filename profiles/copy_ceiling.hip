@@ -11,8 +11,11 @@
 typedef float v4f __attribute__((ext_vector_type(4)));
 
 // W = floats per lane per access (1 or 4); NB batches in flight; NT = nt stores
+// share > 1: rows i - i % share .. share one SOURCE row (what a resampled population looks like: the offspring of an
+// ancestor are neighbours and re-read its row from L2); share == 0: write only (no loads at all)
 template <int W, int NB, bool NT>
-__global__ __launch_bounds__(256) void copy_rows(const float* __restrict__ in, float* __restrict__ out, int n, int Lp, int xcd_chunk)
+__global__ __launch_bounds__(256) void copy_rows(const float* __restrict__ in, float* __restrict__ out, int n, int Lp, int xcd_chunk,
+                                                 int share = 1)
 {
     const unsigned lane = threadIdx.x & 63u;
     const int wave = threadIdx.x >> 6;
@@ -20,7 +23,19 @@ __global__ __launch_bounds__(256) void copy_rows(const float* __restrict__ in, f
     if (xcd_chunk > 0) bid = (bid & 7) * xcd_chunk + (bid >> 3);
     const int i = bid * 4 + wave;
     if (i >= n) return;
-    const float* rin = in + (size_t)i * 5 * Lp;
+    const float* rin = in + (size_t)(share > 1 ? i - i % share : i) * 5 * Lp;
+    if (share == 0) {   // write only
+        float* ro = out + (size_t)i * 5 * Lp;
+        for (int lb = 0; lb + 128 <= Lp; lb += 128)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int p = 0; p < 5; ++p) {
+                    float* d = &ro[p * Lp + lb + t * 64 + lane];
+                    if (NT) __builtin_nontemporal_store(1.0f, d); else *d = 1.0f;
+                }
+        return;
+    }
     float* rout = out + (size_t)i * 5 * Lp;
     constexpr int B = 64 * W * (W == 1 ? 2 : 1);   // landmarks per batch: 128 (two dwords per lane) or 256 (one x4 per lane)
     for (int lb = 0; lb + B * NB <= Lp; lb += B * NB) {
@@ -101,5 +116,15 @@ int main(int argc, char** argv)
     RUN("x4     nb1 nt  in-place", 4, 1, true, true)
     RUN("x4     nb2 nt  in-place", 4, 2, true, true)
     RUN("x4     nb1     in-place", 4, 1, false, true)
+#define RUNS(name, share, bytes_moved)                                                                             \
+    {                                                                                                              \
+        float ms = time_it([&](int r) {                                                                            \
+            float* src = (r & 1) ? b : a; float* dst = (r & 1) ? a : b;                                            \
+            copy_rows<1, 2, true><<<grid, 256>>>(src, dst, n, Lp, chunk, share); }, 20);                            \
+        printf("%-34s %8.1f us  %7.0f GB/s (HBM bytes: %s)\n", name, ms * 1e3, (bytes_moved) / 1e9 / (ms * 1e-3), #bytes_moved); \
+    }
+    RUNS("dword  nb2 nt  write only", 0, (double)bytes)
+    RUNS("dword  nb2 nt  source shared by 16", 16, (double)bytes * (1.0 + 1.0 / 16))
+    RUNS("dword  nb2 nt  source shared by 64", 64, (double)bytes * (1.0 + 1.0 / 64))
     return 0;
 }
