@@ -100,6 +100,8 @@ SIGNATURES = {
     "slam_mapper_next_frame": (_i, [_vp, _vp, _fp]),
     "slam_mapper_get_map_host": (_i, [_vp, _vp, _vp, C.c_int32, C.POINTER(C.c_int32)]),
     "slam_exchange_set_capacity": (_i, [_vp, _i]),
+    "slam_ekf_form_set": (_i, [_vp, _i]),
+    "slam_ekf_form_counts": (_i, [_vp, _vp]),
     "slam_resample_gate_set": (_i, [_vp, _f]),
     "slam_resample_happened_host": (_i, [_vp, C.POINTER(C.c_int)]),
     "slam_comm_unique_id": (_i, [_vp]),
@@ -370,6 +372,15 @@ class Engine:
         d_pose_idx (optional): ancestor's position in an all-gather of the ranks' [x | y | theta] pose blocks."""
         self._ck(self.lib.slam_ancestors_sharded_dev(self.h, _ptr(d_first_all), n_total, n_local, rank, world,
                                                      _ptr(d_src), _ptr(d_plan), _ptr(d_pose_idx)), "ancestors_sharded_dev")
+
+    def ekf_form_set(self, form: int):
+        """-1: the engine chooses the out-of-place EKF kernel; 0: one wavefront per particle; 1: per 8 particles."""
+        self._ck(self.lib.slam_ekf_form_set(self.h, int(form)), "ekf_form_set")
+
+    def ekf_form_counts(self):
+        c = (C.c_int64 * 2)()
+        self._ck(self.lib.slam_ekf_form_counts(self.h, c), "ekf_form_counts")
+        return int(c[0]), int(c[1])
 
     def resample_gate_set(self, ess_frac: float):
         self._ck(self.lib.slam_resample_gate_set(self.h, float(ess_frac)), "resample_gate_set")

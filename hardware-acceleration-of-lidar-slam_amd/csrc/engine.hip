@@ -129,7 +129,11 @@ int slam_engine_create(int device, slam_engine** out)
         hipHostGetDevicePointer((void**)&e->d_hplan, e->h_plan, 0) != hipSuccess ||
         hipHostMalloc((void**)&e->h_gate, sizeof(int32_t) * 2, hipHostMallocMapped) != hipSuccess ||
         hipHostGetDevicePointer((void**)&e->d_hgate, e->h_gate, 0) != hipSuccess ||
-        e->gate_buf.ensure(2 * sizeof(int32_t)) != hipSuccess ||   // the gate's flag + the ticket word of quantise_scan_kernel
+        e->gate_buf.ensure(2 * sizeof(int32_t)) != hipSuccess ||
+        hipHostMalloc((void**)&e->h_heads, sizeof(int32_t) * 2, hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer((void**)&e->d_hheads, e->h_heads, 0) != hipSuccess ||
+        e->heads_buf.ensure(2 * sizeof(int32_t)) != hipSuccess ||
+        hipMemset(e->heads_buf.p, 0, 2 * sizeof(int32_t)) != hipSuccess ||   // the gate's flag + the ticket word of quantise_scan_kernel
         e->scan_buf.ensure(sizeof(float) * 2 * SLAM_MAX_BEAMS) != hipSuccess ||
         hipHostMalloc((void**)&e->h_stage, sizeof(float) * kStageSlots * kStageFloats, hipHostMallocDefault) !=
             hipSuccess) {
@@ -141,6 +145,8 @@ int slam_engine_create(int device, slam_engine** out)
     memset(e->h_plan, 0, sizeof(int32_t) * (SLAM_PLAN_WORDS(kMaxRanks) + 1));
     e->h_gate[0] = 1;
     e->h_gate[1] = 0;
+    e->h_heads[0] = 0;
+    e->h_heads[1] = -1;   // nothing known yet
     {
         const int32_t one[2] = { 1, 0 };   // "the previous frame resampled": nothing is carried into the first frame; ticket = 0
         if (hipMemcpy(e->gate_buf.p, one, sizeof one, hipMemcpyHostToDevice) != hipSuccess) {
@@ -150,6 +156,7 @@ int slam_engine_create(int device, slam_engine** out)
         }
     }
     e->stream = e->own_stream;
+    if (getenv("SLAM_EKF_GROUP")) e->ekf_form = atoi(getenv("SLAM_EKF_GROUP")) != 0;
     *out = e;
     return SLAM_OK;
 }
@@ -185,6 +192,8 @@ int slam_engine_destroy(slam_engine* e)
     if (e->h_fm) (void)hipHostFree(e->h_fm);
     if (e->h_plan) (void)hipHostFree(e->h_plan);
     if (e->h_gate) (void)hipHostFree(e->h_gate);
+    if (e->h_heads) (void)hipHostFree(e->h_heads);
+    e->heads_buf.release();
     e->gate_buf.release();
     e->carry_buf.release();
     if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
@@ -652,8 +661,28 @@ int slam_ekf_update_dev(slam_engine* e, const float* d_map_in, float* d_map_out,
     a.meas_var = meas_var;
     a.loglik = e->ll_buf.as<float>();   // what slam_logweight_ekf_dev will consume
     a.loglik_user = d_loglik;
-    HIP_TRY(launch_ekf_update(e->stream, a, e->prof_next(SLAM_PROF_EKF)));
+    const bool group = nlandmarks > 128 && d_map_in != d_map_out &&
+                       (e->ekf_form >= 0 ? e->ekf_form != 0 : (d_anc && e->prefer_group_form(n, nlandmarks)));
+    HIP_TRY(launch_ekf_update(e->stream, a, e->prof_next(SLAM_PROF_EKF), group));
+    if (d_map_in != d_map_out) e->ekf_form_launches[group ? 1 : 0]++;
     e->ll_n = n;
+    return SLAM_OK;
+}
+
+int slam_ekf_form_set(slam_engine* e, int form)
+{
+    ENTER(e);
+    if (form < -1 || form > 1) return SLAM_ERR_INVALID_ARG;
+    e->ekf_form = getenv("SLAM_EKF_GROUP") ? atoi(getenv("SLAM_EKF_GROUP")) : form;   // the environment wins (measurements)
+    return SLAM_OK;
+}
+
+int slam_ekf_form_counts(slam_engine* e, int64_t counts[2])
+{
+    ENTER(e);
+    if (!counts) return SLAM_ERR_INVALID_ARG;
+    counts[0] = e->ekf_form_launches[0];
+    counts[1] = e->ekf_form_launches[1];
     return SLAM_OK;
 }
 
@@ -731,7 +760,7 @@ int slam_ancestors_from_scan_dev(slam_engine* e, int n, uint64_t seed, uint32_t 
     const uint32_t frac = e->carry_n == n ? e->gate_frac_q16 : 0;   // the gate needs the sums of a gated quantise_scan
     const GateOut gate = frac ? e->gate_next() : GateOut();
     if (ancestors_from_scan_fits(n)) {
-        HIP_TRY(launch_ancestors_from_scan(e->stream, cdf, cdf + n, n, seed, frame, d_anc, frac, gate));
+        HIP_TRY(launch_ancestors_from_scan(e->stream, cdf, cdf + n, n, seed, frame, d_anc, frac, gate, e->heads_out()));
         return SLAM_OK;
     }
     // more tiles than the one-launch form keeps in LDS: the two-launch form through a scratch `first` array
@@ -866,7 +895,8 @@ int slam_ancestors_sharded_dev(slam_engine* e, const int32_t* d_first_all, int64
     const uint32_t seq = ++e->plan_seq;
     HIP_TRY(launch_ancestors_sharded(e->stream, d_first_all, n_total, n_local, rank, world, e->shard_buf.as<int32_t>(),
                                      d_plan, d_src, d_pose_idx, e->d_hplan,
-                                     reinterpret_cast<uint32_t*>(e->d_hplan + SLAM_PLAN_WORDS(kMaxRanks)), seq, e->exch_cap));
+                                     reinterpret_cast<uint32_t*>(e->d_hplan + SLAM_PLAN_WORDS(kMaxRanks)), seq, e->exch_cap,
+                                     e->d_hheads));
     e->shard_n = n_local;   // what slam_migrate_pack_dev will read
     e->plan_world = world;
     return SLAM_OK;

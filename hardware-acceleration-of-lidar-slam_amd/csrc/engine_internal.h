@@ -103,6 +103,29 @@ struct slam_engine {
     DevBuf carry_buf;          // float[n]
     int carry_n = -1;
 
+    // feedback of the resample stages: roughly how many distinct ancestors the last one left {count, n} (mapped host
+    // memory, read without synchronisation: it only steers the choice between two equivalent EKF kernels)
+    int32_t* h_heads = nullptr;
+    int32_t* d_hheads = nullptr;
+    DevBuf heads_buf;          // {count, ticket}
+
+    slam::HeadsOut heads_out()
+    {
+        slam::HeadsOut h;
+        h.counter = heads_buf.as<unsigned int>();
+        h.h_out = d_hheads;
+        return h;
+    }
+    // neighbours share ancestors (fewer than 3 distinct in 10 slots) and the rows are short enough for the grouped form
+    int ekf_form = -1;         // slam_ekf_form_set: -1 choose by the feedback, 0 row per wavefront, 1 grouped
+    int64_t ekf_form_launches[2] = { 0, 0 };   // out-of-place launches so far: [0] one wavefront per particle, [1] grouped
+    bool prefer_group_form(int n, int nlandmarks) const
+    {
+        if (ekf_form >= 0) return ekf_form != 0;
+        const int heads = h_heads[0], hn = h_heads[1];
+        return hn == n && nlandmarks <= 2048 && (int64_t)heads * 10 < (int64_t)n * 3;
+    }
+
     slam::GateOut gate_next()
     {
         slam::GateOut g;

@@ -88,7 +88,9 @@ struct EkfArgs {
     float* loglik_user;   // optional second copy for the caller
     int xcd_chunk;        // set by the launcher: workgroups per XCD when the grid is renumbered XCD-contiguously, else 0
 };
-hipError_t launch_ekf_update(hipStream_t stream, const EkfArgs& a, const EventPair* ev = nullptr);
+// prefer_group: use the grouped out-of-place form (neighbouring particles share their source rows in registers) — a
+// speed choice only, both forms give the same bits
+hipError_t launch_ekf_update(hipStream_t stream, const EkfArgs& a, const EventPair* ev = nullptr, bool prefer_group = false);
 
 // carry / prev_resampled (optional): see logweight_kernel — the weights a frame without resample left behind
 hipError_t launch_logweight(hipStream_t stream, const float* score, const float* loglik, float gain, int n,
@@ -102,6 +104,12 @@ hipError_t launch_quantise_weights(hipStream_t stream, const float* logw, const 
 // The resample gate (ESS-gated resampling; oracle: orc_ess_resample).  frac_q16 = threshold * 65536, 0 = no gate
 // (resample every frame).  Where the verdict goes: a device flag and, optionally, mapped host memory
 // {int32 resampled, uint32 sequence number}.
+// Where a resample stage reports roughly how many distinct ancestors it left: counter = {count, ticket} (device, zeroed
+// once, left zeroed), h_out = {count, n} in mapped host memory.
+struct HeadsOut {
+    unsigned int* counter = nullptr;
+    int32_t* h_out = nullptr;
+};
 struct GateOut {
     int32_t* d_flag = nullptr;
     int32_t* h_flag = nullptr;
@@ -130,7 +138,7 @@ hipError_t launch_ancestors(hipStream_t stream, const int32_t* first_all, int64_
 bool ancestors_from_scan_fits(int n);
 hipError_t launch_ancestors_from_scan(hipStream_t stream, const uint64_t* cdf_local, const uint64_t* tile_total, int n,
                                       uint64_t seed, uint32_t frame, int32_t* anc, uint32_t frac_q16 = 0,
-                                      const GateOut& gate = GateOut());
+                                      const GateOut& gate = GateOut(), const HeadsOut& heads = HeadsOut());
 // multi-GPU resample (see pf_kernels.hip): per-peer slot runs, offsets in the packed exchange buffers
 enum { kMaxRanks = 16 };
 struct MigratePlan {
@@ -142,7 +150,8 @@ int shard_scan_words(int n);   // int32 words of scratch the two launchers below
 // host_plan / host_flag / seq (optional): also deliver the plan to mapped pinned host memory and release `seq`
 hipError_t launch_ancestors_sharded(hipStream_t stream, const int32_t* first_all, int64_t n_total, int n, int rank,
                                     int world, int32_t* scratch, int32_t* plan, int32_t* src, int32_t* pose_idx,
-                                    int32_t* host_plan, uint32_t* host_flag, uint32_t seq, int recv_cap);
+                                    int32_t* host_plan, uint32_t* host_flag, uint32_t seq, int recv_cap,
+                                    int32_t* host_heads = nullptr);
 hipError_t launch_migrate_pack(hipStream_t stream, const int32_t* scratch, int n, const MigratePlan& plan,
                                const float* pose, int64_t pose_ld, const float* map, int64_t row_stride,
                                int plane_stride, int nlandmarks, float* out);

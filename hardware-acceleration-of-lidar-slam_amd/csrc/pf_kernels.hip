@@ -12,6 +12,8 @@
 // All kernels are HBM-streaming or latency-bound integer work; there is no GEMM shape here
 // (the largest matrix is 2x2), hence no MFMA.
 
+#include <stdlib.h>
+
 #include "det_math.h"
 #include "kernels.h"
 
@@ -273,6 +275,199 @@ __global__ __launch_bounds__(kEkfWaves * 64) void ekf_update_kernel(EkfArgs a)
     if (lane == 0) {
         a.loglik[i] = total;
         if (a.loglik_user) a.loglik_user[i] = total;
+    }
+}
+
+// ---- grouped form of the out-of-place update: ONE WAVEFRONT OWNS G NEIGHBOURING PARTICLES.
+// After a resample the slots are sorted by ancestor, so neighbouring particles mostly descend from the same one.  The
+// row-per-wavefront kernel lets them share the source row through L2; measured (profiles/copy_ceiling.hip) even a pure copy
+// pays for that — 155 us at 64k x 512 columns when 16 neighbours share a source, against 109 us when nothing is re-read.
+// Here the wavefront walks the landmarks in the OUTER loop and its G particles in the inner one: a batch of the source
+// row stays in registers while every particle of the group that descends from it is updated with its own pose and stored
+// to its own row — the re-reads never leave the register file, the observation table is read once per group.  Per
+// (particle, landmark) the arithmetic, its order and the log-likelihood summation are those of ekf_batches (bit-exact:
+// the same tests cover both kernels); the per-particle accumulators live in LDS between batches.
+template <int NB>
+struct EkfBatch {   // NB batches of 128 landmarks of one source row + the observations of those landmarks
+    v2f m[NB][5], zx[NB], zy[NB];
+    bool obs[NB][2];
+    unsigned off[NB][2];
+};
+
+struct EkfPose {   // one particle of the group (wave-uniform values)
+    __amdgpu_buffer_rsrc_t rout;
+    v2f s, c, px, py;
+};
+
+// update NB batches already in registers with one particle's pose and store them to its row (FULL batches only: every
+// lane's landmarks lie inside the padded row; landmarks beyond L count as "not observed", padding is copied along)
+template <int NB>
+__device__ __forceinline__ void ekf_apply(const EkfBatch<NB>& b, const EkfPose& w, int pl, v2f q2, v2f& acc)
+{
+#pragma unroll
+    for (int g = 0; g < NB; ++g) {
+        const v2f mx = b.m[g][0], my = b.m[g][1], pxx = b.m[g][2], pxy = b.m[g][3], pyy = b.m[g][4];
+        if (__ballot(b.obs[g][0] || b.obs[g][1]) == 0) {   // no observation among these 128 landmarks: plain copy
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int p = 0; p < 5; ++p) row_store(w.rout, b.off[g][t], p * pl, b.m[g][p][t]);
+            continue;
+        }
+        const v2f s = w.s, c = w.c, px = w.px, py = w.py, q = q2;
+        const v2f dx = mx - px, dy = my - py;
+        const v2f vx = b.zx[g] - (c * dx - s * dy);
+        const v2f vy = b.zy[g] - (s * dx + c * dy);
+        const v2f a00 = c * pxx - s * pxy, a01 = c * pxy - s * pyy;
+        const v2f a10 = s * pxx + c * pxy, a11 = s * pxy + c * pyy;
+        const v2f s00 = (a00 * c - a01 * s) + q;
+        const v2f s01 = a00 * s + a01 * c;
+        const v2f s11 = (a10 * s + a11 * c) + q;
+        const v2f det = s00 * s11 - s01 * s01;
+        const v2f idet = (v2f){1.0f / det[0], 1.0f / det[1]};
+        const v2f i00 = s11 * idet, i01 = -s01 * idet, i11 = s00 * idet;
+        const v2f k00 = a00 * i00 + a10 * i01, k01 = a00 * i01 + a10 * i11;
+        const v2f k10 = a01 * i00 + a11 * i01, k11 = a01 * i01 + a11 * i11;
+        v2f o0 = mx + (k00 * vx + k01 * vy);
+        v2f o1 = my + (k10 * vx + k11 * vy);
+        v2f o2 = pxx - (k00 * a00 + k01 * a10);
+        v2f o3 = pxy - (k00 * a01 + k01 * a11);
+        v2f o4 = pyy - (k10 * a01 + k11 * a11);
+        const v2f maha = vx * (i00 * vx + i01 * vy) + vy * (i01 * vx + i11 * vy);
+        v2f ll = ((bc2(0.0f) - bc2(0.5f) * maha) - bc2(0.5f) * det_logf2(det)) - bc2(1.8378770664f);
+        const v2f f0 = px + (c * b.zx[g] + s * b.zy[g]);   // first sighting: the observed point, P = R, no likelihood
+        const v2f f1 = py + (c * b.zy[g] - s * b.zx[g]);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const bool ob = b.obs[g][t];
+            const bool first = pxx[t] < 0.0f;
+            float r0 = first ? f0[t] : o0[t], r1 = first ? f1[t] : o1[t], r2 = first ? q[t] : o2[t];
+            float r3 = first ? 0.0f : o3[t], r4 = first ? q[t] : o4[t], rl = first ? 0.0f : ll[t];
+            r0 = ob ? r0 : mx[t];
+            r1 = ob ? r1 : my[t];
+            r2 = ob ? r2 : pxx[t];
+            r3 = ob ? r3 : pxy[t];
+            r4 = ob ? r4 : pyy[t];
+            ll[t] = ob ? rl : 0.0f;
+            row_store(w.rout, b.off[g][t], 0 * pl, r0);
+            row_store(w.rout, b.off[g][t], 1 * pl, r1);
+            row_store(w.rout, b.off[g][t], 2 * pl, r2);
+            row_store(w.rout, b.off[g][t], 3 * pl, r3);
+            row_store(w.rout, b.off[g][t], 4 * pl, r4);
+        }
+        acc = acc + ll;
+    }
+}
+
+constexpr int kEkfGroup = 8;   // particles per wavefront in the grouped form
+
+__device__ __forceinline__ float lane_value(float v, int k)   // lane k's value, wave-uniform (v_readlane_b32)
+{
+    return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), k));
+}
+
+template <int NB>
+__global__ __launch_bounds__(kEkfWaves * 64) void ekf_update_group_kernel(EkfArgs a)
+{
+    constexpr int G = kEkfGroup;
+    __shared__ float s_acc[kEkfWaves][G][128];   // per particle of the group: the 128 accumulators of the specification
+    const unsigned lane = threadIdx.x & 63u;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    int bid = blockIdx.x;
+    if (a.xcd_chunk > 0) bid = (bid & 7) * a.xcd_chunk + (bid >> 3);   // each XCD a contiguous eighth (see ekf_update_kernel)
+    const int g0 = (bid * kEkfWaves + wave) * G;
+    if (g0 >= a.n) return;
+    const int nslots = a.n - g0 < G ? a.n - g0 : G;
+    // lane k prepares particle g0 + k: its source row and the trig of its heading; read back with v_readlane below
+    const int mine = g0 + ((int)lane < nslots ? (int)lane : 0);
+    const int src_l = a.anc ? a.anc[mine] : mine;
+    float st_l, ct_l;
+    det_sincosf(a.th[mine], st_l, ct_l);
+    const float px_l = a.x[mine], py_l = a.y[mine];
+#pragma unroll
+    for (int k = 0; k < G; ++k) {
+        s_acc[wave][k][lane] = 0.0f;
+        s_acc[wave][k][lane + 64] = 0.0f;
+    }
+    const int pl = __builtin_amdgcn_readfirstlane(a.plane_stride * 4);
+    const int row_bytes = __builtin_amdgcn_readfirstlane(5 * a.plane_stride * 4);
+    const gchar* ozx = uniform_gptr(a.obs_zx);
+    const gchar* ozy = uniform_gptr(a.obs_zy);
+    const unsigned L = (unsigned)a.nlandmarks, room = (unsigned)a.plane_stride;
+    const v2f q2 = bc2(a.meas_var);
+    const float nan = __uint_as_float(0x7fc00000u);
+
+    auto pose_of = [&](int k) {
+        EkfPose w;
+        const int i = g0 + k;
+        w.rout = __builtin_amdgcn_make_buffer_rsrc((void*)uniform_gptr(a.map_out + (int64_t)i * a.row_stride), 0, row_bytes, 0x00020000);
+        w.s = bc2(lane_value(st_l, k));
+        w.c = bc2(lane_value(ct_l, k));
+        w.px = bc2(lane_value(px_l, k));
+        w.py = bc2(lane_value(py_l, k));
+        return w;
+    };
+
+    unsigned lb = 0;
+    for (; lb < L && lb + 128u * NB <= room; lb += 128u * NB) {
+        EkfBatch<NB> b;
+        // the observations of these landmarks: the same for every particle of the group
+#pragma unroll
+        for (int g = 0; g < NB; ++g)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const unsigned l = lb + (unsigned)g * 128u + 64u * t + lane;
+                const bool in = l < L;
+                b.off[g][t] = l * 4u;
+                const unsigned zo = (in ? l : 0u) * 4u;   // clamped index + select instead of a predicated load
+                const float vx = *(const gfloat*)(ozx + zo), vy = *(const gfloat*)(ozy + zo);
+                b.zx[g][t] = in ? vx : nan;
+                b.zy[g][t] = in ? vy : nan;
+                b.obs[g][t] = b.zx[g][t] == b.zx[g][t] && b.zy[g][t] == b.zy[g][t];
+            }
+        int prev = -1;
+        for (int k = 0; k < nslots; ++k) {
+            const int src = __builtin_amdgcn_readlane(src_l, k);
+            if (src != prev) {   // a new ancestor: its batch into registers (wave-uniform branch)
+                const __amdgpu_buffer_rsrc_t rin =
+                    __builtin_amdgcn_make_buffer_rsrc((void*)uniform_gptr(a.map_in + (int64_t)src * a.row_stride), 0, row_bytes, 0x00020000);
+#pragma unroll
+                for (int g = 0; g < NB; ++g)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int p = 0; p < 5; ++p) b.m[g][p][t] = row_load(rin, b.off[g][t], p * pl);
+                prev = src;
+            }
+            const EkfPose w = pose_of(k);
+            v2f acc = (v2f){s_acc[wave][k][lane], s_acc[wave][k][lane + 64]};
+            ekf_apply<NB>(b, w, pl, q2, acc);
+            s_acc[wave][k][lane] = acc[0];
+            s_acc[wave][k][lane + 64] = acc[1];
+        }
+    }
+    // what is left of the rows (a tail shorter than NB batches) and the reduction: particle by particle, general form
+    for (int k = 0; k < nslots; ++k) {
+        const int i = g0 + k;
+        const int src = __builtin_amdgcn_readlane(src_l, k);
+        EkfLane w;
+        w.rin = __builtin_amdgcn_make_buffer_rsrc((void*)uniform_gptr(a.map_in + (int64_t)src * a.row_stride), 0, row_bytes, 0x00020000);
+        const EkfPose pw = pose_of(k);
+        w.rout = pw.rout;
+        w.pl = pl;
+        w.ozx = ozx;
+        w.ozy = ozy;
+        w.L = L;
+        w.s = pw.s; w.c = pw.c; w.px = pw.px; w.py = pw.py; w.q = q2;
+        v2f acc = (v2f){s_acc[wave][k][lane], s_acc[wave][k][lane + 64]};
+        unsigned lt = lb;
+        for (; lt < L && lt + 128u <= room; lt += 128u) ekf_batches<1, true, true>(w, lt, lane, acc);
+        for (; lt < L; lt += 128u) ekf_batches<1, false, true>(w, lt, lane, acc);
+        const float total = wave_xor_tree_sum(acc[0] + acc[1]);
+        if (lane == 0) {
+            a.loglik[i] = total;
+            if (a.loglik_user) a.loglik_user[i] = total;
+        }
     }
 }
 
@@ -718,6 +913,36 @@ __global__ __launch_bounds__(kBlock) void offspring_from_scan_kernel(const uint6
     first[i] = comb_first(c_excl, total, n_total, key0, key1, frame);
 }
 
+// Feedback for the host's choice between the two out-of-place EKF forms (it changes speed, never results): about how many
+// DISTINCT ancestors the resample left — a slot counts when its wavefront neighbour descends from another particle (so
+// wavefront boundaries count once too often: at most n / 64).  Summed with one atomic per workgroup; the workgroup that
+// finishes last hands {count, n} to mapped host memory and clears the counter.  The host reads it without any
+// synchronisation, a frame or two late.
+__device__ __forceinline__ void count_heads(const HeadsOut& h, int val, bool valid, int n)
+{
+    if (!h.counter) return;
+    __shared__ int s_heads[kBlock / 64];
+    __shared__ bool s_last_heads;
+    const int up = __shfl_up(val, 1, 64);
+    const bool head = valid && ((threadIdx.x & 63) == 0 || up != val);
+    const int cnt = __popcll(__ballot(head));
+    if ((threadIdx.x & 63) == 0) s_heads[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int sum = 0;
+        for (int w = 0; w < kBlock / 64; ++w) sum += s_heads[w];
+        atomicAdd(&h.counter[0], (unsigned)sum);
+        __threadfence();
+        s_last_heads = atomicAdd(&h.counter[1], 1u) == gridDim.x - 1;
+        if (s_last_heads) {
+            __threadfence();
+            h.h_out[0] = (int32_t)atomicExch(&h.counter[0], 0u);
+            h.h_out[1] = n;
+            h.counter[1] = 0;
+        }
+    }
+}
+
 // Single GPU: the ancestor of every slot straight from the tile-local scan, without materialising `first`.
 // first[i] <= j  <=>  N*C_excl(i) <= j*S + u  (first[i] = ceil((N*C_excl(i) - u)/S), clamped at 0), so the ancestor
 // of slot j — the last i with first[i] <= j — is the number of k in [0, n-1) with N*C_incl(k) <= j*S + u.
@@ -730,7 +955,7 @@ __global__ __launch_bounds__(kBlock) void ancestors_from_scan_kernel(const uint6
                                                                      uint32_t frame, int32_t* __restrict__ anc,
                                                                      const uint64_t* __restrict__ tile_s16,
                                                                      const uint64_t* __restrict__ tile_q16,
-                                                                     uint32_t frac_q16, GateOut gate)
+                                                                     uint32_t frac_q16, GateOut gate, HeadsOut heads)
 {
     __shared__ uint64_t s_off[kPer * kBlock];
     __shared__ uint64_t s_wave[kBlock / 64];
@@ -751,52 +976,55 @@ __global__ __launch_bounds__(kBlock) void ancestors_from_scan_kernel(const uint6
     for (int k = 0; k < kPer; ++k) s_off[threadIdx.x * kPer + k] = v[k] + excl;
     __syncthreads();
     const int j = blockIdx.x * kBlock + threadIdx.x;
+    bool resample = true;
     if (frac_q16 != 0) {   // resample gate: the same verdict in every workgroup
         s16 = block_sum_u64(s16, s_wave);
         q16 = block_sum_u64(q16, s_wave);
-        const bool resample = ess_wants_resample(s16, q16, (uint64_t)n, frac_q16);
+        resample = ess_wants_resample(s16, q16, (uint64_t)n, frac_q16);
         if (blockIdx.x == 0 && threadIdx.x == 0) publish_gate(gate, resample);
+    }
+    int val = -1;   // this slot's ancestor (-1: no such slot)
+    if (j < n) {
         if (!resample) {
-            if (j < n) anc[j] = j;
-            return;
-        }
-    }
-    if (j >= n) return;
-    if (total == 0 || (total >> 63)) {   // see offspring_offsets_kernel: every slot gets the last particle
-        anc[j] = n - 1;
-        return;
-    }
-    const u32x4 r = philox4x32_10(0u, 0u, frame, 1u /* resample stream */, key0, key1);
-    const uint64_t comb_u = __umul64hi((uint64_t)r.v[0] | ((uint64_t)r.v[1] << 32), total);
-    uint64_t t_lo = (uint64_t)j * total, t_hi = __umul64hi((uint64_t)j, total);
-    t_lo += comb_u;
-    t_hi += t_lo < comb_u ? 1ull : 0ull;
-    const uint64_t N = (uint64_t)n;
-    int lo = 0, hi = n - 1;   // number of k in [0, n-1) with N*C_incl(k) <= T
-    // The search is a chain of dependent L2 round trips, so it is cut 8 ways per step instead of 2: seven pivots are
-    // loaded side by side (log8 n steps instead of log2 n: 48 -> ~20 us at 1M slots).  The predicate is monotone in k,
-    // so the new bounds are the largest pivot that satisfies it and the smallest that does not.
-    while (lo < hi) {
-        const int64_t span = hi - lo;
-        int mid[7];
-        uint64_t c[7];
+            val = j;   // the frame keeps its population
+        } else if (total == 0 || (total >> 63)) {   // see offspring_offsets_kernel: every slot gets the last particle
+            val = n - 1;
+        } else {
+            const u32x4 r = philox4x32_10(0u, 0u, frame, 1u /* resample stream */, key0, key1);
+            const uint64_t comb_u = __umul64hi((uint64_t)r.v[0] | ((uint64_t)r.v[1] << 32), total);
+            uint64_t t_lo = (uint64_t)j * total, t_hi = __umul64hi((uint64_t)j, total);
+            t_lo += comb_u;
+            t_hi += t_lo < comb_u ? 1ull : 0ull;
+            const uint64_t N = (uint64_t)n;
+            int lo = 0, hi = n - 1;   // number of k in [0, n-1) with N*C_incl(k) <= T
+            // The search is a chain of dependent L2 round trips, so it is cut 8 ways per step instead of 2: seven pivots
+            // are loaded side by side (log8 n steps instead of log2 n).  The predicate is monotone in k, so the new bounds
+            // are the largest pivot that satisfies it and the smallest that does not.
+            while (lo < hi) {
+                const int64_t span = hi - lo;
+                int mid[7];
+                uint64_t c[7];
 #pragma unroll
-        for (int t = 0; t < 7; ++t) {
-            mid[t] = lo + (int)((span * (t + 1)) >> 3);   // in [lo, hi)
-            c[t] = cdf_local[mid[t]] + s_off[mid[t] / kScanTile];
-        }
-        int nlo = lo, nhi = hi;
+                for (int t = 0; t < 7; ++t) {
+                    mid[t] = lo + (int)((span * (t + 1)) >> 3);   // in [lo, hi)
+                    c[t] = cdf_local[mid[t]] + s_off[mid[t] / kScanTile];
+                }
+                int nlo = lo, nhi = hi;
 #pragma unroll
-        for (int t = 0; t < 7; ++t) {
-            const uint64_t x_lo = c[t] * N, x_hi = __umul64hi(c[t], N);
-            const bool le = x_hi < t_hi || (x_hi == t_hi && x_lo <= t_lo);
-            nlo = le && mid[t] + 1 > nlo ? mid[t] + 1 : nlo;
-            nhi = !le && mid[t] < nhi ? mid[t] : nhi;
+                for (int t = 0; t < 7; ++t) {
+                    const uint64_t x_lo = c[t] * N, x_hi = __umul64hi(c[t], N);
+                    const bool le = x_hi < t_hi || (x_hi == t_hi && x_lo <= t_lo);
+                    nlo = le && mid[t] + 1 > nlo ? mid[t] + 1 : nlo;
+                    nhi = !le && mid[t] < nhi ? mid[t] : nhi;
+                }
+                lo = nlo;
+                hi = nhi;
+            }
+            val = lo;
         }
-        lo = nlo;
-        hi = nhi;
+        anc[j] = val;
     }
-    anc[j] = lo;
+    count_heads(heads, val, j < n, n);
 }
 
 __global__ __launch_bounds__(kBlock) void ancestors_kernel(const int32_t* __restrict__ first_all, int64_t n_total,
@@ -925,7 +1153,8 @@ __global__ __launch_bounds__(kBlock) void shard_plan_kernel(const int32_t* __res
                                                             int32_t* __restrict__ boff, int ntiles,
                                                             int32_t* __restrict__ plan, int32_t* __restrict__ rplan,
                                                             int32_t* __restrict__ host_plan,
-                                                            uint32_t* __restrict__ host_flag, uint32_t seq, int recv_cap)
+                                                            uint32_t* __restrict__ host_flag, uint32_t seq, int recv_cap,
+                                                            int32_t* __restrict__ host_heads)
 {
     __shared__ int32_t s_part[kBlock];
     for (int y = 0; y < 2; ++y) {   // exclusive scan of the tile totals, kBlock-sized chunks with a running carry
@@ -1004,6 +1233,10 @@ __global__ __launch_bounds__(kBlock) void shard_plan_kernel(const int32_t* __res
             host_plan[1 + world + q] = s_rcnt[q];
             host_plan[1 + 2 * world + q] = s_sbase[q];
         }
+    }
+    if (host_heads) {   // distinct ancestors among my slots = heads (feedback for the choice of the EKF form)
+        host_heads[0] = shard_prefix(pfx, boff, 0, n, ntiles, n - 1);
+        host_heads[1] = n;
     }
     plan[0] = anything;   // bit 0: somebody exchanges rows; bit 1: some rank's staging area might not hold them
     if (host_plan) {   // zero-copy delivery: the host polls the flag instead of a device-to-host copy + stream sync
@@ -1221,7 +1454,7 @@ hipError_t launch_motion_sample(hipStream_t stream, const float* sx, const float
     return hipGetLastError();
 }
 
-hipError_t launch_ekf_update(hipStream_t stream, const EkfArgs& a_in, const EventPair* ev)
+hipError_t launch_ekf_update(hipStream_t stream, const EkfArgs& a_in, const EventPair* ev, bool prefer_group)
 {
     if (a_in.n <= 0) return hipSuccess;
     EkfArgs a = a_in;
@@ -1232,6 +1465,21 @@ hipError_t launch_ekf_update(hipStream_t stream, const EkfArgs& a_in, const Even
         blocks = 8 * a.xcd_chunk;
     }
     const bool copy = a.map_in != a.map_out;   // in place: rows without an observation stay as they are
+    // out of place, more than one batch per row: optionally the grouped form (kEkfGroup neighbouring particles per wavefront,
+    // shared source rows stay in registers): faster when neighbours share ancestors, slower when they do not (the caller
+    // knows roughly how many distinct ancestors the last resample left; slam_ekf_form_set forces one form).
+    if (copy && a.nlandmarks > 128 && prefer_group) {
+        int gblocks = (a.n + kEkfWaves * kEkfGroup - 1) / (kEkfWaves * kEkfGroup);
+        a.xcd_chunk = 0;
+        if (gblocks >= 64) {
+            a.xcd_chunk = (gblocks + 7) / 8;
+            gblocks = 8 * a.xcd_chunk;
+        }
+        if (ev) (void)hipEventRecord(ev->start, stream);
+        ekf_update_group_kernel<2><<<gblocks, kEkfWaves * 64, 0, stream>>>(a);
+        if (ev) (void)hipEventRecord(ev->stop, stream);
+        return hipGetLastError();
+    }
     // batches of 128 landmarks in flight per wavefront: 2 measured best at 64k x 500 (1: 178 us, 2: 166 us, 4: 180 us)
     const int nb = a.nlandmarks <= 128 ? 1 : 2;
     if (ev) (void)hipEventRecord(ev->start, stream);
@@ -1333,7 +1581,8 @@ hipError_t launch_offspring_offsets(hipStream_t stream, const uint64_t* cdf, int
 bool ancestors_from_scan_fits(int n) { return n > 0 && (n + kScanTile - 1) / kScanTile <= kMaxLdsTiles; }
 
 hipError_t launch_ancestors_from_scan(hipStream_t stream, const uint64_t* cdf_local, const uint64_t* tile_total, int n,
-                                      uint64_t seed, uint32_t frame, int32_t* anc, uint32_t frac_q16, const GateOut& gate)
+                                      uint64_t seed, uint32_t frame, int32_t* anc, uint32_t frac_q16, const GateOut& gate,
+                                      const HeadsOut& heads)
 {
     if (n <= 0) return hipSuccess;
     const int ntiles = (n + kScanTile - 1) / kScanTile;
@@ -1341,10 +1590,11 @@ hipError_t launch_ancestors_from_scan(hipStream_t stream, const uint64_t* cdf_lo
     if (ntiles <= kBlock)
         ancestors_from_scan_kernel<1><<<blocks_for(n), kBlock, 0, stream>>>(cdf_local, tile_total, ntiles, n, (uint32_t)seed,
                                                                             (uint32_t)(seed >> 32), frame, anc, ts, tq,
-                                                                            frac_q16, gate);
+                                                                            frac_q16, gate, heads);
     else
         ancestors_from_scan_kernel<kMaxLdsTiles / kBlock><<<blocks_for(n), kBlock, 0, stream>>>(
-            cdf_local, tile_total, ntiles, n, (uint32_t)seed, (uint32_t)(seed >> 32), frame, anc, ts, tq, frac_q16, gate);
+            cdf_local, tile_total, ntiles, n, (uint32_t)seed, (uint32_t)(seed >> 32), frame, anc, ts, tq, frac_q16, gate,
+            heads);
     return hipGetLastError();
 }
 
@@ -1361,7 +1611,8 @@ int shard_scan_words(int n) { const int t = (n + kShardTile - 1) / kShardTile; r
 // scratch (int32 words, shard_scan_words(n)): gsrc[n] | pfx[2][n] | boff[2][ntiles] | rplan[2*kMaxRanks]
 hipError_t launch_ancestors_sharded(hipStream_t stream, const int32_t* first_all, int64_t n_total, int n, int rank,
                                     int world, int32_t* scratch, int32_t* plan, int32_t* src, int32_t* pose_idx,
-                                    int32_t* host_plan, uint32_t* host_flag, uint32_t seq, int recv_cap)
+                                    int32_t* host_plan, uint32_t* host_flag, uint32_t seq, int recv_cap,
+                                    int32_t* host_heads)
 {
     if (n <= 0) return hipSuccess;
     const int ntiles = (n + kShardTile - 1) / kShardTile;
@@ -1372,7 +1623,7 @@ hipError_t launch_ancestors_sharded(hipStream_t stream, const int32_t* first_all
     shard_search_kernel<<<blocks_for(n), kBlock, 0, stream>>>(first_all, n_total, n, rank, gsrc);
     shard_flag_scan_kernel<<<dim3(ntiles, 2), kBlock, 0, stream>>>(first_all, n_total, n, rank, gsrc, pfx, boff, ntiles);
     shard_plan_kernel<<<1, kBlock, 0, stream>>>(first_all, n_total, n, rank, world, pfx, boff, ntiles, plan, rplan,
-                                                host_plan, host_flag, seq, recv_cap);
+                                                host_plan, host_flag, seq, recv_cap, host_heads);
     ancestors_sharded_kernel<<<blocks_for(n), kBlock, 0, stream>>>(gsrc, pfx, boff, ntiles, rplan, n, rank, world, src,
                                                                    pose_idx);
     return hipGetLastError();

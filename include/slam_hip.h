@@ -209,6 +209,15 @@ int slam_ekf_update_dev(slam_engine *e, const float *d_map_in, float *d_map_out,
                         int nlandmarks, const float *d_x, const float *d_y, const float *d_th, const int32_t *d_anc,
                         int n, float meas_var, float *d_loglik);
 
+/* The out-of-place update has two kernels that give the SAME bits: one wavefront per particle (neighbouring particles
+ * share their ancestor's row through L2), and one wavefront per 8 neighbouring particles (the shared row stays in
+ * registers: faster when a resample left few distinct ancestors, slower when neighbours do not share).  form = -1 (the
+ * initial state): the engine chooses, steered by how many distinct ancestors its last resample stage left and by the row
+ * length; 0 / 1 force the first / second kernel (tests, measurements; the environment variable SLAM_EKF_GROUP overrides). */
+int slam_ekf_form_set(slam_engine *e, int form);
+/* out-of-place EKF launches of this engine so far: counts[0] one wavefront per particle, counts[1] the grouped kernel */
+int slam_ekf_form_counts(slam_engine *e, int64_t counts[2]);
+
 /* A11: logw[i] = loglik[i] - score[i] * score_gain  (either input may be NULL = 0) and
  * *d_max = max_i logw[i] (float, device).  Then, with the GLOBAL maximum m (after an all-reduce MAX
  * over shards): wq[i] = (uint64) (exp_det(logw[i] - m) * 2^32)  and  *d_sum = sum(wq)  (exact

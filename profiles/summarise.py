@@ -28,7 +28,8 @@ Lp = (L + 31) // 32 * 32
 
 def counter(mode, name):
     f = glob.glob(str(src / f"{tag}_pmc_{name}_{mode}" / "*" / "*counter_collection.csv"))[0]
-    rows = [r for r in csv.DictReader(open(f)) if KERNEL in r["Kernel_Name"] and r["Counter_Name"] == name]
+    # both out-of-place kernels (ekf_update_kernel / ekf_update_group_kernel) count as "the EKF kernel"
+    rows = [r for r in csv.DictReader(open(f)) if "ekf_update_" in r["Kernel_Name"] and r["Counter_Name"] == name]
     return [float(r["Counter_Value"]) * 1024 for r in rows]
 
 

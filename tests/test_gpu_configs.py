@@ -57,7 +57,8 @@ def _resample_like(rng, n):
     return np.sort(rng.choice(n, n, p=u / u.sum())).astype(np.int32)
 
 
-def _full_size_ekf(eng, orc, n, L, Lp, nobs, seed, nsample=4096):
+def _full_size_ekf(eng, orc, n, L, Lp, nobs, seed, nsample=4096, form=-1):
+    eng.ekf_form_set(form)
     rng = np.random.default_rng(seed)
     m_in = _device_map(n, L, Lp, seed)
     m_out = torch.full((n, 5, Lp), -777.0, device=DEV)
@@ -107,22 +108,25 @@ def _full_size_ekf(eng, orc, n, L, Lp, nobs, seed, nsample=4096):
     assert bool(torch.equal(again[:, :, :L], m_out[:, :, :L])) and bool(torch.equal(ll, ll2))
     del m_in, m_out, again
     torch.cuda.empty_cache()
+    eng.ekf_form_set(-1)
 
 
 def test_config4_share_512k_x_5000_landmarks(eng, orc):
     """BASELINE configs[4], one GPU's share: 524 288 particles x 5 000 landmarks, Lp = 5 024 (39 whole 128-landmark
     batches and a tail per row), resample gather fused, every landmark observed."""
-    _full_size_ekf(eng, orc, 524288, 5000, 5024, 5000, seed=5000)
+    _full_size_ekf(eng, orc, 524288, 5000, 5024, 5000, seed=5000, form=0)
 
 
-def test_north_star_1m_x_1000_landmarks(eng, orc):
-    """The north-star target workload: 1 048 576 particles x 1 000 landmarks on one GPU (Lp = 1 024)."""
-    _full_size_ekf(eng, orc, 1048576, 1000, 1024, 1000, seed=1000)
+@pytest.mark.parametrize("form", [0, 1])
+def test_north_star_1m_x_1000_landmarks(eng, orc, form):
+    """The north-star target workload: 1 048 576 particles x 1 000 landmarks on one GPU (Lp = 1 024), with either
+    out-of-place kernel (one wavefront per particle / per 8 neighbouring particles)."""
+    _full_size_ekf(eng, orc, 1048576, 1000, 1024, 1000, seed=1000, form=form)
 
 
 def test_north_star_sparse_observations(eng, orc):
     """Same size, only 32 of the 1 000 landmarks observed: the other 968 are copied through."""
-    _full_size_ekf(eng, orc, 1048576, 1000, 1024, 32, seed=1032, nsample=4096)
+    _full_size_ekf(eng, orc, 1048576, 1000, 1024, 32, seed=1032, nsample=4096, form=1)
 
 
 @pytest.mark.parametrize("L,Lp", [(4999, 4999), (4999, 5024), (5000, 5000), (5000, 5024), (5024, 5024), (8191, 8192),
@@ -132,6 +136,7 @@ def test_ekf_long_rows_small_n(eng, orc, L, Lp):
     against the CPU specification: in place, out of place, with the fused gather, subsets observed."""
     rng = np.random.default_rng(L * 3 + Lp)
     for n, with_anc, in_place, nobs in [(67, True, False, L), (5, False, True, L // 2), (130, True, False, 37), (64, False, False, 0)]:
+        eng.ekf_form_set(n % 2)   # 67, 5 -> the grouped out-of-place kernel; 130, 64 -> one wavefront per particle
         rows = n + (9 if with_anc else 0)
         mp = np.full((rows, 5, Lp), -555.0, np.float32)
         mp[:, 0:2, :L] = rng.normal(0, 3, (rows, 2, L))
@@ -158,6 +163,7 @@ def test_ekf_long_rows_small_n(eng, orc, L, Lp):
         tag = f"L={L} Lp={Lp} n={n} nobs={nobs} anc={with_anc} in_place={in_place}"
         assert np.array_equal(bits(got[:n, :, :L]), bits(want[:n, :, :L])), tag
         assert np.array_equal(bits(ll.cpu().numpy()), bits(wl)), tag
+    eng.ekf_form_set(-1)
 
 
 # ------------------------------------------------------------------ the sharded C session (slam_pf_create_sharded)
