@@ -233,8 +233,8 @@ def main():
     ap.add_argument("--presort-poses", action="store_true",
                     help="experiment, --mode score: upload the poses grouped by 4-pixel / matching-heading cells (what a "
                          "spatial ordering of the lanes would buy the scorer)")
-    ap.add_argument("--ekf-form", type=int, default=-1, choices=[-1, 0, 1],
-                    help="out-of-place EKF kernel: -1 the engine chooses (default), 0 one wavefront per particle, 1 per 8 particles")
+    ap.add_argument("--ekf-form", type=int, default=-1, choices=[-1, 0, 1, 2],
+                    help="out-of-place EKF kernel: -1 the engine chooses (default), 0 one wavefront per particle, 1 / 2 per 4 / 2 particles")
     ap.add_argument("--force-collectives", action="store_true",
                     help="diagnostics, --gpus 1 only: run the multi-GPU code path (every RCCL collective, the sharded index "
                          "kernels, the plan read-back) on a one-rank group to price its control overhead")

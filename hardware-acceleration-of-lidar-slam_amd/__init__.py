@@ -374,7 +374,7 @@ class Engine:
                                                      _ptr(d_src), _ptr(d_plan), _ptr(d_pose_idx)), "ancestors_sharded_dev")
 
     def ekf_form_set(self, form: int):
-        """-1: the engine chooses the out-of-place EKF kernel; 0: one wavefront per particle; 1: per 8 particles."""
+        """-1: the engine chooses the out-of-place EKF kernel; 0: one wavefront per particle; 1 / 2: per 4 / 2 particles."""
         self._ck(self.lib.slam_ekf_form_set(self.h, int(form)), "ekf_form_set")
 
     def ekf_form_counts(self):

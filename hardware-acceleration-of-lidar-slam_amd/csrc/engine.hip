@@ -156,7 +156,7 @@ int slam_engine_create(int device, slam_engine** out)
         }
     }
     e->stream = e->own_stream;
-    if (getenv("SLAM_EKF_GROUP")) e->ekf_form = atoi(getenv("SLAM_EKF_GROUP")) != 0;
+    if (getenv("SLAM_EKF_GROUP")) e->ekf_form = atoi(getenv("SLAM_EKF_GROUP"));
     *out = e;
     return SLAM_OK;
 }
@@ -661,8 +661,7 @@ int slam_ekf_update_dev(slam_engine* e, const float* d_map_in, float* d_map_out,
     a.meas_var = meas_var;
     a.loglik = e->ll_buf.as<float>();   // what slam_logweight_ekf_dev will consume
     a.loglik_user = d_loglik;
-    const bool group = nlandmarks > 128 && d_map_in != d_map_out &&
-                       (e->ekf_form >= 0 ? e->ekf_form != 0 : (d_anc && e->prefer_group_form(n, nlandmarks)));
+    const int group = nlandmarks > 128 && d_map_in != d_map_out ? e->ekf_group_size(n, d_anc != nullptr) : 0;
     HIP_TRY(launch_ekf_update(e->stream, a, e->prof_next(SLAM_PROF_EKF), group));
     if (d_map_in != d_map_out) e->ekf_form_launches[group ? 1 : 0]++;
     e->ll_n = n;
@@ -672,7 +671,7 @@ int slam_ekf_update_dev(slam_engine* e, const float* d_map_in, float* d_map_out,
 int slam_ekf_form_set(slam_engine* e, int form)
 {
     ENTER(e);
-    if (form < -1 || form > 1) return SLAM_ERR_INVALID_ARG;
+    if (form < -1 || form > 2) return SLAM_ERR_INVALID_ARG;
     e->ekf_form = getenv("SLAM_EKF_GROUP") ? atoi(getenv("SLAM_EKF_GROUP")) : form;   // the environment wins (measurements)
     return SLAM_OK;
 }

@@ -116,14 +116,16 @@ struct slam_engine {
         h.h_out = d_hheads;
         return h;
     }
-    // neighbours share ancestors (fewer than 3 distinct in 10 slots) and the rows are short enough for the grouped form
-    int ekf_form = -1;         // slam_ekf_form_set: -1 choose by the feedback, 0 row per wavefront, 1 grouped
+    int ekf_form = -1;         // slam_ekf_form_set: -1 choose by the feedback, 0 row per wavefront, 1 / 2 grouped by 4 / 2
     int64_t ekf_form_launches[2] = { 0, 0 };   // out-of-place launches so far: [0] one wavefront per particle, [1] grouped
-    bool prefer_group_form(int n, int nlandmarks) const
+    // particles per wavefront of an out-of-place update that gathers through `anc` (0 = one wavefront per particle): 4 when
+    // neighbours share ancestors (fewer than 3 distinct in 10 slots, as far as the last resample stage reported), else 2
+    int ekf_group_size(int n, bool has_anc) const
     {
-        if (ekf_form >= 0) return ekf_form != 0;
+        if (ekf_form >= 0) return ekf_form == 0 ? 0 : (ekf_form == 2 ? 2 : 4);
+        if (!has_anc) return 0;
         const int heads = h_heads[0], hn = h_heads[1];
-        return hn == n && nlandmarks <= 2048 && (int64_t)heads * 10 < (int64_t)n * 3;
+        return hn == n && (int64_t)heads * 10 < (int64_t)n * 3 ? 4 : 2;
     }
 
     slam::GateOut gate_next()

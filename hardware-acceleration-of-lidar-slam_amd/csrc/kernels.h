@@ -88,9 +88,9 @@ struct EkfArgs {
     float* loglik_user;   // optional second copy for the caller
     int xcd_chunk;        // set by the launcher: workgroups per XCD when the grid is renumbered XCD-contiguously, else 0
 };
-// prefer_group: use the grouped out-of-place form (neighbouring particles share their source rows in registers) — a
-// speed choice only, both forms give the same bits
-hipError_t launch_ekf_update(hipStream_t stream, const EkfArgs& a, const EventPair* ev = nullptr, bool prefer_group = false);
+// group_size: 0 = one wavefront per particle; 2 / 4 / 8 = the grouped out-of-place form (that many neighbouring particles
+// per wavefront share their source rows in registers) — a speed choice only, every form gives the same bits
+hipError_t launch_ekf_update(hipStream_t stream, const EkfArgs& a, const EventPair* ev = nullptr, int group_size = 0);
 
 // carry / prev_resampled (optional): see logweight_kernel — the weights a frame without resample left behind
 hipError_t launch_logweight(hipStream_t stream, const float* score, const float* loglik, float gain, int n,

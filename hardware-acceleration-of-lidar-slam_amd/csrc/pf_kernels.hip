@@ -278,7 +278,7 @@ __global__ __launch_bounds__(kEkfWaves * 64) void ekf_update_kernel(EkfArgs a)
     }
 }
 
-// ---- grouped form of the out-of-place update: ONE WAVEFRONT OWNS G NEIGHBOURING PARTICLES.
+// ---- grouped form of the out-of-place update: ONE WAVEFRONT OWNS G NEIGHBOURING PARTICLES (G = 2, 4 or 8).
 // After a resample the slots are sorted by ancestor, so neighbouring particles mostly descend from the same one.  The
 // row-per-wavefront kernel lets them share the source row through L2; measured (profiles/copy_ceiling.hip) even a pure copy
 // pays for that — 155 us at 64k x 512 columns when 16 neighbours share a source, against 109 us when nothing is re-read.
@@ -359,17 +359,15 @@ __device__ __forceinline__ void ekf_apply(const EkfBatch<NB>& b, const EkfPose& 
     }
 }
 
-constexpr int kEkfGroup = 8;   // particles per wavefront in the grouped form
 
 __device__ __forceinline__ float lane_value(float v, int k)   // lane k's value, wave-uniform (v_readlane_b32)
 {
     return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), k));
 }
 
-template <int NB>
+template <int NB, int G>
 __global__ __launch_bounds__(kEkfWaves * 64) void ekf_update_group_kernel(EkfArgs a)
 {
-    constexpr int G = kEkfGroup;
     __shared__ float s_acc[kEkfWaves][G][128];   // per particle of the group: the 128 accumulators of the specification
     const unsigned lane = threadIdx.x & 63u;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -1454,7 +1452,7 @@ hipError_t launch_motion_sample(hipStream_t stream, const float* sx, const float
     return hipGetLastError();
 }
 
-hipError_t launch_ekf_update(hipStream_t stream, const EkfArgs& a_in, const EventPair* ev, bool prefer_group)
+hipError_t launch_ekf_update(hipStream_t stream, const EkfArgs& a_in, const EventPair* ev, int group_size)
 {
     if (a_in.n <= 0) return hipSuccess;
     EkfArgs a = a_in;
@@ -1465,18 +1463,28 @@ hipError_t launch_ekf_update(hipStream_t stream, const EkfArgs& a_in, const Even
         blocks = 8 * a.xcd_chunk;
     }
     const bool copy = a.map_in != a.map_out;   // in place: rows without an observation stay as they are
-    // out of place, more than one batch per row: optionally the grouped form (kEkfGroup neighbouring particles per wavefront,
-    // shared source rows stay in registers): faster when neighbours share ancestors, slower when they do not (the caller
-    // knows roughly how many distinct ancestors the last resample left; slam_ekf_form_set forces one form).
-    if (copy && a.nlandmarks > 128 && prefer_group) {
-        int gblocks = (a.n + kEkfWaves * kEkfGroup - 1) / (kEkfWaves * kEkfGroup);
+    // out of place, more than one batch per row: optionally the grouped form (group_size neighbouring particles per
+    // wavefront, shared source rows stay in registers); the caller knows roughly how many distinct ancestors the last
+    // resample left (slam_ekf_form_set forces one form).
+    if (copy && a.nlandmarks > 128 && group_size > 0) {
+        // group size: measured on MI355X (64k x 500 | 1M x 1000 | 64k x 500 with 50 % distinct ancestors | 512k x 5000; one
+        // wavefront per particle: 156 us | 4.28 ms | 177 us | 10.09 ms): 2 particles 148 | 4.09 | 169 | 9.79; 3: 135;
+        // 4: 139 | 3.86 | 180 | 9.82; 6: 141; 8: 150 | 3.84 | 199 | 9.92.  Hence 4 when neighbours share ancestors, 2 when
+        // they rarely do.  SLAM_EKF_G overrides (measurements).
+        static const int forced = getenv("SLAM_EKF_G") ? atoi(getenv("SLAM_EKF_G")) : 0;
+        const int G = forced ? forced : group_size;
+        int gblocks = (a.n + kEkfWaves * G - 1) / (kEkfWaves * G);
         a.xcd_chunk = 0;
         if (gblocks >= 64) {
             a.xcd_chunk = (gblocks + 7) / 8;
             gblocks = 8 * a.xcd_chunk;
         }
         if (ev) (void)hipEventRecord(ev->start, stream);
-        ekf_update_group_kernel<2><<<gblocks, kEkfWaves * 64, 0, stream>>>(a);
+        switch (G) {
+        case 2: ekf_update_group_kernel<2, 2><<<gblocks, kEkfWaves * 64, 0, stream>>>(a); break;
+        case 8: ekf_update_group_kernel<2, 8><<<gblocks, kEkfWaves * 64, 0, stream>>>(a); break;
+        default: ekf_update_group_kernel<2, 4><<<gblocks, kEkfWaves * 64, 0, stream>>>(a); break;
+        }
         if (ev) (void)hipEventRecord(ev->stop, stream);
         return hipGetLastError();
     }

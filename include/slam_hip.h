@@ -210,10 +210,11 @@ int slam_ekf_update_dev(slam_engine *e, const float *d_map_in, float *d_map_out,
                         int n, float meas_var, float *d_loglik);
 
 /* The out-of-place update has two kernels that give the SAME bits: one wavefront per particle (neighbouring particles
- * share their ancestor's row through L2), and one wavefront per 8 neighbouring particles (the shared row stays in
- * registers: faster when a resample left few distinct ancestors, slower when neighbours do not share).  form = -1 (the
- * initial state): the engine chooses, steered by how many distinct ancestors its last resample stage left and by the row
- * length; 0 / 1 force the first / second kernel (tests, measurements; the environment variable SLAM_EKF_GROUP overrides). */
+ * share their ancestor's row through L2), and one wavefront per 2 or 4 neighbouring particles (the shared row stays in
+ * registers).  form = -1 (the initial state): the engine chooses — grouped whenever the update gathers through resample
+ * indices, 4 particles per wavefront when its last resample stage reported few distinct ancestors, else 2; 0 forces the
+ * first kernel, 1 / 2 the second with 4 / 2 particles per wavefront (tests, measurements; the environment variable
+ * SLAM_EKF_GROUP overrides). */
 int slam_ekf_form_set(slam_engine *e, int form);
 /* out-of-place EKF launches of this engine so far: counts[0] one wavefront per particle, counts[1] the grouped kernel */
 int slam_ekf_form_counts(slam_engine *e, int64_t counts[2]);

@@ -114,13 +114,13 @@ def _full_size_ekf(eng, orc, n, L, Lp, nobs, seed, nsample=4096, form=-1):
 def test_config4_share_512k_x_5000_landmarks(eng, orc):
     """BASELINE configs[4], one GPU's share: 524 288 particles x 5 000 landmarks, Lp = 5 024 (39 whole 128-landmark
     batches and a tail per row), resample gather fused, every landmark observed."""
-    _full_size_ekf(eng, orc, 524288, 5000, 5024, 5000, seed=5000, form=0)
+    _full_size_ekf(eng, orc, 524288, 5000, 5024, 5000, seed=5000, form=2)
 
 
 @pytest.mark.parametrize("form", [0, 1])
 def test_north_star_1m_x_1000_landmarks(eng, orc, form):
     """The north-star target workload: 1 048 576 particles x 1 000 landmarks on one GPU (Lp = 1 024), with either
-    out-of-place kernel (one wavefront per particle / per 8 neighbouring particles)."""
+    out-of-place kernel (one wavefront per particle / per 4 neighbouring particles)."""
     _full_size_ekf(eng, orc, 1048576, 1000, 1024, 1000, seed=1000, form=form)
 
 
@@ -136,7 +136,7 @@ def test_ekf_long_rows_small_n(eng, orc, L, Lp):
     against the CPU specification: in place, out of place, with the fused gather, subsets observed."""
     rng = np.random.default_rng(L * 3 + Lp)
     for n, with_anc, in_place, nobs in [(67, True, False, L), (5, False, True, L // 2), (130, True, False, 37), (64, False, False, 0)]:
-        eng.ekf_form_set(n % 2)   # 67, 5 -> the grouped out-of-place kernel; 130, 64 -> one wavefront per particle
+        eng.ekf_form_set({67: 1, 5: 2, 130: 2, 64: 0}[n])   # grouped by 4 / by 2 / one wavefront per particle
         rows = n + (9 if with_anc else 0)
         mp = np.full((rows, 5, Lp), -555.0, np.float32)
         mp[:, 0:2, :L] = rng.normal(0, 3, (rows, 2, L))

@@ -85,10 +85,10 @@ def _rand_map(rng, L, rows, Lp=None):
     (1, 3, 3, 3, False), (4097, 33, 64, 33, True), (256, 10, 32, 0, True), (130, 128, 128, 128, False),
     (77, 129, 160, 129, True), (64, 300, 320, 1, True), (50, 257, 257, 200, True), (9, 1, 1, 1, False),
 ])
-@pytest.mark.parametrize("form", [0, 1])
+@pytest.mark.parametrize("form", [0, 1, 2])
 def test_ekf_update(eng, orc, n, L, Lp, nobs, with_anc, form):
     import ctypes as C
-    eng.ekf_form_set(form)   # both out-of-place kernels (one wavefront per particle / per 8 particles) give these bits
+    eng.ekf_form_set(form)   # every out-of-place kernel (one wavefront per particle / per 4 / per 2 particles) gives these bits
     rng = np.random.default_rng(n * 31 + L)
     rows = n + 37 if with_anc else n
     mp = _rand_map(rng, L, rows, Lp)
@@ -127,7 +127,7 @@ def test_ekf_update_randomised_shapes(eng, orc):
         Lp = L + int(rng.choice([0, 1, 5, 31, 127, 200]))
         in_place = bool(rng.random() < 0.25)
         with_anc = (not in_place) and bool(rng.random() < 0.6)
-        eng.ekf_form_set(case % 2)
+        eng.ekf_form_set(case % 3)
         rows = n + (int(rng.integers(0, 50)) if with_anc else 0)
         mp = _rand_map(rng, L, rows, Lp)
         x, y, th = (rng.normal(0, 1, n).astype(np.float32) for _ in range(3))
@@ -564,7 +564,7 @@ def test_ranks_on_one_card_equal_one_rank_at_scale(tmp_path):
     assert max(int(p["migrated"].max()) for p in parts) > 20      # the exchange really carried rows
 
 
-@pytest.mark.parametrize("form", [0, 1])
+@pytest.mark.parametrize("form", [0, 1, 2])
 def test_full_size_ekf_config2_vs_oracle(eng, orc, form):
     """BASELINE config 2 at full size — 65 536 particles x 500 landmarks, every landmark observed, resample
     gather fused in: the whole 2 x 655 MB update against the CPU specification, bit for bit (both kernel forms)."""
