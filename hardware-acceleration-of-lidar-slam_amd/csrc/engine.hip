@@ -148,7 +148,7 @@ int slam_engine_create(int device, slam_engine** out)
     e->h_heads[0] = 0;
     e->h_heads[1] = -1;   // nothing known yet
     {
-        const int32_t one[2] = { 1, 0 };   // "the previous frame resampled": nothing is carried into the first frame; ticket = 0
+        const int32_t one[16] = { 1 };   // "the previous frame resampled": nothing is carried into the first frame; the rest 0
         if (hipMemcpy(e->gate_buf.p, one, sizeof one, hipMemcpyHostToDevice) != hipSuccess) {
             (void)hipGetLastError();
             slam_engine_destroy(e);
@@ -731,7 +731,7 @@ int slam_quantise_scan_dev(slam_engine* e, const float* d_logw, const float* d_m
         carry = e->carry_buf.as<float>();
     }
     HIP_TRY(launch_quantise_scan(e->stream, d_logw, d_max, e->bmax_buf.as<float>(), e->bmax_count, n, cdf, tiles, d_sum,
-                                 carry, tiles + ntiles, tiles + 2 * ntiles, e->gate_buf.as<unsigned int>() + 1));
+                                 carry, tiles + ntiles, tiles + 2 * ntiles, e->gate_buf.as<unsigned int>() + 2));
     e->scan_n = n;
     e->carry_n = carry ? n : -1;
     return SLAM_OK;

@@ -97,15 +97,15 @@ hipError_t launch_logweight(hipStream_t stream, const float* score, const float*
                             float* logw, float* block_max_scratch, float* d_max, const float* carry = nullptr,
                             const int32_t* prev_resampled = nullptr);
 int logweight_scratch_elems(int n);
-int logweight_scratch_floats();   // size of block_max_scratch: block maxima + one ticket word, zero-initialised once
+int logweight_scratch_floats();   // size of block_max_scratch: block maxima + two words, zero-initialised once
 hipError_t launch_quantise_weights(hipStream_t stream, const float* logw, const float* d_max, int n, uint64_t* wq,
                                    uint64_t* d_sum);
 
 // The resample gate (ESS-gated resampling; oracle: orc_ess_resample).  frac_q16 = threshold * 65536, 0 = no gate
 // (resample every frame).  Where the verdict goes: a device flag and, optionally, mapped host memory
 // {int32 resampled, uint32 sequence number}.
-// Where a resample stage reports roughly how many distinct ancestors it left: counter = {count, ticket} (device, zeroed
-// once, left zeroed), h_out = {count, n} in mapped host memory.
+// Where a resample stage reports roughly how many distinct ancestors it left: counter = one 8-byte-aligned pair of words
+// (device, zeroed once, left zeroed), h_out = {count, n} in mapped host memory.
 struct HeadsOut {
     unsigned int* counter = nullptr;
     int32_t* h_out = nullptr;

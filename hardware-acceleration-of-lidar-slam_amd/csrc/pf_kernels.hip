@@ -483,8 +483,7 @@ __global__ __launch_bounds__(kBlock) void logweight_kernel(const float* __restri
                                                            const float* __restrict__ loglik, float gain, int n,
                                                            const float* __restrict__ carry,
                                                            const int32_t* __restrict__ prev_resampled,
-                                                           float* __restrict__ logw, float* __restrict__ block_max,
-                                                           float* __restrict__ d_max, unsigned int* __restrict__ ticket)
+                                                           float* __restrict__ logw, float* __restrict__ block_max)
 {
     __shared__ float s_max[kBlock / 64];
     float m = -INFINITY;
@@ -500,29 +499,27 @@ __global__ __launch_bounds__(kBlock) void logweight_kernel(const float* __restri
     m = wave_max(m);
     if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = m;
     __syncthreads();
-    __shared__ bool s_last;
     if (threadIdx.x == 0) {
         for (int w = 1; w < kBlock / 64; ++w) m = fmaxf(m, s_max[w]);
         block_max[blockIdx.x] = m;
-        s_last = false;
-        if (d_max) {   // the workgroup that finishes last reduces the block maxima (saves the 1-workgroup launch behind this one)
-            __threadfence();
-            s_last = atomicAdd(ticket, 1u) == gridDim.x - 1;
-        }
     }
-    __syncthreads();
-    if (!s_last) return;
-    __threadfence();
-    float g = -INFINITY;
-    for (int i = threadIdx.x; i < (int)gridDim.x; i += kBlock) g = fmaxf(g, __hip_atomic_load(&block_max[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    g = wave_max(g);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = g;
+}
+
+// Several GPUs: the maximum of the block maxima as one float for the all-reduce.  (Folding this into the kernel above with
+// a "last workgroup done" ticket was measured and dropped: two atomics per workgroup on one address run at ~88 per
+// microsecond, 47 us at 2048 workgroups against 5 us for this launch.)
+__global__ __launch_bounds__(kBlock) void max_finalize_kernel(const float* __restrict__ block_max, int nblocks,
+                                                              float* __restrict__ d_max)
+{
+    __shared__ float s_max[kBlock / 64];
+    float m = -INFINITY;
+    for (int i = threadIdx.x; i < nblocks; i += kBlock) m = fmaxf(m, block_max[i]);
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = m;
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int w = 1; w < kBlock / 64; ++w) g = fmaxf(g, s_max[w]);
-        *d_max = g;
-        *ticket = 0;
+        for (int w = 1; w < kBlock / 64; ++w) m = fmaxf(m, s_max[w]);
+        *d_max = m;
     }
 }
 
@@ -738,26 +735,23 @@ __global__ __launch_bounds__(kBlock) void quantise_scan_kernel(const float* __re
             tile_q16[blockIdx.x] = b;
         }
     }
-    if (!d_sum) return;
-    // several GPUs: the shard's sums (what the ranks all-gather), by the workgroup that finishes last
-    __shared__ bool s_last;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence();
-        s_last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+    if (!d_sum || threadIdx.x != 0) return;
+    // several GPUs: the shard's sums (what the ranks all-gather) through integer atomics; the ticket add depends on their
+    // return values, so it is issued only after they have landed; the workgroup that finishes last hands the sums over and
+    // clears the accumulators.  No fences: nothing but atomics is published (a release fence per workgroup — an L2
+    // write-back across the XCDs — made this kernel 33 instead of 12 us at 512 workgroups).  Saves the one-workgroup launch
+    // behind this kernel at the usual shard sizes (32 workgroups at 64k particles).
+    unsigned long long* acc = reinterpret_cast<unsigned long long*>(ticket + 2);   // 3 accumulators behind the ticket
+    unsigned long long dep = atomicAdd(&acc[0], (unsigned long long)total);
+    if (GATED) {
+        dep ^= atomicAdd(&acc[1], (unsigned long long)tile_s16[blockIdx.x]);
+        dep ^= atomicAdd(&acc[2], (unsigned long long)tile_q16[blockIdx.x]);
     }
-    __syncthreads();
-    if (!s_last) return;
-    __threadfence();
-    const uint64_t* src[3] = { tile_total, tile_s16, tile_q16 };
-    for (int a = 0; a < (GATED ? 3 : 1); ++a) {
-        uint64_t acc = 0;
-        for (int t = threadIdx.x; t < (int)gridDim.x; t += kBlock)
-            acc += __hip_atomic_load(&src[a][t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        acc = block_sum_u64(acc, s_wave);
-        if (threadIdx.x == 0) d_sum[a] = acc;
-    }
-    if (threadIdx.x == 0) *ticket = 0;
+    uint32_t one = 1u;
+    asm volatile("" : "+v"(one) : "v"(dep));
+    if (atomicAdd(&ticket[0], one) != gridDim.x - 1) return;
+    for (int a = 0; a < (GATED ? 3 : 1); ++a) d_sum[a] = atomicExch(&acc[a], 0ull);
+    ticket[0] = 0;
 }
 
 // The resample gate (oracle: orc_ess_resample): resample iff ESS < frac * N, i.e. S^2 * 65536 < frac_q16 * N * Q, in
@@ -914,31 +908,28 @@ __global__ __launch_bounds__(kBlock) void offspring_from_scan_kernel(const uint6
 // Feedback for the host's choice between the two out-of-place EKF forms (it changes speed, never results): about how many
 // DISTINCT ancestors the resample left — a slot counts when its wavefront neighbour descends from another particle (so
 // wavefront boundaries count once too often: at most n / 64).  Summed with one atomic per workgroup; the workgroup that
-// finishes last hands {count, n} to mapped host memory and clears the counter.  The host reads it without any
-// synchronisation, a frame or two late.
+// finishes last hands {count, n} to mapped host memory and clears the counter (8-byte aligned pair of words).  The host
+// reads it without any synchronisation, a frame or two late.
 __device__ __forceinline__ void count_heads(const HeadsOut& h, int val, bool valid, int n)
 {
     if (!h.counter) return;
     __shared__ int s_heads[kBlock / 64];
-    __shared__ bool s_last_heads;
     const int up = __shfl_up(val, 1, 64);
     const bool head = valid && ((threadIdx.x & 63) == 0 || up != val);
     const int cnt = __popcll(__ballot(head));
     if ((threadIdx.x & 63) == 0) s_heads[threadIdx.x >> 6] = cnt;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        int sum = 0;
-        for (int w = 0; w < kBlock / 64; ++w) sum += s_heads[w];
-        atomicAdd(&h.counter[0], (unsigned)sum);
-        __threadfence();
-        s_last_heads = atomicAdd(&h.counter[1], 1u) == gridDim.x - 1;
-        if (s_last_heads) {
-            __threadfence();
-            h.h_out[0] = (int32_t)atomicExch(&h.counter[0], 0u);
-            h.h_out[1] = n;
-            h.counter[1] = 0;
-        }
-    }
+    if (threadIdx.x != 0) return;
+    int sum = 0;
+    for (int w = 0; w < kBlock / 64; ++w) sum += s_heads[w];
+    // ONE 64-bit atomic carries both the count (high word) and the number of workgroups done (low word): nothing else is
+    // published, so no fence is needed (a __threadfence() per workgroup made this kernel 2.5x slower at 1M slots)
+    unsigned long long* acc = reinterpret_cast<unsigned long long*>(h.counter);
+    const unsigned long long old = atomicAdd(acc, ((unsigned long long)(unsigned)sum << 32) | 1ull);
+    if ((unsigned)(old & 0xffffffffu) != gridDim.x - 1) return;
+    h.h_out[0] = (int32_t)((old >> 32) + (unsigned)sum);
+    h.h_out[1] = n;
+    atomicExch(acc, 0ull);
 }
 
 // Single GPU: the ancestor of every slot straight from the tile-local scan, without materialising `first`.
@@ -1504,7 +1495,7 @@ hipError_t launch_ekf_update(hipStream_t stream, const EkfArgs& a_in, const Even
 constexpr int kMaxWeightBlocks = 2048;
 static int capped_blocks(int n) { const int b = blocks_for(n); return b < kMaxWeightBlocks ? b : kMaxWeightBlocks; }
 int logweight_scratch_elems(int n) { return capped_blocks(n > 0 ? n : 1); }
-int logweight_scratch_floats() { return kMaxWeightBlocks + 1; }   // block maxima + the ticket word (zero-initialise once)
+int logweight_scratch_floats() { return kMaxWeightBlocks + 2; }   // block maxima + {ticket, running maximum} (zero-initialise once)
 
 hipError_t launch_logweight(hipStream_t stream, const float* score, const float* loglik, float gain, int n,
                             float* logw, float* block_max_scratch, float* d_max, const float* carry,
@@ -1512,9 +1503,8 @@ hipError_t launch_logweight(hipStream_t stream, const float* score, const float*
 {
     if (n <= 0) return hipSuccess;
     const int nb = capped_blocks(n);
-    // block_max_scratch[nb] is followed by the ticket word of the in-kernel final reduction (kept zero by the kernel)
-    logweight_kernel<<<nb, kBlock, 0, stream>>>(score, loglik, gain, n, carry, prev_resampled, logw, block_max_scratch, d_max,
-                                                reinterpret_cast<unsigned int*>(block_max_scratch + kMaxWeightBlocks));
+    logweight_kernel<<<nb, kBlock, 0, stream>>>(score, loglik, gain, n, carry, prev_resampled, logw, block_max_scratch);
+    if (d_max) max_finalize_kernel<<<1, kBlock, 0, stream>>>(block_max_scratch, nb, d_max);
     return hipGetLastError();
 }
 
@@ -1550,7 +1540,7 @@ hipError_t launch_quantise_scan(hipStream_t stream, const float* logw, const flo
 {
     if (n <= 0) return hipSuccess;
     const int ntiles = (n + kScanTile - 1) / kScanTile;
-    // `ticket`: one zero-initialised word the kernel leaves zeroed (the in-kernel final sums for d_sum)
+    // `ticket`: {ticket, pad, three 64-bit accumulators} (8-byte aligned behind the pad), zero-initialised, left zeroed
     if (carry)
         quantise_scan_kernel<true><<<ntiles, kBlock, 0, stream>>>(logw, d_max, block_max, nblock_max, n, cdf_local, tile_total,
                                                                   carry, tile_s16, tile_q16, d_sum, ticket);

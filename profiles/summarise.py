@@ -13,6 +13,7 @@ the read bytes are known a priori: 20 B x n x padded landmarks).
 """
 import csv
 import glob
+import os
 import json
 import shutil
 import sys
@@ -27,16 +28,16 @@ Lp = (L + 31) // 32 * 32
 
 
 def counter(mode, name):
-    f = glob.glob(str(src / f"{tag}_pmc_{name}_{mode}" / "*" / "*counter_collection.csv"))[0]
+    f = max(glob.glob(str(src / f"{tag}_pmc_{name}_{mode}" / "*" / "*counter_collection.csv")), key=os.path.getmtime)   # the newest run
     # both out-of-place kernels (ekf_update_kernel / ekf_update_group_kernel) count as "the EKF kernel"
     rows = [r for r in csv.DictReader(open(f)) if "ekf_update_" in r["Kernel_Name"] and r["Counter_Name"] == name]
     return [float(r["Counter_Value"]) * 1024 for r in rows]
 
 
 for mode, out in (("pf", "bench_pf"), ("score", "bench_score")):
-    f = glob.glob(str(src / f"{tag}_trace_{mode}" / "*" / "*kernel_stats.csv"))
+    f = sorted(glob.glob(str(src / f"{tag}_trace_{mode}" / "*" / "*kernel_stats.csv")), key=os.path.getmtime)
     if f:
-        shutil.copy(f[0], here / f"{tag}_{out}_kernel_stats.csv")
+        shutil.copy(f[-1], here / f"{tag}_{out}_kernel_stats.csv")
 
 if (src / f"{tag}_copy_ceiling.txt").exists():
     shutil.copy(src / f"{tag}_copy_ceiling.txt", here / f"{tag}_copy_ceiling.txt")

@@ -3,6 +3,7 @@
 -> profiles/TAG_pmc_score.md: per-launch averages, the derived rates, and what they say about the kernel's bound."""
 import csv
 import glob
+import os
 import sys
 from pathlib import Path
 
@@ -14,7 +15,7 @@ POSES, BEAMS, CUS, CLK = 1048576, 360, 256, 2.4e9
 
 vals = {}
 for d in sorted(glob.glob(str(src / f"{tag}_scorepmc_*"))):
-    for f in glob.glob(d + "/*/*counter_collection.csv"):
+    for f in sorted(glob.glob(d + "/*/*counter_collection.csv"), key=os.path.getmtime)[-1:]:   # the newest run
         rows = [r for r in csv.DictReader(open(f)) if "score_poses_kernel" in r["Kernel_Name"]]
         for name in sorted(set(r["Counter_Name"] for r in rows)):
             v = [float(r["Counter_Value"]) for r in rows if r["Counter_Name"] == name]
