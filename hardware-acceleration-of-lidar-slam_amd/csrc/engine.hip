@@ -759,7 +759,9 @@ int slam_ancestors_from_scan_dev(slam_engine* e, int n, uint64_t seed, uint32_t 
     const uint32_t frac = e->carry_n == n ? e->gate_frac_q16 : 0;   // the gate needs the sums of a gated quantise_scan
     const GateOut gate = frac ? e->gate_next() : GateOut();
     if (ancestors_from_scan_fits(n)) {
-        HIP_TRY(launch_ancestors_from_scan(e->stream, cdf, cdf + n, n, seed, frame, d_anc, frac, gate, e->heads_out()));
+        // the distinct-ancestor count only steers the EKF's kernel choice: made only for populations that have maps
+        HIP_TRY(launch_ancestors_from_scan(e->stream, cdf, cdf + n, n, seed, frame, d_anc, frac, gate,
+                                           e->ll_n == n ? e->heads_out() : HeadsOut()));
         return SLAM_OK;
     }
     // more tiles than the one-launch form keeps in LDS: the two-launch form through a scratch `first` array
