@@ -29,8 +29,7 @@ struct slam_pf {
     int Lp = 0;                                // plane stride: L rounded up to 32 floats (128-byte rows)
     int32_t* anc[2] = { nullptr, nullptr };
     float *score = nullptr, *logw = nullptr;
-    int32_t *count = nullptr, *first = nullptr, *best_idx = nullptr;
-    float* best_val = nullptr;
+    int32_t *count = nullptr, *first = nullptr;
     int cur = 0;       // pose / ancestor buffer holding the current particles
     int map_cur = 0;   // map buffer holding the current maps (flips only when the maps are rewritten)
     bool has_anc = false;
@@ -49,7 +48,6 @@ struct slam_pf {
     int32_t* d_plan = nullptr;      // exchange plan of the frame, device copy
     float *sbuf = nullptr, *rbuf = nullptr;   // grow-only exchange buffers
     size_t sbuf_floats = 0, rbuf_floats = 0;
-    float* cand = nullptr;          // [world][5] best-particle candidates
     bool exchange_pending = false;  // resample done, map rows not exchanged yet
     int rows_received = 0;
     // results a host asks for every frame (heaviest particle, posterior mean): written by ONE kernel to mapped host
@@ -204,7 +202,6 @@ int create_common(slam_engine* e, const slam_pf_config* cfg, slam_comm* comm, in
     }
     ok = ok && dev_alloc((void**)&pf->score, n * 4) == hipSuccess && dev_alloc((void**)&pf->logw, n * 4) == hipSuccess &&
          dev_alloc((void**)&pf->count, n * 4) == hipSuccess && dev_alloc((void**)&pf->first, n * 4) == hipSuccess &&
-         dev_alloc((void**)&pf->best_idx, 4) == hipSuccess && dev_alloc((void**)&pf->best_val, 4) == hipSuccess &&
          dev_alloc((void**)&pf->res_dev, 64) == hipSuccess && dev_alloc((void**)&pf->sums_acc, 64) == hipSuccess &&
          dev_alloc(&pf->res_all, 64 * G) == hipSuccess &&
          hipMemset(pf->sums_acc, 0, 64) == hipSuccess &&
@@ -216,8 +213,7 @@ int create_common(slam_engine* e, const slam_pf_config* cfg, slam_comm* comm, in
              dev_alloc((void**)&pf->pose_stage, 3 * cap * 4) == hipSuccess &&
              dev_alloc((void**)&pf->first_all, n * G * 4) == hipSuccess && dev_alloc((void**)&pf->d_max, 4) == hipSuccess &&
              dev_alloc((void**)&pf->d_sum, 3 * 8) == hipSuccess && dev_alloc((void**)&pf->totals, 3 * 8 * G) == hipSuccess &&
-             dev_alloc((void**)&pf->d_plan, 4 * SLAM_PLAN_WORDS(kMaxRanks)) == hipSuccess &&
-             dev_alloc((void**)&pf->cand, 4 * 5 * G) == hipSuccess;
+             dev_alloc((void**)&pf->d_plan, 4 * SLAM_PLAN_WORDS(kMaxRanks)) == hipSuccess;
     if (!ok) {
         (void)hipGetLastError();
         slam_pf_destroy(pf);
@@ -273,10 +269,9 @@ int slam_pf_destroy(slam_pf* pf)
         (void)hipFree(pf->map[b]);
         (void)hipFree(pf->pose_idx[b]);
     }
-    for (void* p : { (void*)pf->score, (void*)pf->logw, (void*)pf->count, (void*)pf->first, (void*)pf->best_idx,
-                     (void*)pf->best_val, (void*)pf->pose_all, (void*)pf->pose_stage, (void*)pf->first_all,
+    for (void* p : { (void*)pf->score, (void*)pf->logw, (void*)pf->count, (void*)pf->first, (void*)pf->pose_all, (void*)pf->pose_stage, (void*)pf->first_all,
                      (void*)pf->d_max, (void*)pf->d_sum, (void*)pf->totals, (void*)pf->d_plan, (void*)pf->sbuf,
-                     (void*)pf->rbuf, (void*)pf->cand, (void*)pf->res_dev, (void*)pf->sums_acc, pf->res_all })
+                     (void*)pf->rbuf, (void*)pf->res_dev, (void*)pf->sums_acc, pf->res_all })
         (void)hipFree(p);
     if (pf->h_res) (void)hipHostFree(pf->h_res);
     delete pf;

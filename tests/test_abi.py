@@ -52,3 +52,21 @@ def test_no_cpu_fallback_without_gpu():
     assert rc == -1 and not h.value
     # calls on a null engine are rejected, not emulated
     assert lib.slam_engine_sync(None) == -2
+
+
+def test_header_is_plain_c_and_cxx(tmp_path):
+    """include/slam_hip.h is the drop-in boundary: it must compile on its own as C99 and as C++ (no HIP, torch or RCCL
+    types in the signatures), and a C host built against it must link with the library alone."""
+    import subprocess
+
+    pkg = load_package()
+    hdr = pkg.HEADER_PATH
+    c = tmp_path / "t.c"
+    c.write_text(f'#include "{hdr}"\nint main(void) {{ slam_pf_config cfg; slam_pf_view v; cfg.n_particles = 1; v.anc = 0; (void)cfg; (void)v; '
+                 'return slam_abi_version() == SLAM_ABI_VERSION ? 0 : 1; }\n')
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-fsyntax-only", str(c)], check=True)
+    subprocess.run(["g++", "-std=c++11", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-x", "c++", str(c)], check=True)
+    exe = tmp_path / "t"
+    subprocess.run(["gcc", "-std=c99", "-o", str(exe), str(c), f"-L{pkg.LIB_PATH.parent}", "-lslam_hip",
+                    f"-Wl,-rpath,{pkg.LIB_PATH.parent}"], check=True)
+    assert subprocess.run([str(exe)]).returncode == 0   # needs no GPU: it only asks for the ABI version
