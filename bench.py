@@ -436,7 +436,7 @@ def main():
     for kk in (eng.PROF_SCORE, eng.PROF_EKF):
         eng.profile_read(kk)
     migrated = 0
-    forms0 = eng.ekf_form_counts()
+    forms0 = eng.ekf_form_counts() + eng.ekf_inplace_form_counts()
     t0 = time.perf_counter()
     for k in range(args.warmup, args.warmup + args.steps):
         one_step(k)
@@ -444,8 +444,8 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     eng.profile_enable()
-    forms1 = eng.ekf_form_counts()
-    forms = (forms1[0] - forms0[0], forms1[1] - forms0[1])   # out-of-place EKF launches of the timed region, by kernel
+    forms1 = eng.ekf_form_counts() + eng.ekf_inplace_form_counts()
+    forms = tuple(b - a for a, b in zip(forms0, forms1))   # EKF launches of the timed region, by kernel (out of place x2, in place x2)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -563,7 +563,8 @@ def main():
                      "avg_launch_ms": dur_ms, "avg_event_bracket_ms": raw_ms,
                      "event_bracket_overhead_ms": bracket_overhead_ms,
                      "launches": int(ekf_n if kern.startswith("ekf") else score_n),
-                     "ekf_launches_by_kernel": {"ekf_update_kernel": forms[0], "ekf_update_group_kernel": forms[1]},
+                     "ekf_launches_by_kernel": {"ekf_update_kernel": forms[0], "ekf_update_group_kernel": forms[1],
+                                                "ekf_update_kernel(in place)": forms[2], "ekf_sparse_kernel": forms[3]},
                      "other_kernel_avg_ms": {"score_poses_kernel": kernel_ms(score_ms, score_n),
                                              "ekf_update_kernel": kernel_ms(ekf_ms, ekf_n)}},
     }

@@ -102,6 +102,8 @@ SIGNATURES = {
     "slam_exchange_set_capacity": (_i, [_vp, _i]),
     "slam_ekf_form_set": (_i, [_vp, _i]),
     "slam_ekf_form_counts": (_i, [_vp, _vp]),
+    "slam_ekf_inplace_form_set": (_i, [_vp, _i]),
+    "slam_ekf_inplace_form_counts": (_i, [_vp, _vp]),
     "slam_resample_gate_set": (_i, [_vp, _f]),
     "slam_resample_happened_host": (_i, [_vp, C.POINTER(C.c_int)]),
     "slam_comm_unique_id": (_i, [_vp]),
@@ -380,6 +382,15 @@ class Engine:
     def ekf_form_counts(self):
         c = (C.c_int64 * 2)()
         self._ck(self.lib.slam_ekf_form_counts(self.h, c), "ekf_form_counts")
+        return int(c[0]), int(c[1])
+
+    def ekf_inplace_form_set(self, form: int):
+        """-1: the engine chooses the in-place EKF kernel; 0: whole rows; 1: the observed landmarks only (compact list)."""
+        self._ck(self.lib.slam_ekf_inplace_form_set(self.h, int(form)), "ekf_inplace_form_set")
+
+    def ekf_inplace_form_counts(self):
+        c = (C.c_int64 * 2)()
+        self._ck(self.lib.slam_ekf_inplace_form_counts(self.h, c), "ekf_inplace_form_counts")
         return int(c[0]), int(c[1])
 
     def resample_gate_set(self, ess_frac: float):

@@ -132,6 +132,8 @@ int slam_engine_create(int device, slam_engine** out)
         e->gate_buf.ensure(2 * sizeof(int32_t)) != hipSuccess ||
         hipHostMalloc((void**)&e->h_heads, sizeof(int32_t) * 2, hipHostMallocMapped) != hipSuccess ||
         hipHostGetDevicePointer((void**)&e->d_hheads, e->h_heads, 0) != hipSuccess ||
+        hipHostMalloc((void**)&e->h_obs, sizeof(int32_t) * 2, hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer((void**)&e->d_hobs, e->h_obs, 0) != hipSuccess ||
         e->heads_buf.ensure(2 * sizeof(int32_t)) != hipSuccess ||
         hipMemset(e->heads_buf.p, 0, 2 * sizeof(int32_t)) != hipSuccess ||   // the gate's flag + the ticket word of quantise_scan_kernel
         e->scan_buf.ensure(sizeof(float) * 2 * SLAM_MAX_BEAMS) != hipSuccess ||
@@ -147,6 +149,9 @@ int slam_engine_create(int device, slam_engine** out)
     e->h_gate[1] = 0;
     e->h_heads[0] = 0;
     e->h_heads[1] = -1;   // nothing known yet
+    e->h_obs[0] = 0;
+    e->h_obs[1] = -1;
+    if (getenv("SLAM_EKF_INPLACE")) e->ekf_inplace_form = atoi(getenv("SLAM_EKF_INPLACE"));
     {
         const int32_t one[16] = { 1 };   // "the previous frame resampled": nothing is carried into the first frame; the rest 0
         if (hipMemcpy(e->gate_buf.p, one, sizeof one, hipMemcpyHostToDevice) != hipSuccess) {
@@ -193,6 +198,8 @@ int slam_engine_destroy(slam_engine* e)
     if (e->h_plan) (void)hipHostFree(e->h_plan);
     if (e->h_gate) (void)hipHostFree(e->h_gate);
     if (e->h_heads) (void)hipHostFree(e->h_heads);
+    if (e->h_obs) (void)hipHostFree(e->h_obs);
+    e->obs_list.release();
     e->heads_buf.release();
     e->gate_buf.release();
     e->carry_buf.release();
@@ -620,6 +627,7 @@ int slam_obs_upload_host(slam_engine* e, const int32_t* landmark_id, const float
     e->d_obs_zx = e->obs_buf.as<float>();
     e->d_obs_zy = e->obs_buf.as<float>() + L;
     e->obs_nlandmarks = nlandmarks;
+    e->obs_list_valid = false;
     return SLAM_OK;
 }
 
@@ -630,6 +638,7 @@ int slam_obs_set_dev(slam_engine* e, const float* d_zx_by_landmark, const float*
     e->d_obs_zx = d_zx_by_landmark;
     e->d_obs_zy = d_zy_by_landmark;
     e->obs_nlandmarks = nlandmarks;
+    e->obs_list_valid = false;
     return SLAM_OK;
 }
 
@@ -661,9 +670,41 @@ int slam_ekf_update_dev(slam_engine* e, const float* d_map_in, float* d_map_out,
     a.meas_var = meas_var;
     a.loglik = e->ll_buf.as<float>();   // what slam_logweight_ekf_dev will consume
     a.loglik_user = d_loglik;
-    const int group = nlandmarks > 128 && d_map_in != d_map_out ? e->ekf_group_size(n, d_anc != nullptr) : 0;
-    HIP_TRY(launch_ekf_update(e->stream, a, e->prof_next(SLAM_PROF_EKF), group));
-    if (d_map_in != d_map_out) e->ekf_form_launches[group ? 1 : 0]++;
+    if (d_map_in == d_map_out) {
+        // in place: whole rows, or — when the last list that was built had few observations — the observed landmarks only
+        const bool can_list = nlandmarks <= kObsListMaxLandmarks;
+        const bool sparse = can_list && (e->ekf_inplace_form >= 0 ? e->ekf_inplace_form == 1
+                                                                  : e->h_obs[1] == nlandmarks && 4 * (int64_t)e->h_obs[0] <= nlandmarks);
+        const bool build = can_list && !e->obs_list_valid && (sparse || e->ekf_inplace_form < 0);
+        const size_t L = (size_t)nlandmarks;
+        int32_t* li = nullptr;
+        if (build || sparse) {
+            if (e->obs_list.cap < 4 * (4 * L + 2)) {
+                HIP_TRY(hipStreamSynchronize(e->stream));
+                HIP_TRY(e->obs_list.ensure(4 * (4 * L + 2)));
+                e->obs_list_valid = false;
+            }
+            li = e->obs_list.as<int32_t>();
+        }
+        auto build_list = [&]() -> hipError_t {
+            e->obs_list_valid = true;
+            return launch_build_obs_list(e->stream, e->d_obs_zx, e->d_obs_zy, nlandmarks, li, (float*)(li + L),
+                                         (float*)(li + 2 * L), li + 3 * L, li + 4 * L, e->d_hobs);
+        };
+        if (sparse) {
+            if (!e->obs_list_valid) HIP_TRY(build_list());
+            HIP_TRY(launch_ekf_sparse(e->stream, a, li, (const float*)(li + L), (const float*)(li + 2 * L), li + 3 * L,
+                                      li + 4 * L, e->prof_next(SLAM_PROF_EKF)));
+        } else {
+            HIP_TRY(launch_ekf_update(e->stream, a, e->prof_next(SLAM_PROF_EKF), 0));
+            if (build) HIP_TRY(build_list());   // after the update: only the count for the next frames is wanted
+        }
+        e->ekf_inplace_launches[sparse ? 1 : 0]++;
+    } else {
+        const int group = nlandmarks > 128 ? e->ekf_group_size(n, d_anc != nullptr) : 0;
+        HIP_TRY(launch_ekf_update(e->stream, a, e->prof_next(SLAM_PROF_EKF), group));
+        e->ekf_form_launches[group ? 1 : 0]++;
+    }
     e->ll_n = n;
     return SLAM_OK;
 }
@@ -673,6 +714,23 @@ int slam_ekf_form_set(slam_engine* e, int form)
     ENTER(e);
     if (form < -1 || form > 2) return SLAM_ERR_INVALID_ARG;
     e->ekf_form = getenv("SLAM_EKF_GROUP") ? atoi(getenv("SLAM_EKF_GROUP")) : form;   // the environment wins (measurements)
+    return SLAM_OK;
+}
+
+int slam_ekf_inplace_form_set(slam_engine* e, int form)
+{
+    ENTER(e);
+    if (form < -1 || form > 1) return SLAM_ERR_INVALID_ARG;
+    e->ekf_inplace_form = getenv("SLAM_EKF_INPLACE") ? atoi(getenv("SLAM_EKF_INPLACE")) : form;
+    return SLAM_OK;
+}
+
+int slam_ekf_inplace_form_counts(slam_engine* e, int64_t counts[2])
+{
+    ENTER(e);
+    if (!counts) return SLAM_ERR_INVALID_ARG;
+    counts[0] = e->ekf_inplace_launches[0];
+    counts[1] = e->ekf_inplace_launches[1];
     return SLAM_OK;
 }
 

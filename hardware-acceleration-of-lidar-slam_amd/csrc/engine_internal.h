@@ -116,6 +116,16 @@ struct slam_engine {
         h.h_out = d_hheads;
         return h;
     }
+    // in-place updates (frames that keep their population) have two equivalent kernels as well: whole rows in batches of
+    // 128 landmarks, or only the observed landmarks from a compact list (obs_list: ids | zx | zy | rounds, [L] each, then
+    // {nobs, highest round}).  The list is built at most once per observation table; {nobs, L} of the last build sit in
+    // mapped host memory and steer the choice for the following frames (read without synchronisation).
+    DevBuf obs_list;
+    bool obs_list_valid = false;
+    int32_t* h_obs = nullptr;
+    int32_t* d_hobs = nullptr;
+    int ekf_inplace_form = -1;   // slam_ekf_inplace_form_set: -1 by the feedback, 0 whole rows, 1 observed landmarks only
+    int64_t ekf_inplace_launches[2] = { 0, 0 };
     int ekf_form = -1;         // slam_ekf_form_set: -1 choose by the feedback, 0 row per wavefront, 1 / 2 grouped by 4 / 2
     int64_t ekf_form_launches[2] = { 0, 0 };   // out-of-place launches so far: [0] one wavefront per particle, [1] grouped
     // particles per wavefront of an out-of-place update that gathers through `anc` (0 = one wavefront per particle): 4 when

@@ -93,6 +93,14 @@ struct EkfArgs {
 hipError_t launch_ekf_update(hipStream_t stream, const EkfArgs& a, const EventPair* ev = nullptr, int group_size = 0);
 
 // carry / prev_resampled (optional): see logweight_kernel — the weights a frame without resample left behind
+// In-place update of the OBSERVED landmarks only (frames that keep their population): the observation table is first
+// compacted into a list in landmark order (ids, measurements, accumulator rounds; count[2] = {nobs, highest round} on the
+// device, {nobs, L} optionally in mapped host memory), then one lane per observation gathers, updates and scatters.
+constexpr int kObsListMaxLandmarks = 65536;   // the list form keeps a bitmap of the observed landmarks in LDS
+hipError_t launch_build_obs_list(hipStream_t stream, const float* tzx, const float* tzy, int L, int32_t* id, float* zx,
+                                 float* zy, int32_t* round, int32_t* count, int32_t* h_count);
+hipError_t launch_ekf_sparse(hipStream_t stream, const EkfArgs& a, const int32_t* id, const float* zx, const float* zy,
+                             const int32_t* round, const int32_t* count, const EventPair* ev = nullptr);
 hipError_t launch_logweight(hipStream_t stream, const float* score, const float* loglik, float gain, int n,
                             float* logw, float* block_max_scratch, float* d_max, const float* carry = nullptr,
                             const int32_t* prev_resampled = nullptr);

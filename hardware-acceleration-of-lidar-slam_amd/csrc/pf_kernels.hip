@@ -469,6 +469,169 @@ __global__ __launch_bounds__(kEkfWaves * 64) void ekf_update_group_kernel(EkfArg
     }
 }
 
+// ---- sparse in-place form: frames that keep their population update only the OBSERVED landmarks, in place.
+// Walking the rows in batches of 128 (ekf_batches, in place) runs the whole update arithmetic at full wavefront cost for
+// the handful of lanes of a batch that hold an observation and touches every line a batch's observed landmarks lie in
+// once per batch.  Here the observations are first compacted into a list sorted by landmark (once per observation
+// table, build_obs_list_kernel); a wavefront then owns one particle and a LANE owns an observation (two per lane, as
+// float2): gather the five values at that landmark, update, scatter them back — the same arithmetic in the same order.
+// The log-likelihood keeps the summation order of the specification (landmark l adds to accumulator l mod 128 in order
+// of l): the accumulators live in LDS, and observations that fall into the same accumulator carry a round number
+// (how many earlier observations share it) and are added round by round.
+struct ObsList {
+    const int32_t* id;      // [nobs] landmark of observation k, ascending
+    const float *zx, *zy;   // [nobs]
+    const int32_t* round;   // [nobs] number of earlier observations with the same id mod 128
+    const int32_t* count;   // [2] device: nobs, highest round
+};
+
+// one workgroup: table (NaN = not observed) -> list in landmark order, rounds, counts (also to mapped host memory).
+// L <= kObsListMaxLandmarks (the bitmap of observed landmarks lives in LDS).
+__global__ __launch_bounds__(1024) void build_obs_list_kernel(const float* __restrict__ tzx, const float* __restrict__ tzy,
+                                                              int L, int32_t* __restrict__ id, float* __restrict__ zx,
+                                                              float* __restrict__ zy, int32_t* __restrict__ round,
+                                                              int32_t* __restrict__ count, int32_t* __restrict__ h_count)
+{
+    __shared__ unsigned s_bits[kObsListMaxLandmarks / 32];
+    __shared__ int s_wave[16];
+    __shared__ int s_base;
+    __shared__ int s_max_round;
+    if (threadIdx.x == 0) { s_base = 0; s_max_round = 0; }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int l0 = 0; l0 < L; l0 += 1024) {   // ordered compaction, 1024 landmarks per step
+        const int l = l0 + (int)threadIdx.x;
+        const float vx = l < L ? tzx[l] : __builtin_nanf(""), vy = l < L ? tzy[l] : __builtin_nanf("");
+        const bool ob = vx == vx && vy == vy;
+        const unsigned long long m = __ballot(ob);
+        if (lane == 0) s_wave[wave] = __popcll(m);
+        if (lane == 0) s_bits[(l0 >> 5) + 2 * wave] = (unsigned)m;
+        if (lane == 32) s_bits[(l0 >> 5) + 2 * wave + 1] = (unsigned)(m >> 32);
+        __syncthreads();
+        int off = s_base;
+        for (int w = 0; w < wave; ++w) off += s_wave[w];
+        if (ob) {
+            const int k = off + __popcll(m & ((1ull << lane) - 1ull));
+            id[k] = l;
+            zx[k] = vx;
+            zy[k] = vy;
+            // round: earlier observed landmarks with the same l mod 128 = the same bit of every fourth word below
+            int r = 0;
+            for (int b = l - 128; b >= 0; b -= 128) r += (int)((s_bits[b >> 5] >> (b & 31)) & 1u);
+            round[k] = r;
+            if (r > 0) atomicMax(&s_max_round, r);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int tot = 0;
+            for (int w = 0; w < 16; ++w) tot += s_wave[w];
+            s_base += tot;
+        }
+        __syncthreads();
+    }
+    const int nobs = s_base;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        count[0] = nobs;
+        count[1] = s_max_round;
+        if (h_count) {
+            h_count[0] = nobs;
+            h_count[1] = L;
+        }
+    }
+}
+
+__global__ __launch_bounds__(kEkfWaves * 64) void ekf_sparse_kernel(EkfArgs a, ObsList ol)
+{
+    __shared__ float s_acc[kEkfWaves][128];
+    const unsigned lane = threadIdx.x & 63u;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    int bid = blockIdx.x;
+    if (a.xcd_chunk > 0) bid = (bid & 7) * a.xcd_chunk + (bid >> 3);
+    const int i = bid * kEkfWaves + wave;
+    if (i >= a.n) return;
+    float st_, ct_;
+    det_sincosf(a.th[i], st_, ct_);
+    const int row_bytes = __builtin_amdgcn_readfirstlane(5 * a.plane_stride * 4);
+    const int pl = __builtin_amdgcn_readfirstlane(a.plane_stride * 4);
+    const __amdgpu_buffer_rsrc_t row =   // in place: the particle's own row, read and written
+        __builtin_amdgcn_make_buffer_rsrc((void*)uniform_gptr(a.map_out + (int64_t)i * a.row_stride), 0, row_bytes, 0x00020000);
+    const v2f s = bc2(st_), c = bc2(ct_), px = bc2(a.x[i]), py = bc2(a.y[i]), q = bc2(a.meas_var);
+    const int nobs = __builtin_amdgcn_readfirstlane(ol.count[0]);
+    const int max_round = __builtin_amdgcn_readfirstlane(ol.count[1]);
+    s_acc[wave][lane] = 0.0f;
+    s_acc[wave][lane + 64] = 0.0f;
+    for (int k0 = 0; k0 < nobs; k0 += 128) {
+        bool ob[2];
+        unsigned off[2];
+        int slot[2], rnd[2];
+        v2f zx, zy, m[5];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int k = k0 + 64 * t + (int)lane;
+            ob[t] = k < nobs;
+            const int kk = ob[t] ? k : 0;
+            const int l = ol.id[kk];
+            off[t] = (unsigned)l * 4u;
+            slot[t] = l & 127;
+            rnd[t] = ol.round[kk];
+            zx[t] = ol.zx[kk];
+            zy[t] = ol.zy[kk];
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int p = 0; p < 5; ++p) m[p][t] = ob[t] ? row_load(row, off[t], p * pl) : 1.0f;   // 1: harmless operands for idle lanes
+        const v2f mx = m[0], my = m[1], pxx = m[2], pxy = m[3], pyy = m[4];
+        const v2f dx = mx - px, dy = my - py;
+        const v2f vx = zx - (c * dx - s * dy);
+        const v2f vy = zy - (s * dx + c * dy);
+        const v2f a00 = c * pxx - s * pxy, a01 = c * pxy - s * pyy;
+        const v2f a10 = s * pxx + c * pxy, a11 = s * pxy + c * pyy;
+        const v2f s00 = (a00 * c - a01 * s) + q;
+        const v2f s01 = a00 * s + a01 * c;
+        const v2f s11 = (a10 * s + a11 * c) + q;
+        const v2f det = s00 * s11 - s01 * s01;
+        const v2f idet = (v2f){1.0f / det[0], 1.0f / det[1]};
+        const v2f i00 = s11 * idet, i01 = -s01 * idet, i11 = s00 * idet;
+        const v2f k00 = a00 * i00 + a10 * i01, k01 = a00 * i01 + a10 * i11;
+        const v2f k10 = a01 * i00 + a11 * i01, k11 = a01 * i01 + a11 * i11;
+        const v2f o0 = mx + (k00 * vx + k01 * vy);
+        const v2f o1 = my + (k10 * vx + k11 * vy);
+        const v2f o2 = pxx - (k00 * a00 + k01 * a10);
+        const v2f o3 = pxy - (k00 * a01 + k01 * a11);
+        const v2f o4 = pyy - (k10 * a01 + k11 * a11);
+        const v2f maha = vx * (i00 * vx + i01 * vy) + vy * (i01 * vx + i11 * vy);
+        const v2f ll = ((bc2(0.0f) - bc2(0.5f) * maha) - bc2(0.5f) * det_logf2(det)) - bc2(1.8378770664f);
+        const v2f f0 = px + (c * zx + s * zy);   // first sighting: the observed point, P = R, no likelihood
+        const v2f f1 = py + (c * zy - s * zx);
+        float term[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const bool first = pxx[t] < 0.0f;
+            term[t] = first ? 0.0f : ll[t];
+            if (ob[t]) {
+                row_store(row, off[t], 0 * pl, first ? f0[t] : o0[t]);
+                row_store(row, off[t], 1 * pl, first ? f1[t] : o1[t]);
+                row_store(row, off[t], 2 * pl, first ? q[t] : o2[t]);
+                row_store(row, off[t], 3 * pl, first ? 0.0f : o3[t]);
+                row_store(row, off[t], 4 * pl, first ? q[t] : o4[t]);
+            }
+        }
+        // log-likelihood: accumulator = landmark mod 128, in order of the landmark: round by round (observations of one
+        // accumulator have distinct rounds; a wavefront's LDS operations execute in order)
+        for (int r = 0; r <= max_round; ++r)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+                if (ob[t] && rnd[t] == r) s_acc[wave][slot[t]] = s_acc[wave][slot[t]] + term[t];
+    }
+    const float total = wave_xor_tree_sum(s_acc[wave][lane] + s_acc[wave][lane + 64]);
+    if (lane == 0) {
+        a.loglik[i] = total;
+        if (a.loglik_user) a.loglik_user[i] = total;
+    }
+}
+
 // ------------------------------------------------------------------ A11: weights
 __device__ __forceinline__ float wave_max(float v)
 {
@@ -1485,6 +1648,31 @@ constexpr int kMaxWeightBlocks = 2048;
 static int capped_blocks(int n) { const int b = blocks_for(n); return b < kMaxWeightBlocks ? b : kMaxWeightBlocks; }
 int logweight_scratch_elems(int n) { return capped_blocks(n > 0 ? n : 1); }
 int logweight_scratch_floats() { return kMaxWeightBlocks + 2; }   // block maxima + {ticket, running maximum} (zero-initialise once)
+
+hipError_t launch_build_obs_list(hipStream_t stream, const float* tzx, const float* tzy, int L, int32_t* id, float* zx,
+                                 float* zy, int32_t* round, int32_t* count, int32_t* h_count)
+{
+    build_obs_list_kernel<<<1, 1024, 0, stream>>>(tzx, tzy, L, id, zx, zy, round, count, h_count);
+    return hipGetLastError();
+}
+
+hipError_t launch_ekf_sparse(hipStream_t stream, const EkfArgs& a_in, const int32_t* id, const float* zx, const float* zy,
+                             const int32_t* round, const int32_t* count, const EventPair* ev)
+{
+    if (a_in.n <= 0) return hipSuccess;
+    EkfArgs a = a_in;
+    int blocks = (a.n + kEkfWaves - 1) / kEkfWaves;
+    a.xcd_chunk = 0;
+    if (blocks >= 64) {
+        a.xcd_chunk = (blocks + 7) / 8;
+        blocks = 8 * a.xcd_chunk;
+    }
+    ObsList ol{ id, zx, zy, round, count };
+    if (ev) (void)hipEventRecord(ev->start, stream);
+    ekf_sparse_kernel<<<blocks, kEkfWaves * 64, 0, stream>>>(a, ol);
+    if (ev) (void)hipEventRecord(ev->stop, stream);
+    return hipGetLastError();
+}
 
 hipError_t launch_logweight(hipStream_t stream, const float* score, const float* loglik, float gain, int n,
                             float* logw, float* block_max_scratch, float* d_max, const float* carry,

@@ -218,6 +218,14 @@ int slam_ekf_update_dev(slam_engine *e, const float *d_map_in, float *d_map_out,
 int slam_ekf_form_set(slam_engine *e, int form);
 /* out-of-place EKF launches of this engine so far: counts[0] one wavefront per particle, counts[1] the grouped kernel */
 int slam_ekf_form_counts(slam_engine *e, int64_t counts[2]);
+/* The in-place update (d_map_in == d_map_out: frames that keep their population, slam_resample_gate_set) also has two
+ * kernels with the SAME bits: whole rows in batches of 128 landmarks, and the observed landmarks only, from a list
+ * the engine compacts out of the observation table once per table (nlandmarks <= 65536).  form = -1 (initial): the
+ * second whenever the last list built for this nlandmarks held at most nlandmarks / 4 observations; 0 / 1 force the
+ * first / second (tests, measurements; environment variable SLAM_EKF_INPLACE overrides).
+ * counts[0] / counts[1]: in-place launches so far of the first / second. */
+int slam_ekf_inplace_form_set(slam_engine *e, int form);
+int slam_ekf_inplace_form_counts(slam_engine *e, int64_t counts[2]);
 
 /* A11: logw[i] = loglik[i] - score[i] * score_gain  (either input may be NULL = 0) and
  * *d_max = max_i logw[i] (float, device).  Then, with the GLOBAL maximum m (after an all-reduce MAX

@@ -128,6 +128,7 @@ def test_ekf_update_randomised_shapes(eng, orc):
         in_place = bool(rng.random() < 0.25)
         with_anc = (not in_place) and bool(rng.random() < 0.6)
         eng.ekf_form_set(case % 3)
+        eng.ekf_inplace_form_set(case // 3 % 2)   # in place: whole rows / the observed landmarks from the compact list
         rows = n + (int(rng.integers(0, 50)) if with_anc else 0)
         mp = _rand_map(rng, L, rows, Lp)
         x, y, th = (rng.normal(0, 1, n).astype(np.float32) for _ in range(3))
@@ -154,6 +155,63 @@ def test_ekf_update_randomised_shapes(eng, orc):
         else:
             assert np.array_equal(bits(got[:, :, L:]), bits(mp[:, :, L:])), tag    # in place never touches the padding
     eng.ekf_form_set(-1)
+    eng.ekf_inplace_form_set(-1)
+
+
+@pytest.mark.parametrize("form", [0, 1, -1])
+def test_ekf_in_place_forms(eng, orc, form):
+    """The two in-place kernels (whole rows in batches of 128 landmarks; the observed landmarks only, from the compact
+    list) against the CPU specification: landmark counts up to configs[4]'s 5000, observation counts from none to all —
+    with several observations per log-likelihood accumulator (l mod 128), more than 128 observations (several passes of
+    the list kernel), unseen landmarks, observations given as a host list and as a device table.  form -1: whatever
+    the engine picks from the previous list's count must give the same bits."""
+    import ctypes as C
+    rng = np.random.default_rng(77 + form)
+    eng.ekf_inplace_form_set(form)
+    before = eng.ekf_inplace_form_counts()
+    ncases = 0
+    for L, nobs_list in [(1, [0, 1]), (127, [5, 127]), (500, [0, 1, 32, 125, 300, 500]), (1000, [32, 129, 1000]), (5000, [32, 700, 5000])]:
+        for nobs in nobs_list:
+            for n in (3, 260):
+                Lp = L + int(rng.choice([0, 12]))
+                mp = _rand_map(rng, L, n, Lp)
+                x, y, th = (rng.normal(0, 1, n).astype(np.float32) for _ in range(3))
+                if rng.random() < 0.5:   # clustered: landmarks of ONE accumulator (l mod 128), as many as there are
+                    ids = int(rng.integers(0, 128)) + 128 * rng.permutation((L + 127) // 128)[:nobs]
+                    ids = ids[ids < L]
+                else:
+                    ids = rng.permutation(L)[:nobs]
+                ids = ids.astype(np.int32)
+                rng.shuffle(ids)
+                k = len(ids)
+                zx, zy = rng.normal(0, 2, k).astype(np.float32), rng.normal(0, 2, k).astype(np.float32)
+                if ncases % 2:
+                    eng.obs_upload(ids, zx, zy, L)
+                    tabs = None
+                else:
+                    tx, ty = np.full(L, np.nan, np.float32), np.full(L, np.nan, np.float32)
+                    tx[ids], ty[ids] = zx, zy
+                    tabs = (dev(tx), dev(ty))
+                    eng.obs_set_dev(tabs[0], tabs[1], L)
+                d = dev(mp)
+                ll = torch.empty(n, device=DEV)
+                eng.ekf_update_dev(d, d, 5 * Lp, Lp, L, dev(x), dev(y), dev(th), None, n, 0.015, ll)
+                want, wl = mp.copy(), np.empty(n, np.float32)
+                orc.lib().orc_ekf_update(want, want, 5 * Lp, Lp, L, x, y, th, None, n, ids, zx, zy, k, 0.015, wl)
+                tag = f"form {form}: n={n} L={L} Lp={Lp} nobs={k}"
+                assert np.array_equal(bits(host(d)), bits(want)), tag   # padding included: never touched
+                assert np.array_equal(bits(host(ll)), bits(wl)), tag
+                ncases += 1
+    after = eng.ekf_inplace_form_counts()
+    eng.ekf_inplace_form_set(-1)
+    d0, d1 = after[0] - before[0], after[1] - before[1]
+    assert d0 + d1 == ncases
+    if form == 0:
+        assert d1 == 0
+    elif form == 1:
+        assert d0 == 0
+    else:
+        assert d0 > 0 and d1 > 0   # the feedback chose each of them at some point
 
 
 def test_ekf_in_place_and_argument_checks(eng, orc):
