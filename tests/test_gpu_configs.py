@@ -167,7 +167,7 @@ def test_ekf_long_rows_small_n(eng, orc, L, Lp):
 
 
 # ------------------------------------------------------------------ the sharded C session (slam_pf_create_sharded)
-def _run_c_session_ranks(world, n_total, L, frames, transport="local", recv_capacity=0, ess=0.0):
+def _run_c_session_ranks(world, n_total, L, frames, transport="local", recv_capacity=0, ess=0.0, inplace_form=-1):
     """`world` ranks of the C-level sharded session in THIS process, one host thread per rank, all on cuda:0
     (in-process transport), or a one-rank RCCL communicator.  Returns the concatenated population."""
     import threading
@@ -188,6 +188,7 @@ def _run_c_session_ranks(world, n_total, L, frames, transport="local", recv_capa
     def rank_main(r):
         try:
             eng = pkg.Engine(0)
+            eng.ekf_inplace_form_set(inplace_form)   # frames that keep their population: whole rows / the compact observation list
             eng.grid_set_dev(0, d_edt, gm)
             eng.scan_upload(bx, by)
             comm = None
@@ -341,15 +342,16 @@ def _gated_reference(orc, n, L, frames, ess):
     return np.stack([x[anc], y[anc], th[anc]]), (mp[anc] if L else None), verdicts
 
 
+@pytest.mark.parametrize("inplace_form", [0, 1])
 @pytest.mark.parametrize("L,ess", [(6, 0.5), (0, 0.1), (6, 0.2), (6, 0.05), (6, 0.9)])
-def test_ess_gated_session_matches_specification(orc, L, ess):
+def test_ess_gated_session_matches_specification(orc, L, ess, inplace_form):
     """slam_pf_config.resample_ess_frac: frames whose effective sample size stays above the threshold keep their
     population (ancestor = itself, EKF in place on the observed landmarks, weights carried into the next frame); the
     verdict is integer arithmetic on the device.  Poses and maps after 9 frames equal the CPU specification bit for bit,
     and the scenario contains frames of both kinds."""
     n, frames = 4096, 9
     want_pose, want_map, verdicts = _gated_reference(orc, n, L, frames, ess)
-    got = _run_c_session_ranks(1, n, L, frames, transport=None, ess=ess)[0]
+    got = _run_c_session_ranks(1, n, L, frames, transport=None, ess=ess, inplace_form=inplace_form)[0]
     assert np.array_equal(bits(got["pose"]), bits(want_pose))
     if L:
         assert np.array_equal(bits(got["map"]), bits(want_map))
@@ -365,7 +367,7 @@ def test_ess_gated_sharded_session_equals_one_rank(orc, world, L):
     exchange nothing."""
     n_total, frames, ess = 4096, 9, (0.5 if L else 0.1)
     one = _run_c_session_ranks(1, n_total, L, frames, transport=None, ess=ess)[0]
-    many = _run_c_session_ranks(world, n_total, L, frames, ess=ess)
+    many = _run_c_session_ranks(world, n_total, L, frames, ess=ess, inplace_form=1)   # ranks: list form; one GPU: the engine's choice
     assert np.array_equal(bits(np.concatenate([p["pose"] for p in many], axis=1)), bits(one["pose"]))
     if L:
         assert np.array_equal(bits(np.concatenate([p["map"] for p in many], axis=0)), bits(one["map"]))
