@@ -628,6 +628,7 @@ int slam_obs_upload_host(slam_engine* e, const int32_t* landmark_id, const float
     e->d_obs_zy = e->obs_buf.as<float>() + L;
     e->obs_nlandmarks = nlandmarks;
     e->obs_list_valid = false;
+    e->obs_table_owned = true;
     return SLAM_OK;
 }
 
@@ -639,6 +640,7 @@ int slam_obs_set_dev(slam_engine* e, const float* d_zx_by_landmark, const float*
     e->d_obs_zy = d_zy_by_landmark;
     e->obs_nlandmarks = nlandmarks;
     e->obs_list_valid = false;
+    e->obs_table_owned = false;   // the caller may rewrite the arrays between launches: a list made from them is never reused
     return SLAM_OK;
 }
 
@@ -673,6 +675,7 @@ int slam_ekf_update_dev(slam_engine* e, const float* d_map_in, float* d_map_out,
     if (d_map_in == d_map_out) {
         // in place: whole rows, or — when the last list that was built had few observations — the observed landmarks only
         const bool can_list = nlandmarks <= kObsListMaxLandmarks;
+        if (!e->obs_table_owned) e->obs_list_valid = false;   // the caller's arrays may have been rewritten since the last launch
         const bool sparse = can_list && (e->ekf_inplace_form >= 0 ? e->ekf_inplace_form == 1
                                                                   : e->h_obs[1] == nlandmarks && 4 * (int64_t)e->h_obs[0] <= nlandmarks);
         const bool build = can_list && !e->obs_list_valid && (sparse || e->ekf_inplace_form < 0);

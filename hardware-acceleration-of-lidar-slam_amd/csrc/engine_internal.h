@@ -122,6 +122,7 @@ struct slam_engine {
     // mapped host memory and steer the choice for the following frames (read without synchronisation).
     DevBuf obs_list;
     bool obs_list_valid = false;
+    bool obs_table_owned = false;   // the table is the engine's own copy (slam_obs_upload_host), not the caller's arrays
     int32_t* h_obs = nullptr;
     int32_t* d_hobs = nullptr;
     int ekf_inplace_form = -1;   // slam_ekf_inplace_form_set: -1 by the feedback, 0 whole rows, 1 observed landmarks only

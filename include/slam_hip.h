@@ -201,7 +201,8 @@ int slam_obs_upload_host(slam_engine *e, const int32_t *landmark_id, const float
                          int nlandmarks);
 /* Observations already on the device, as the table the engine works on: entry l of the two arrays is the
  * observation of landmark l, NaN in d_zx_by_landmark[l] = landmark l was not observed this frame.  Nothing is
- * copied: the arrays must stay valid until the EKF call that uses them has run. */
+ * copied: the arrays must stay valid until the EKF call that uses them has run.  Their contents may be rewritten
+ * between launches without another slam_obs_set_dev: every launch reads them afresh (stream-ordered). */
 int slam_obs_set_dev(slam_engine *e, const float *d_zx_by_landmark, const float *d_zy_by_landmark, int nlandmarks);
 /* d_loglik may be NULL: the log-likelihoods always stay inside the engine as well, where
  * slam_logweight_ekf_dev picks them up. */

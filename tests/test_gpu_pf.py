@@ -214,6 +214,36 @@ def test_ekf_in_place_forms(eng, orc, form):
         assert d0 > 0 and d1 > 0   # the feedback chose each of them at some point
 
 
+@pytest.mark.parametrize("form", [0, 1])
+def test_ekf_in_place_sees_a_rewritten_device_table(eng, orc, form):
+    """slam_obs_set_dev adopts the caller's arrays: when the caller rewrites them between two launches (same pointers,
+    no second slam_obs_set_dev), the next update must use the new contents — the compact list is never reused for tables
+    the engine does not own."""
+    rng = np.random.default_rng(31 + form)
+    n, L = 300, 200
+    mp = _rand_map(rng, L, n)
+    x, y, th = (rng.normal(0, 1, n).astype(np.float32) for _ in range(3))
+    tx, ty = torch.full((L,), float("nan"), device=DEV), torch.full((L,), float("nan"), device=DEV)
+    eng.ekf_inplace_form_set(form)
+    eng.obs_set_dev(tx, ty, L)
+    d = dev(mp)
+    ll = torch.empty(n, device=DEV)
+    want = mp.copy()
+    for rnd in range(3):
+        ids = np.sort(rng.permutation(L)[:7 + 5 * rnd]).astype(np.int32)
+        zx, zy = rng.normal(0, 2, len(ids)).astype(np.float32), rng.normal(0, 2, len(ids)).astype(np.float32)
+        tx.fill_(float("nan"))
+        ty.fill_(float("nan"))
+        tx[torch.from_numpy(ids.astype(np.int64)).to(DEV)] = dev(zx)
+        ty[torch.from_numpy(ids.astype(np.int64)).to(DEV)] = dev(zy)
+        torch.cuda.synchronize()
+        eng.ekf_update_dev(d, d, 5 * L, L, L, dev(x), dev(y), dev(th), None, n, 0.02, ll)
+        want, wl = orc.ekf_update(want, x, y, th, None, ids, zx, zy, 0.02)
+        assert np.array_equal(bits(host(d)), bits(want)), rnd
+        assert np.array_equal(bits(host(ll)), bits(wl)), rnd
+    eng.ekf_inplace_form_set(-1)
+
+
 def test_ekf_in_place_and_argument_checks(eng, orc):
     pkg = load_package()
     rng = np.random.default_rng(2)
