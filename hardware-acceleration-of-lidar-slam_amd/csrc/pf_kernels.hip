@@ -1613,7 +1613,9 @@ hipError_t launch_ekf_update(hipStream_t stream, const EkfArgs& a_in, const Even
         // group size: measured on MI355X (64k x 500 | 1M x 1000 | 64k x 500 with 50 % distinct ancestors | 512k x 5000; one
         // wavefront per particle: 156 us | 4.28 ms | 177 us | 10.09 ms): 2 particles 148 | 4.09 | 169 | 9.79; 3: 135;
         // 4: 139 | 3.86 | 180 | 9.82; 6: 141; 8: 150 | 3.84 | 199 | 9.92.  Hence 4 when neighbours share ancestors, 2 when
-        // they rarely do.  SLAM_EKF_G overrides (measurements).
+        // they rarely do.  SLAM_EKF_G overrides (measurements).  Batches in flight per pass (the first template argument),
+        // group of 4, 64k x 500 | 1M x 1000 | 512k x 5000: 1: 150 us | 3.97 ms; 2: 140-145 | 3.90-3.92 | 9.79; 3: 144 | 4.02;
+        // 4: 137-139 | 3.86 | 9.86 — within the run-to-run spread: 2 kept (82 VGPRs, 5 waves per SIMD; 4 needs 114).
         static const int forced = getenv("SLAM_EKF_G") ? atoi(getenv("SLAM_EKF_G")) : 0;
         const int G = forced ? forced : group_size;
         int gblocks = (a.n + kEkfWaves * G - 1) / (kEkfWaves * G);
