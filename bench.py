@@ -30,7 +30,8 @@ One JSON line on stdout (rank 0), including
                  (nothing comes out of L2 there: the streaming figure); `read_only_frac` is the north star's definition
                  (20 B x n x L_observed / t / peak) on that sweep
   cpu_baseline — the CPU port of the same frame loop (oracle/, single thread) timed on this host
-                 on a bounded sample (rank 0, N = 1 only)
+                 on a bounded sample (rank 0, N = 1 only); cpu_baseline_threads: the same port with its per-particle
+                 stages on up to 16 host threads (SURVEY 8d's optional "all cores" line), about 8 s more
 """
 from __future__ import annotations
 
@@ -183,6 +184,76 @@ def cpu_baseline(args, occ, meta_t, frames, landmarks, budget_s=12.0):
             "host_cpu": model, "host_cores_total": os.cpu_count(),
             "sample": f"{n} particles x {done} frames of the same workload ({args.beams} beams, {L} landmarks, "
                       f"{args.grid}^2 EDT), oracle/ C port, 1 thread, {el:.1f} s"}
+
+
+def cpu_baseline_threads(args, occ, meta_t, frames, landmarks, budget_s=8.0):
+    """The same CPU port with the per-particle stages (motion, score, EKF) spread over host threads, particles in
+    contiguous chunks — SURVEY 8(d)'s optional "all cores" line, labelled as such.  The GPU box gives one GPU's job 16
+    cores' worth of CPU, so 16 threads at most.  ctypes releases the interpreter lock inside the C functions."""
+    import ctypes as C
+    from concurrent.futures import ThreadPoolExecutor
+
+    import oracle
+
+    T = max(1, min(16, os.cpu_count() or 1))
+    rows = cols = args.grid
+    edt = oracle.edt(occ, rows, cols, 10.0, "window")
+    m = oracle.meta(rows, cols, cols, *meta_t)
+    per = 512
+    n = per * T
+    rng = np.random.default_rng(99)
+    p0 = true_pose(0)
+    pose = [(p0[k] + rng.normal(0, s, n)).astype(np.float32) for k, s in ((0, 0.05), (1, 0.05), (2, 0.01))]
+    L = len(landmarks)
+    use_ekf = bool(L) and args.mode != "score"
+    mp = np.zeros((n, 5, max(L, 1)), np.float32)
+    if L:
+        mp[:, 0] = landmarks[:, 0] + rng.normal(0, 0.1, (n, L))
+        mp[:, 1] = landmarks[:, 1] + rng.normal(0, 0.1, (n, L))
+        mp[:, 2] = 0.05
+        mp[:, 4] = 0.05
+    mp2 = np.empty_like(mp)
+    new = [np.empty(n, np.float32) for _ in range(3)]
+    score, ll = np.empty(n, np.float32), np.zeros(n, np.float32)
+    lib = oracle.lib()
+    anc = None
+    done = 0
+
+    def chunk(c, fr, frame):
+        sl = slice(c * per, (c + 1) * per)
+        a = None if anc is None else anc[sl]
+        src = pose if a is not None else [p[sl] for p in pose]   # ancestors index the whole population
+        x, y, th = oracle.motion_sample(src[0], src[1], src[2], a, per, c * per, fr["dp"], args.sigma, 1234, frame)
+        for k, v in enumerate((x, y, th)):
+            new[k][sl] = v
+        score[sl] = oracle.score_poses_det(m, edt, fr["bx"], fr["by"], x, y, th)[0]
+        if use_ekf:
+            ids = np.ascontiguousarray(fr["ids"], np.int32)
+            lib.orc_ekf_update(mp if a is not None else mp[sl], mp2[sl], 5 * L, L, L, x, y, th,
+                               a.ctypes.data_as(C.c_void_p) if a is not None else None, per, ids,
+                               np.ascontiguousarray(fr["zx"], np.float32), np.ascontiguousarray(fr["zy"], np.float32), len(ids),
+                               args.meas_var, ll[sl])
+
+    with ThreadPoolExecutor(T) as pool:
+        t0 = time.perf_counter()
+        while True:
+            fr = frames[done % len(frames)]
+            list(pool.map(lambda c: chunk(c, fr, done), range(T)))
+            pose = [v.copy() for v in new]
+            if use_ekf:
+                mp, mp2 = mp2, mp
+            elif L and anc is not None:
+                mp = mp[anc]
+            logw, mx = oracle.logweight(score, ll if use_ekf else None, args.score_gain)
+            wq, _ = oracle.quantise_weights(logw, mx)
+            anc = np.ascontiguousarray(oracle.resample(wq, 1234, done), np.int32)
+            done += 1
+            el = time.perf_counter() - t0
+            if el > budget_s and done >= 3:
+                break
+    return {"value": n * done / el, "unit": "particle-updates/s", "cores": T, "kind": "port",
+            "sample": f"{n} particles x {done} frames of the same workload, oracle/ C port, per-particle stages on {T} host "
+                      f"threads (weights and resample on one), {el:.1f} s"}
 
 
 class stdout_to_stderr:
@@ -570,6 +641,7 @@ def main():
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, occ, (float(pixel), float(min_x), float(min_y)), frames, landmarks)
+        out["cpu_baseline_threads"] = cpu_baseline_threads(args, occ, (float(pixel), float(min_x), float(min_y)), frames, landmarks)
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:
