@@ -1152,7 +1152,18 @@ __global__ __launch_bounds__(kBlock) void ancestors_from_scan_kernel(const uint6
             t_lo += comb_u;
             t_hi += t_lo < comb_u ? 1ull : 0ull;
             const uint64_t N = (uint64_t)n;
-            int lo = 0, hi = n - 1;   // number of k in [0, n-1) with N*C_incl(k) <= T
+            // number of k in [0, n-1) with N*C_incl(k) <= T.  First among the tiles, in LDS: the CDF at the end of tile t is
+            // the offset of tile t + 1 (the grand total for the last one), so whole tiles below T are counted without
+            // touching memory; then inside the one tile that holds the boundary (each step there is a dependent L2 round trip:
+            // 11 of them instead of log2 n).
+            int tlo = 0, thi = ntiles - 1;   // first tile whose last element lies above T (the last tile if none does)
+            while (tlo < thi) {
+                const int mid = (tlo + thi) >> 1;
+                const uint64_t c = s_off[mid + 1];   // mid + 1 <= ntiles - 1
+                const uint64_t x_lo = c * N, x_hi = __umul64hi(c, N);
+                if (x_hi < t_hi || (x_hi == t_hi && x_lo <= t_lo)) tlo = mid + 1; else thi = mid;
+            }
+            int lo = tlo * kScanTile, hi = (tlo + 1) * kScanTile < n - 1 ? (tlo + 1) * kScanTile : n - 1;
             // (an 8-ary search — seven pivots per step side by side — was measured equal: 10.5 us at 64k slots, 62 us at 1M:
             // fewer dependent round trips, but seven times the gathers)
             while (lo < hi) {
