@@ -253,6 +253,51 @@ def test_score_dispatch_boundaries_and_max_beams(eng, orc, npose, nbeams):
         assert np.array_equal(bits(hits), bits(h2))
 
 
+@pytest.mark.parametrize("case", ["clustered", "spread", "edges", "odd_stride", "tiny"])
+def test_score_pose_layouts_vs_oracle(eng, orc, case):
+    """Pose populations of different shapes against the CPU specification, bit for bit: clustered like the offspring of a
+    resample (runs of ~16 near-identical neighbours), spread over metres and radians, clusters whose beams fall off the
+    grid on every side, a grid whose row stride is not a multiple of 4 cells, pose counts that leave most of a wavefront /
+    workgroup empty, beam counts 0, 1, 2, odd."""
+    pkg = load_package()
+    rng = np.random.default_rng({"clustered": 1, "spread": 2, "edges": 3, "odd_stride": 4, "tiny": 5}[case])
+    grid, ld, pixel, lo = 512, 512, 0.05, -12.8
+    cfgs = [(70_000, 360), (140_000, 90)]
+    if case == "odd_stride":
+        ld = 515
+    if case == "tiny":
+        cfgs = [(1, 360), (63, 7), (65, 1), (257, 2), (300, 0), (4097, 359)]
+    occ = np.zeros((grid, ld), np.int32)
+    occ[:, :grid] = (rng.random((grid, grid)) < 0.02)
+    meta = pkg.grid_meta(grid, grid, ld, pixel, lo, lo)
+    edt = eng.grid_upload(2, occ, meta, 10.0, want_edt=True)
+    om = orc.meta(grid, grid, ld, pixel, lo, lo)
+    for npose, nbeams in cfgs:
+        ang = rng.uniform(-np.pi, np.pi, nbeams)
+        rad = rng.uniform(0.5, 14.0, nbeams)
+        bx, by = (rad * np.cos(ang)).astype(np.float32), (rad * np.sin(ang)).astype(np.float32)
+        eng.scan_upload(bx, by)
+        if case == "spread":
+            x, y, th = (s * rng.standard_normal(npose) for s in (2.0, 2.0, 1.0))
+        elif case == "edges":   # clusters around points near and beyond every border
+            c = rng.integers(0, 8, npose)
+            cx = np.array([-12.7, 12.7, 0, 0, -13.5, 13.5, 12.0, -12.0])[c]
+            cy = np.array([0, 0, -12.7, 12.7, 13.5, -13.5, 12.0, -12.0])[c]
+            x, y, th = cx + 0.02 * rng.standard_normal(npose), cy + 0.02 * rng.standard_normal(npose), 0.7 * c + 0.003 * rng.standard_normal(npose)
+        else:   # offspring of a resample: runs of ~16 neighbours around an ancestor, motion noise on top
+            anc = np.sort(rng.integers(0, max(npose // 16, 1), npose))
+            ax, ay, at = (s * rng.standard_normal(max(npose // 16, 1)) for s in (0.1, 0.1, 0.02))
+            x, y, th = (ax[anc] + 0.01 * rng.standard_normal(npose), ay[anc] + 0.01 * rng.standard_normal(npose),
+                        0.4 + at[anc] + 0.002 * rng.standard_normal(npose))
+        x, y, th = (np.asarray(v, np.float32) for v in (x, y, th))
+        s_gpu, c_gpu = eng.score_poses_host(2, x, y, th)
+        s_cpu, c_cpu = orc.score_poses_det(om, edt, bx, by, x, y, th)
+        assert np.array_equal(c_gpu, c_cpu), (case, npose, nbeams)
+        assert np.array_equal(bits(s_gpu), bits(s_cpu)), (case, npose, nbeams)
+        if nbeams and case != "edges":
+            assert c_gpu.max() > 0
+
+
 def test_full_size_score_config3_properties(eng, orc):
     """BASELINE config 3 at full size: 1 048 576 poses, 360 beams, 2048^2 EDT.  A 16k-pose sample is checked
     against the oracle bit for bit; the size-independent property — a pose's score does not depend on which
