@@ -306,6 +306,9 @@ def main():
                          "spatial ordering of the lanes would buy the scorer)")
     ap.add_argument("--ekf-form", type=int, default=-1, choices=[-1, 0, 1, 2],
                     help="out-of-place EKF kernel: -1 the engine chooses (default), 0 one wavefront per particle, 1 / 2 per 4 / 2 particles")
+    ap.add_argument("--paged", action="store_true",
+                    help="C session, one GPU: landmark maps as copy-on-write pages (slam_pf_paged_set) instead of one row per "
+                         "particle: for frames that observe few of many landmarks (--observed K); no no-reuse sweep")
     ap.add_argument("--force-collectives", action="store_true",
                     help="diagnostics, --gpus 1 only: run the multi-GPU code path (every RCCL collective, the sharded index "
                          "kernels, the plan read-back) on a one-rank group to price its control overhead")
@@ -354,6 +357,11 @@ def main():
 
     eng = pkg.Engine(dev_index)
     eng.ekf_form_set(args.ekf_form)
+    if args.paged:
+        if args.driver != "c" or world > 1 or args.force_collectives or args.mode != "pf":
+            sys.exit("bench.py: --paged is for the C session on one GPU, --mode pf")
+        eng.pf_paged_set(True)
+        args.no_sweep = True
     use_c = args.driver == "c"
     if use_c and args.dist_backend != "nccl":
         sys.exit("bench.py: --driver c exchanges over RCCL; use --driver py for a gloo rehearsal")
@@ -424,7 +432,9 @@ def main():
     pf.set_poses(*init)
     if L:
         lm = torch.from_numpy(landmarks.astype(np.float32)).to(dev)
-        m0 = views()[1]                                   # [particle][plane][Lp]
+        paged = use_c and pf.is_paged()
+        # paged maps have no rows to write into: the same rows are made in a scratch tensor and handed over once
+        m0 = torch.empty((n, 5, Lp), dtype=torch.float32, device=dev) if paged else views()[1]   # [particle][plane][Lp]
         for i0 in range(0, n, 65536):                     # in chunks: the temporaries of a 1M x 1k map are 4 GB each
             i1 = min(i0 + 65536, n)
             m0[i0:i1, 0, :L] = lm[:, 0] + 0.1 * torch.randn((i1 - i0, L), device=dev)
@@ -432,6 +442,11 @@ def main():
         m0[:n, 2, :L] = 0.05
         m0[:n, 3, :L] = 0.0
         m0[:n, 4, :L] = 0.05
+        if paged:
+            torch.cuda.synchronize()
+            pf.set_map_dev(m0, 5 * Lp, Lp)
+            eng.sync()
+            del m0
     score_t = torch.zeros(n, dtype=torch.float32, device=dev)
     count_t = torch.zeros(n, dtype=torch.int32, device=dev)
     loglik_t = torch.zeros(n, dtype=torch.float32, device=dev)
@@ -580,6 +595,8 @@ def main():
 
     # the engine picks one of two out-of-place EKF kernels that give the same bits; name the one that ran
     ekf_name = "ekf_update_group_kernel" if forms[1] > forms[0] else "ekf_update_kernel"
+    if args.paged:
+        ekf_name = "ekf_paged_kernel"
     if ekf_n and (ekf_ms >= score_ms or args.mode == "ekf"):
         kern, raw_ms, dur_ms, alg = ekf_name, ekf_ms / ekf_n, kernel_ms(ekf_ms, ekf_n), ekf_bytes
     else:
@@ -589,7 +606,7 @@ def main():
     traffic, traffic_src = None, None
     tfile = ROOT / "profiles" / "traffic.json"   # HBM bytes per launch from rocprofv3 --pmc runs of this same command
     if tfile.exists():
-        key = (f"{args.mode}:{n}:{args.beams}:{L}:{args.grid}" + (f":obs{L_obs}" if L_obs != L else "")
+        key = (f"{args.mode}:{n}:{args.beams}:{L}:{args.grid}" + (":paged" if args.paged else "") + (f":obs{L_obs}" if L_obs != L else "")
                + (f":ess{args.ess}" if 0 < args.ess < 1 else ""))   # a gated run has its own traffic (none on file: falls back)
         rec = json.loads(tfile.read_text()).get(key, {})
         traffic, traffic_src = rec.get("ekf_update_kernel" if kern.startswith("ekf") else kern), rec.get("source")
@@ -618,6 +635,7 @@ def main():
                    "rows_received_per_frame_max_rank": migrated if world > 1 else 0,
                    "distinct_ancestor_frac": distinct_frac,
                    "resample_ess_frac": args.ess if use_c else 0.0,
+                   "map_layout": "pages (copy-on-write, 32 landmarks)" if args.paged else "rows",
                    "frames_resampled": (pf.frames_resampled() if use_c and 0 < args.ess < 1 else None)},
         "roofline": {"bound": "hbm", "kernel": kern, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "achieved_basis": basis,

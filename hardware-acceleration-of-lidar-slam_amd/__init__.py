@@ -103,6 +103,9 @@ SIGNATURES = {
     "slam_ekf_form_set": (_i, [_vp, _i]),
     "slam_ekf_form_counts": (_i, [_vp, _vp]),
     "slam_ekf_inplace_form_set": (_i, [_vp, _i]),
+    "slam_pf_paged_set": (_i, [_vp, _i]),
+    "slam_pf_is_paged": (_i, [_vp]),
+    "slam_pf_set_map_dev": (_i, [_vp, _vp, _i64, _i]),
     "slam_ekf_inplace_form_counts": (_i, [_vp, _vp]),
     "slam_resample_gate_set": (_i, [_vp, _f]),
     "slam_resample_happened_host": (_i, [_vp, C.POINTER(C.c_int)]),
@@ -384,6 +387,10 @@ class Engine:
         self._ck(self.lib.slam_ekf_form_counts(self.h, c), "ekf_form_counts")
         return int(c[0]), int(c[1])
 
+    def pf_paged_set(self, on: bool):
+        """Sessions made from now on keep their maps as copy-on-write pages (one GPU; same results as rows)."""
+        self._ck(self.lib.slam_pf_paged_set(self.h, int(bool(on))), "pf_paged_set")
+
     def ekf_inplace_form_set(self, form: int):
         """-1: the engine chooses the in-place EKF kernel; 0: whole rows; 1: the observed landmarks only (compact list)."""
         self._ck(self.lib.slam_ekf_inplace_form_set(self.h, int(form)), "ekf_inplace_form_set")
@@ -573,6 +580,13 @@ class PfSession:
         rows = _np(rows, np.float32)
         assert rows.shape == (self.n, 5, self.L)
         self.e._ck(self.e.lib.slam_pf_set_map_host(self.h, _ptr(rows)), "pf_set_map")
+
+    def set_map_dev(self, d_rows, row_stride: int, plane_stride: int):
+        """Maps from device memory: rows [n_particles][5][plane_stride] floats, row_stride floats apart (asynchronous)."""
+        self.e._ck(self.e.lib.slam_pf_set_map_dev(self.h, _ptr(d_rows), int(row_stride), int(plane_stride)), "pf_set_map_dev")
+
+    def is_paged(self) -> bool:
+        return bool(self.e.lib.slam_pf_is_paged(self.h))
 
     def step(self, slot, dp, use_observations=False):
         self.e._ck(self.e.lib.slam_pf_step(self.h, slot, _f3(dp), 1 if use_observations else 0), "pf_step")

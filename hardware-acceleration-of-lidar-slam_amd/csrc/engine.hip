@@ -152,6 +152,7 @@ int slam_engine_create(int device, slam_engine** out)
     e->h_obs[0] = 0;
     e->h_obs[1] = -1;
     if (getenv("SLAM_EKF_INPLACE")) e->ekf_inplace_form = atoi(getenv("SLAM_EKF_INPLACE"));
+    if (getenv("SLAM_PF_PAGED")) e->pf_paged = atoi(getenv("SLAM_PF_PAGED")) != 0;
     {
         const int32_t one[16] = { 1 };   // "the previous frame resampled": nothing is carried into the first frame; the rest 0
         if (hipMemcpy(e->gate_buf.p, one, sizeof one, hipMemcpyHostToDevice) != hipSuccess) {
@@ -717,6 +718,14 @@ int slam_ekf_form_set(slam_engine* e, int form)
     ENTER(e);
     if (form < -1 || form > 2) return SLAM_ERR_INVALID_ARG;
     e->ekf_form = getenv("SLAM_EKF_GROUP") ? atoi(getenv("SLAM_EKF_GROUP")) : form;   // the environment wins (measurements)
+    return SLAM_OK;
+}
+
+int slam_pf_paged_set(slam_engine* e, int on)
+{
+    ENTER(e);
+    if (on < 0 || on > 1) return SLAM_ERR_INVALID_ARG;
+    e->pf_paged = on != 0;
     return SLAM_OK;
 }
 

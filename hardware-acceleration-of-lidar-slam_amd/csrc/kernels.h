@@ -101,6 +101,44 @@ hipError_t launch_build_obs_list(hipStream_t stream, const float* tzx, const flo
                                  float* zy, int32_t* round, int32_t* count, int32_t* h_count);
 hipError_t launch_ekf_sparse(hipStream_t stream, const EkfArgs& a, const int32_t* id, const float* zx, const float* zy,
                              const int32_t* round, const int32_t* count, const EventPair* ev = nullptr);
+// ---- paged_kernels.hip: landmark maps as copy-on-write pages of kPageLandmarks landmarks (5 planes x 32 floats = 640 B)
+constexpr int kPageLandmarks = 32;
+struct PagedEkfArgs {
+    float* pool;             // [npages][5][32]
+    const int32_t* pt_in;    // [rows][nb] page tables of the ancestors
+    int32_t* pt_out;         // [n][nb]    page tables of this frame's particles
+    int nb;                  // pages per particle
+    const int32_t* anc;      // source table of particle i (nullptr: i)
+    int n, nlandmarks;
+    const float *x, *y, *th;
+    const float *obs_zx, *obs_zy;   // table form, NaN = not observed
+    float meas_var;
+    float* loglik;
+    float* loglik_user;
+    const int32_t *tpage, *tindex, *count;   // launch_page_list of the same table
+    const int32_t* freelist;                 // particle i takes entries pool_state[base] + [i * T, (i + 1) * T)
+    const int32_t* pool_state;               // written by launch_page_list of this frame
+    uint32_t* stamp;                         // [npages]: every page a new table names gets stamp_now
+    uint32_t stamp_now;
+};
+// pool_state (pool_state_words() int32 on the device): the free list's bookkeeping — how long it is, how much of it has
+// been handed out, whether launch_free_list (to be called behind this launcher every frame) has to make a new one first
+int pool_state_words();
+hipError_t launch_page_list(hipStream_t stream, const float* zx, const float* zy, int L, int nb, int32_t* tpage, int32_t* tindex,
+                            int32_t* count, int n, int32_t* pool_state);
+hipError_t launch_ekf_paged(hipStream_t stream, const PagedEkfArgs& a, const EventPair* ev = nullptr);
+hipError_t launch_page_table_gather(hipStream_t stream, const int32_t* pt_in, int32_t* pt_out, int nb, const int32_t* anc, int n);
+// free list = pages whose stamp differs from `live`, the stamp of the last update (in no particular order); does
+// nothing unless launch_page_list asked for it
+hipError_t launch_free_list(hipStream_t stream, const uint32_t* stamp, int npages, uint32_t live, int32_t* freelist,
+                            int32_t* pool_state);
+hipError_t launch_pages_from_rows(hipStream_t stream, const float* rows, int64_t row_stride, int plane_stride, int nlandmarks,
+                                  int nb, int n, float* pool, int32_t* pt, int32_t* freelist, int npages, int32_t* pool_state);
+hipError_t launch_rows_from_pages(hipStream_t stream, const float* pool, const int32_t* pt, int nb, const int32_t* anc, int n,
+                                  float* rows, int64_t row_stride, int plane_stride, int nlandmarks);
+hipError_t launch_pages_reset(hipStream_t stream, float* pool, int32_t* pt, int64_t nentries, int32_t* freelist, int npages,
+                              int32_t* pool_state);
+
 hipError_t launch_logweight(hipStream_t stream, const float* score, const float* loglik, float gain, int n,
                             float* logw, float* block_max_scratch, float* d_max, const float* carry = nullptr,
                             const int32_t* prev_resampled = nullptr);

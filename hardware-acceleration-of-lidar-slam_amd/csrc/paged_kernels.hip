@@ -1,0 +1,416 @@
+// paged_kernels.hip — landmark maps as copy-on-write PAGES (the K-observed frame).
+//
+// One row per particle (pf_kernels.hip) makes every resampling frame rewrite every row in full, because the fused gather
+// writes particle j's copy of its ancestor's row into the other buffer: 10 KB per particle at 500 landmarks, whether the
+// frame observed 500 landmarks or 5.  Here a particle's map is a PAGE TABLE: entry b names the page that holds landmarks
+// 32 b ... 32 b + 31 (5 planes x 32 floats = 640 bytes = five 128-byte lines).  Resampling copies page-table rows (4 bytes
+// per 32 landmarks); offspring of one ancestor SHARE its pages.  The update of a frame touches only the pages that hold an
+// observed landmark: it reads the ancestor's page, applies the update and writes the result to a FRESH page from the free
+// list (a shared page is never written), and names that page in the particle's new table.  Pages nobody names any more are
+// found once per frame: the update stamps every page the new tables name; the free list of the next frame is the list of
+// pages without this frame's stamp (a compaction: count, offsets, scatter).
+//
+// Arithmetic, its order and the log-likelihood summation order (landmark l adds to accumulator l mod 128 in order of l,
+// then j + (j + 64), then the xor butterfly) are those of ekf_batches in pf_kernels.hip: a paged and a row-per-particle
+// session give the same bits (tests/test_gpu_paged.py).
+// No counterpart in the reference (it has no particles or landmarks).
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "det_math.h"
+#include "kernels.h"
+
+namespace slam {
+
+namespace {
+
+constexpr int kPage = kPageLandmarks;          // landmarks per page
+constexpr int kPageFloats = 5 * kPage;         // floats per page: planes mu_x | mu_y | P_xx | P_xy | P_yy
+constexpr int kWaves = 4;                      // particles per workgroup
+// PoolState (device, kPoolStateWords int32): bookkeeping of the free list between frames, all of it on the device
+enum { kPoolFree = 0,    // entries in the free list
+       kPoolUsed = 1,    // ... of which handed out already
+       kPoolRenew = 2,   // this frame: the list is made anew before the update takes from it
+       kPoolBase = 3 };  // this frame: first entry the update takes
+
+__device__ __forceinline__ float wave_xor_tree_sum(float v)   // t[j] = t[j] + t[j ^ s], s = 1 .. 32: all lanes equal
+{
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) v = v + __shfl_xor(v, s, 64);
+    return v;
+}
+
+// The pages a frame touches: page b is touched when one of its landmarks has an observation (table form: NaN = none).
+// One workgroup, one landmark per thread and step: a page is a 32-lane half of a wavefront, "touched" a ballot.
+// tpage[0 .. T) ascending, tindex[b] = position of page b in tpage or -1, count[0] = T.
+__global__ __launch_bounds__(1024) void page_list_kernel(const float* __restrict__ zx, const float* __restrict__ zy, int L,
+                                                         int nb, int32_t* __restrict__ tpage, int32_t* __restrict__ tindex,
+                                                         int32_t* __restrict__ count, int n, int32_t* __restrict__ pool_state)
+{
+    __shared__ int s_wave[16];
+    __shared__ int s_base;
+    if (threadIdx.x == 0) s_base = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int l0 = 0; l0 < nb * kPage; l0 += 1024) {   // 32 pages per step, two per wavefront
+        const int l = l0 + (int)threadIdx.x;
+        bool ob = false;
+        if (l < L) {
+            const float vx = zx[l], vy = zy[l];
+            ob = vx == vx && vy == vy;
+        }
+        const unsigned long long m = __ballot(ob);
+        const int t_lo = (uint32_t)m != 0u ? 1 : 0, t_hi = (uint32_t)(m >> 32) != 0u ? 1 : 0;
+        if (lane == 0) s_wave[wave] = t_lo + t_hi;
+        __syncthreads();
+        int off = s_base;
+        for (int w = 0; w < wave; ++w) off += s_wave[w];
+        const int b = (l0 >> 5) + 2 * wave + (lane >> 5);
+        if ((lane & 31) == 0 && b < nb) {
+            const bool touched = lane ? t_hi : t_lo;
+            const int t = off + (lane ? t_lo : 0);
+            tindex[b] = touched ? t : -1;
+            if (touched) tpage[t] = b;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int tot = 0;
+            for (int w = 0; w < 16; ++w) tot += s_wave[w];
+            s_base += tot;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const int T = s_base;
+        count[0] = T;
+        // Where this frame's n * T fresh pages come from (PoolState): the part of the free list nobody has been given yet —
+        // or, when that is too short, a list made anew by free_list_kernel (launched behind this kernel, it looks at the
+        // flag), which always holds at least n * nb pages.
+        const int64_t want = (int64_t)n * T;
+        const bool renew = (int64_t)pool_state[kPoolUsed] + want > (int64_t)pool_state[kPoolFree];
+        pool_state[kPoolRenew] = renew ? 1 : 0;
+        if (renew) pool_state[kPoolFree] = 0;   // the list kernel adds its tiles' counts to it
+        const int first = renew ? 0 : pool_state[kPoolUsed];
+        pool_state[kPoolBase] = first;
+        pool_state[kPoolUsed] = first + (int)want;
+    }
+}
+
+// One wavefront = one particle.  (1) its new page-table row: the ancestor's entries, fresh pages for the touched ones,
+// every named page stamped; (2) the touched pages, two at a time (lanes 0-31 / 32-63 = the 32 landmarks of a page).
+__global__ __launch_bounds__(kWaves * 64) void ekf_paged_kernel(PagedEkfArgs a)
+{
+    __shared__ float s_acc[kWaves][128];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int i = blockIdx.x * kWaves + wave;
+    if (i >= a.n) return;
+    const int src = a.anc ? a.anc[i] : i;
+    const int T = __builtin_amdgcn_readfirstlane(a.count[0]);
+    const int32_t* __restrict__ row_in = a.pt_in + (int64_t)src * a.nb;
+    int32_t* __restrict__ row_out = a.pt_out + (int64_t)i * a.nb;
+    const int fbase = __builtin_amdgcn_readfirstlane(a.pool_state[kPoolBase]);
+    const int32_t* __restrict__ fresh = a.freelist + fbase + (int64_t)i * T;   // this particle's T fresh pages
+    for (int b = lane; b < a.nb; b += 64) {
+        const int t = a.tindex[b];
+        const int32_t page = t < 0 ? row_in[b] : fresh[t];
+        row_out[b] = page;
+        a.stamp[page] = a.stamp_now;   // named by a table of this frame (same value from every writer)
+    }
+    float st, ct;
+    det_sincosf(a.th[i], st, ct);
+    const float s = st, c = ct, px = a.x[i], py = a.y[i], q = a.meas_var;
+    s_acc[wave][lane] = 0.0f;
+    s_acc[wave][lane + 64] = 0.0f;
+    const int half = lane >> 5, slot = lane & 31;
+    struct Loaded {   // one pair of touched pages in flight: this lane's landmark of its page
+        float mx, my, pxx, pxy, pyy, zx, zy;
+        float* pout;
+        int k;        // log-likelihood accumulator of the landmark (l mod 128)
+        bool valid;
+    };
+    // page pairs whose loads are issued before the first is used: 1 (measured at 64k x 500, 32 observed: 91 us; 2: 106 us,
+    // 3: 114 us, 4: 139 us — 47 / 66 / 76 / 86 registers)
+    constexpr int kIter = 1;
+    for (int c0 = 0; c0 < T; c0 += 64) {   // 64 touched pages at a time: lane t holds what page c0 + t needs
+        const int tl = c0 + lane < T ? c0 + lane : T - 1;
+        const int my_b = a.tpage[tl];
+        const int my_old = row_in[my_b], my_new = fresh[tl];
+        const int tc = T - c0 < 64 ? T - c0 : 64;
+        auto load = [&](int t0) {
+            Loaded v;
+            const int t = t0 + half;
+            v.valid = t < tc;
+            const int tt = v.valid ? t : t0;
+            const int b = __shfl(my_b, tt, 64);
+            const int l = b * kPage + slot;
+            const float* __restrict__ pin = a.pool + (int64_t)__shfl(my_old, tt, 64) * kPageFloats + slot;
+            v.pout = a.pool + (int64_t)__shfl(my_new, tt, 64) * kPageFloats + slot;
+            v.mx = pin[0 * kPage];
+            v.my = pin[1 * kPage];
+            v.pxx = pin[2 * kPage];
+            v.pxy = pin[3 * kPage];
+            v.pyy = pin[4 * kPage];
+            const bool in = l < a.nlandmarks;
+            v.zx = in ? a.obs_zx[l] : __builtin_nanf("");
+            v.zy = in ? a.obs_zy[l] : __builtin_nanf("");
+            v.k = (b & 3) * kPage + slot;
+            return v;
+        };
+        auto apply = [&](const Loaded& v) {
+            const float mx = v.mx, my = v.my, pxx = v.pxx, pxy = v.pxy, pyy = v.pyy, zx = v.zx, zy = v.zy;
+            const bool ob = zx == zx && zy == zy;
+            // the arithmetic of ekf_batches (pf_kernels.hip), one landmark per lane
+            const float dx = mx - px, dy = my - py;
+            const float vx = zx - (c * dx - s * dy);
+            const float vy = zy - (s * dx + c * dy);
+            const float a00 = c * pxx - s * pxy, a01 = c * pxy - s * pyy;
+            const float a10 = s * pxx + c * pxy, a11 = s * pxy + c * pyy;
+            const float s00 = (a00 * c - a01 * s) + q;
+            const float s01 = a00 * s + a01 * c;
+            const float s11 = (a10 * s + a11 * c) + q;
+            const float det = s00 * s11 - s01 * s01;
+            const float idet = 1.0f / det;
+            const float i00 = s11 * idet, i01 = -s01 * idet, i11 = s00 * idet;
+            const float k00 = a00 * i00 + a10 * i01, k01 = a00 * i01 + a10 * i11;
+            const float k10 = a01 * i00 + a11 * i01, k11 = a01 * i01 + a11 * i11;
+            const float o0 = mx + (k00 * vx + k01 * vy);
+            const float o1 = my + (k10 * vx + k11 * vy);
+            const float o2 = pxx - (k00 * a00 + k01 * a10);
+            const float o3 = pxy - (k00 * a01 + k01 * a11);
+            const float o4 = pyy - (k10 * a01 + k11 * a11);
+            const float maha = vx * (i00 * vx + i01 * vy) + vy * (i01 * vx + i11 * vy);
+            const float ll = ((0.0f - 0.5f * maha) - 0.5f * det_logf(det)) - 1.8378770664f;
+            const float f0 = px + (c * zx + s * zy);   // first sighting: the observed point, P = R, no likelihood
+            const float f1 = py + (c * zy - s * zx);
+            const bool first = pxx < 0.0f;
+            float r0 = first ? f0 : o0, r1 = first ? f1 : o1, r2 = first ? q : o2, r3 = first ? 0.0f : o3, r4 = first ? q : o4;
+            const float term = first ? 0.0f : ll;
+            r0 = ob ? r0 : mx;
+            r1 = ob ? r1 : my;
+            r2 = ob ? r2 : pxx;
+            r3 = ob ? r3 : pxy;
+            r4 = ob ? r4 : pyy;
+            if (v.valid) {
+                v.pout[0 * kPage] = r0;
+                v.pout[1 * kPage] = r1;
+                v.pout[2 * kPage] = r2;
+                v.pout[3 * kPage] = r3;
+                v.pout[4 * kPage] = r4;
+            }
+            // accumulator l mod 128, in order of l: the lower page of the pair first (the two pages may share accumulators)
+            if (half == 0 && ob) s_acc[wave][v.k] = s_acc[wave][v.k] + term;
+            __builtin_amdgcn_wave_barrier();
+            if (half == 1 && v.valid && ob) s_acc[wave][v.k] = s_acc[wave][v.k] + term;
+            __builtin_amdgcn_wave_barrier();
+        };
+        for (int tb = 0; tb < tc; tb += 2 * kIter) {
+            Loaded v[kIter];
+#pragma unroll
+            for (int it = 0; it < kIter; ++it)
+                if (tb + 2 * it < tc) v[it] = load(tb + 2 * it);
+#pragma unroll
+            for (int it = 0; it < kIter; ++it)
+                if (tb + 2 * it < tc) apply(v[it]);
+        }
+    }
+    const float total = wave_xor_tree_sum(s_acc[wave][lane] + s_acc[wave][lane + 64]);
+    if (lane == 0) {
+        a.loglik[i] = total;
+        if (a.loglik_user) a.loglik_user[i] = total;
+    }
+}
+
+// A frame without observations: the tables follow their particles, nothing else moves.
+__global__ __launch_bounds__(256) void page_table_gather_kernel(const int32_t* __restrict__ pt_in, int32_t* __restrict__ pt_out,
+                                                                int nb, const int32_t* __restrict__ anc, int n)
+{
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)n * nb) return;
+    const int i = (int)(idx / nb), b = (int)(idx - (int64_t)i * nb);
+    pt_out[idx] = pt_in[(int64_t)(anc ? anc[i] : i) * nb + b];
+}
+
+// ---- free list = pages without the latest stamp (every update stamps every page its new tables name, so at any time the
+// pages in use are exactly those with the stamp of the last update).  Launched every frame behind page_list_kernel, it
+// does something only when that kernel asked for a new list (a few times per nb / T frames: a list holds >= n * nb pages
+// and a frame takes n * T).  A workgroup counts the free pages of its tile, claims that many slots of the list with ONE
+// atomic add and fills them (the order of the list does not matter: page numbers are internal, results do not depend on
+// them).
+constexpr int kFreeTile = 8192;
+
+__global__ __launch_bounds__(256) void free_list_kernel(const uint32_t* __restrict__ stamp, int npages, uint32_t live,
+                                                        int32_t* __restrict__ freelist, int32_t* __restrict__ pool_state)
+{
+    __shared__ int s_w[4];
+    __shared__ int s_base;
+    if (pool_state[kPoolRenew] == 0) return;
+    const int base = blockIdx.x * kFreeTile;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int kPer = kFreeTile / 256;   // consecutive pages per thread (strided, coalesced reads measured slower: 25 vs 20 us)
+    const int p0 = base + (int)threadIdx.x * kPer;
+    uint32_t freebits = 0;
+    int c = 0;
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+        const int p = p0 + k;
+        const bool fr = p < npages && stamp[p] != live;
+        freebits |= fr ? 1u << k : 0u;
+        c += fr ? 1 : 0;
+    }
+    int incl = c;   // inclusive scan of the counts over the wavefront, then over the four wavefronts
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += v;
+    }
+    if (lane == 63) s_w[wave] = incl;
+    __syncthreads();
+    int woff = 0, tot = 0;
+    for (int w = 0; w < 4; ++w) {
+        woff += w < wave ? s_w[w] : 0;
+        tot += s_w[w];
+    }
+    if (threadIdx.x == 0) s_base = tot ? atomicAdd(&pool_state[kPoolFree], tot) : 0;
+    __syncthreads();
+    int out = s_base + woff + incl - c;
+#pragma unroll
+    for (int k = 0; k < kPer; ++k)
+        if (freebits >> k & 1u) freelist[out++] = p0 + k;
+}
+
+// ---- rows <-> pages (set / get of whole maps; not on the frame path)
+// rows [n][5][plane_stride] -> pages j * nb + b (the identity table)
+__global__ __launch_bounds__(256) void pages_from_rows_kernel(const float* __restrict__ rows, int64_t row_stride, int plane_stride,
+                                                              int nlandmarks, int nb, int n, float* __restrict__ pool,
+                                                              int32_t* __restrict__ pt)
+{
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;   // one thread per (particle, page, slot)
+    if (idx >= (int64_t)n * nb * kPage) return;
+    const int slot = (int)(idx % kPage);
+    const int64_t pb = idx / kPage;
+    const int b = (int)(pb % nb), i = (int)(pb / nb);
+    const int l = b * kPage + slot;
+    const float* r = rows + (int64_t)i * row_stride;
+    float* pg = pool + pb * kPageFloats + slot;
+#pragma unroll
+    for (int p = 0; p < 5; ++p) pg[p * kPage] = l < nlandmarks ? r[(int64_t)p * plane_stride + l] : (p == 2 ? -1.0f : 0.0f);
+    if (slot == 0) pt[pb] = (int32_t)pb;
+}
+
+// pages of particle anc[i] (or i) -> row i
+__global__ __launch_bounds__(256) void rows_from_pages_kernel(const float* __restrict__ pool, const int32_t* __restrict__ pt,
+                                                              int nb, const int32_t* __restrict__ anc, int n,
+                                                              float* __restrict__ rows, int64_t row_stride, int plane_stride,
+                                                              int nlandmarks)
+{
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)n * nb * kPage) return;
+    const int slot = (int)(idx % kPage);
+    const int64_t pb = idx / kPage;
+    const int b = (int)(pb % nb), i = (int)(pb / nb);
+    const int l = b * kPage + slot;
+    if (l >= nlandmarks) return;
+    const int src = anc ? anc[i] : i;
+    const float* pg = pool + (int64_t)pt[(int64_t)src * nb + b] * kPageFloats + slot;
+    float* r = rows + (int64_t)i * row_stride;
+#pragma unroll
+    for (int p = 0; p < 5; ++p) r[(int64_t)p * plane_stride + l] = pg[p * kPage];
+}
+
+// every particle starts on ONE shared page of landmarks "not seen yet" (page 0), the rest of the pool is free
+__global__ __launch_bounds__(256) void pages_reset_kernel(float* __restrict__ pool, int32_t* __restrict__ pt, int64_t nentries,
+                                                          int32_t* __restrict__ freelist, int npages,
+                                                          int32_t* __restrict__ pool_state)
+{
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx < kPageFloats) pool[idx] = (idx / kPage == 2) ? -1.0f : 0.0f;
+    if (idx < nentries) pt[idx] = 0;
+    if (idx < npages - 1) freelist[idx] = (int32_t)idx + 1;
+    if (idx == 0) {
+        pool_state[kPoolFree] = npages - 1;
+        pool_state[kPoolUsed] = 0;
+        pool_state[kPoolRenew] = 0;
+        pool_state[kPoolBase] = 0;
+    }
+}
+
+// free list = pages first .. first + count - 1, nothing handed out
+__global__ __launch_bounds__(256) void free_iota_kernel(int32_t* __restrict__ out, int first, int count,
+                                                        int32_t* __restrict__ pool_state)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx < count) out[idx] = first + idx;
+    if (idx == 0) {
+        pool_state[kPoolFree] = count;
+        pool_state[kPoolUsed] = 0;
+        pool_state[kPoolRenew] = 0;
+        pool_state[kPoolBase] = 0;
+    }
+}
+
+inline int blocks256(int64_t n) { return (int)((n + 255) / 256); }
+
+}  // namespace
+
+hipError_t launch_page_list(hipStream_t stream, const float* zx, const float* zy, int L, int nb, int32_t* tpage, int32_t* tindex,
+                            int32_t* count, int n, int32_t* pool_state)
+{
+    page_list_kernel<<<1, 1024, 0, stream>>>(zx, zy, L, nb, tpage, tindex, count, n, pool_state);
+    return hipGetLastError();
+}
+
+hipError_t launch_ekf_paged(hipStream_t stream, const PagedEkfArgs& a, const EventPair* ev)
+{
+    if (a.n <= 0) return hipSuccess;
+    if (ev) (void)hipEventRecord(ev->start, stream);
+    ekf_paged_kernel<<<(a.n + kWaves - 1) / kWaves, kWaves * 64, 0, stream>>>(a);
+    if (ev) (void)hipEventRecord(ev->stop, stream);
+    return hipGetLastError();
+}
+
+hipError_t launch_page_table_gather(hipStream_t stream, const int32_t* pt_in, int32_t* pt_out, int nb, const int32_t* anc, int n)
+{
+    if (n <= 0 || nb <= 0) return hipSuccess;
+    page_table_gather_kernel<<<blocks256((int64_t)n * nb), 256, 0, stream>>>(pt_in, pt_out, nb, anc, n);
+    return hipGetLastError();
+}
+
+int pool_state_words() { return 4; }
+
+hipError_t launch_free_list(hipStream_t stream, const uint32_t* stamp, int npages, uint32_t live, int32_t* freelist,
+                            int32_t* pool_state)
+{
+    free_list_kernel<<<(npages + kFreeTile - 1) / kFreeTile, 256, 0, stream>>>(stamp, npages, live, freelist, pool_state);
+    return hipGetLastError();
+}
+
+hipError_t launch_pages_from_rows(hipStream_t stream, const float* rows, int64_t row_stride, int plane_stride, int nlandmarks,
+                                  int nb, int n, float* pool, int32_t* pt, int32_t* freelist, int npages, int32_t* pool_state)
+{
+    pages_from_rows_kernel<<<blocks256((int64_t)n * nb * kPage), 256, 0, stream>>>(rows, row_stride, plane_stride, nlandmarks, nb, n,
+                                                                                  pool, pt);
+    const int used = n * nb;   // the identity table names pages 0 .. n * nb - 1: the rest is free
+    free_iota_kernel<<<blocks256(npages > used ? npages - used : 1), 256, 0, stream>>>(freelist, used, npages - used, pool_state);
+    return hipGetLastError();
+}
+
+hipError_t launch_rows_from_pages(hipStream_t stream, const float* pool, const int32_t* pt, int nb, const int32_t* anc, int n,
+                                  float* rows, int64_t row_stride, int plane_stride, int nlandmarks)
+{
+    rows_from_pages_kernel<<<blocks256((int64_t)n * nb * kPage), 256, 0, stream>>>(pool, pt, nb, anc, n, rows, row_stride,
+                                                                                  plane_stride, nlandmarks);
+    return hipGetLastError();
+}
+
+hipError_t launch_pages_reset(hipStream_t stream, float* pool, int32_t* pt, int64_t nentries, int32_t* freelist, int npages,
+                              int32_t* pool_state)
+{
+    const int64_t m = nentries > npages ? nentries : npages;
+    pages_reset_kernel<<<blocks256(m > kPageFloats ? m : kPageFloats), 256, 0, stream>>>(pool, pt, nentries, freelist, npages,
+                                                                                     pool_state);
+    return hipGetLastError();
+}
+
+}  // namespace slam

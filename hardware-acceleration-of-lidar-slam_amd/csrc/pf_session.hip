@@ -58,6 +58,17 @@ struct slam_pf {
     float* res_dev = nullptr;       // device copy of the payload (what the ranks all-gather)
     unsigned long long* sums_acc = nullptr;   // 4 accumulators + ticket of pose_sums_kernel (kept zeroed by the kernel)
     void* res_all = nullptr;        // [world] payloads
+    // ---- paged maps (slam_pf_paged_set before the session is made; one GPU): copy-on-write pages behind a page table
+    // per particle instead of one row per particle (paged_kernels.hip); map[] stays unallocated
+    bool paged = false;
+    int nb = 0, npages = 0;         // pages per particle; pages in the pool (2 * n * nb: never fewer than n * nb are free)
+    float* pool = nullptr;          // [npages][5][32]
+    int32_t* pt[2] = { nullptr, nullptr };   // [n][nb] page tables, current and next
+    int pt_cur = 0;
+    int32_t* freelist = nullptr;    // [npages] ascending free pages as of the last update
+    uint32_t* stamp = nullptr;      // [npages] frame stamp of the last table that named the page
+    uint32_t stamp_now = 0;
+    int32_t* page_scratch = nullptr;   // tpage[nb] | tindex[nb] | count | the free list's bookkeeping (pool_state_words())
     bool gated = false;             // cfg.resample_ess_frac in (0, 1): a frame resamples only when its ESS is low
     int64_t frames_resampled = 0;   // (as far as the host has looked: one frame behind)
 };
@@ -194,10 +205,27 @@ int create_common(slam_engine* e, const slam_pf_config* cfg, slam_comm* comm, in
     }
     const size_t n = (size_t)pf->n, L = (size_t)pf->L, Lp = (size_t)pf->Lp, cap = (size_t)pf->cap, G = (size_t)pf->world;
     bool ok = true;
+    pf->paged = e->pf_paged && !comm && pf->L > 0;
+    if (pf->paged) {
+        pf->nb = pf->Lp / kPageLandmarks;
+        const int64_t np = 2 * (int64_t)pf->n * pf->nb;
+        if (np > 0x7fffffff) {
+            delete pf;
+            return SLAM_ERR_CAPACITY;
+        }
+        pf->npages = (int)np;
+        const size_t P = (size_t)pf->npages;
+        ok = dev_alloc((void**)&pf->pool, P * 5 * kPageLandmarks * 4) == hipSuccess &&
+             dev_alloc((void**)&pf->freelist, P * 4) == hipSuccess && dev_alloc((void**)&pf->stamp, P * 4) == hipSuccess &&
+             hipMemset(pf->stamp, 0, P * 4) == hipSuccess &&
+             dev_alloc((void**)&pf->page_scratch, (2 * (size_t)pf->nb + 1 + (size_t)pool_state_words()) * 4) == hipSuccess &&
+             hipMemset(pf->page_scratch, 0, (2 * (size_t)pf->nb + 1 + (size_t)pool_state_words()) * 4) == hipSuccess;
+    }
     for (int b = 0; b < 2; ++b) {
         ok = ok && dev_alloc((void**)&pf->pose[b], 3 * n * 4) == hipSuccess;
         ok = ok && dev_alloc((void**)&pf->anc[b], n * 4) == hipSuccess;
-        if (L) ok = ok && dev_alloc((void**)&pf->map[b], 5 * Lp * cap * 4) == hipSuccess;
+        if (L && !pf->paged) ok = ok && dev_alloc((void**)&pf->map[b], 5 * Lp * cap * 4) == hipSuccess;
+        if (pf->paged) ok = ok && dev_alloc((void**)&pf->pt[b], n * (size_t)pf->nb * 4) == hipSuccess;
         if (comm) ok = ok && dev_alloc((void**)&pf->pose_idx[b], n * 4) == hipSuccess;
     }
     ok = ok && dev_alloc((void**)&pf->score, n * 4) == hipSuccess && dev_alloc((void**)&pf->logw, n * 4) == hipSuccess &&
@@ -273,6 +301,9 @@ int slam_pf_destroy(slam_pf* pf)
                      (void*)pf->d_max, (void*)pf->d_sum, (void*)pf->totals, (void*)pf->d_plan, (void*)pf->sbuf,
                      (void*)pf->rbuf, (void*)pf->res_dev, (void*)pf->sums_acc, pf->res_all })
         (void)hipFree(p);
+    for (void* p : { (void*)pf->pool, (void*)pf->pt[0], (void*)pf->pt[1], (void*)pf->freelist, (void*)pf->stamp,
+                     (void*)pf->page_scratch })
+        (void)hipFree(p);
     if (pf->h_res) (void)hipHostFree(pf->h_res);
     delete pf;
     return SLAM_OK;
@@ -288,7 +319,11 @@ int slam_pf_reset(slam_pf* pf, const float pose[3])
     if (int rc = drop_resample(pf)) return rc;
     if (int rc = slam_engine_sync(pf->e)) return rc;
     if (hipMemcpy(pf->pose[pf->cur], h.data(), 3 * n * 4, hipMemcpyHostToDevice) != hipSuccess) return SLAM_ERR_HIP;
-    if (pf->L) {   // P_xx = -1: "not seen yet"
+    if (pf->paged) {   // every particle names ONE shared page of landmarks not seen yet
+        SLAM_HIP_TRY(pf->e, launch_pages_reset(pf->e->stream, pf->pool, pf->pt[pf->pt_cur], (int64_t)pf->n * pf->nb, pf->freelist,
+                                               pf->npages, pf->page_scratch + 2 * pf->nb + 1));
+        if (int rc = slam_engine_sync(pf->e)) return rc;
+    } else if (pf->L) {   // P_xx = -1: "not seen yet"
         const size_t Lp = (size_t)pf->Lp;
         std::vector<float> row(5 * Lp, 0.0f);
         for (size_t l = 0; l < Lp; ++l) row[2 * Lp + l] = -1.0f;
@@ -326,11 +361,37 @@ int slam_pf_set_map_host(slam_pf* pf, const float* rows)
     if (int rc = slam_engine_sync(pf->e)) return rc;
     if (pf->has_anc) return SLAM_ERR_NOT_READY;   // set poses / reset first: a gather is pending
     // host [n][5][L] -> device [n][5][Lp]: 5n planes of L floats each
-    if (hipMemcpy2D(pf->map[pf->map_cur], (size_t)pf->Lp * 4, rows, (size_t)pf->L * 4, (size_t)pf->L * 4,
-                    5 * (size_t)pf->n, hipMemcpyHostToDevice) != hipSuccess)
-        return SLAM_ERR_HIP;
+    float* dense = pf->paged ? nullptr : pf->map[pf->map_cur];
+    if (pf->paged && hipMalloc((void**)&dense, 5 * (size_t)pf->Lp * pf->n * 4) != hipSuccess) return SLAM_ERR_HIP;
+    int rc = SLAM_OK;
+    if (hipMemcpy2D(dense, (size_t)pf->Lp * 4, rows, (size_t)pf->L * 4, (size_t)pf->L * 4, 5 * (size_t)pf->n,
+                    hipMemcpyHostToDevice) != hipSuccess)
+        rc = SLAM_ERR_HIP;
+    if (pf->paged) {
+        if (rc == SLAM_OK) rc = slam_pf_set_map_dev(pf, dense, 5 * (int64_t)pf->Lp, pf->Lp);
+        if (rc == SLAM_OK) rc = slam_engine_sync(pf->e);
+        (void)hipFree(dense);
+    }
+    return rc;
+}
+
+int slam_pf_set_map_dev(slam_pf* pf, const float* d_rows, int64_t row_stride, int plane_stride)
+{
+    if (!pf || !d_rows || !pf->L || plane_stride < pf->L || row_stride < 5 * (int64_t)plane_stride) return SLAM_ERR_INVALID_ARG;
+    if (pf->has_anc) return SLAM_ERR_NOT_READY;   // set poses / reset first: a gather is pending
+    slam_engine* e = pf->e;
+    SLAM_HIP_TRY(e, hipSetDevice(e->device));
+    if (pf->paged) {
+        SLAM_HIP_TRY(e, launch_pages_from_rows(e->stream, d_rows, row_stride, plane_stride, pf->L, pf->nb, pf->n, pf->pool,
+                                               pf->pt[pf->pt_cur], pf->freelist, pf->npages, pf->page_scratch + 2 * pf->nb + 1));
+        return SLAM_OK;
+    }
+    SLAM_HIP_TRY(e, hipMemcpy2DAsync(pf->map[pf->map_cur], (size_t)pf->Lp * 4, d_rows, (size_t)plane_stride * 4, (size_t)pf->L * 4,
+                                     5 * (size_t)pf->n, hipMemcpyDeviceToDevice, e->stream));
     return SLAM_OK;
 }
+
+int slam_pf_is_paged(const slam_pf* pf) { return pf && pf->paged ? 1 : 0; }
 
 int slam_pf_step(slam_pf* pf, int slot, const float dp[3], int use_observations)
 {
@@ -375,7 +436,51 @@ int slam_pf_step(slam_pf* pf, int slot, const float dp[3], int use_observations)
     const bool ekf = L > 0 && use_observations;
     const int mc = pf->map_cur, mn = 1 - mc;
     float* d_max = comm ? pf->d_max : nullptr;
-    if (ekf && in_place) {
+    if (pf->paged) {
+        const int pc = pf->pt_cur;
+        if (ekf) {
+            // touched pages of this frame's observation table, the update into fresh pages, the next frame's free list
+            if (e->obs_nlandmarks != L) return SLAM_ERR_NOT_READY;
+            SLAM_HIP_TRY(e, e->ll_buf.ensure(sizeof(float) * sn));
+            int32_t *tpage = pf->page_scratch, *tindex = tpage + pf->nb, *count = tindex + pf->nb, *pstate = count + 1;
+            SLAM_HIP_TRY(e, launch_page_list(e->stream, e->d_obs_zx, e->d_obs_zy, L, pf->nb, tpage, tindex, count, n, pstate));
+            // a new free list when the old one runs short (decided on the device; the pages in use carry the last stamp)
+            SLAM_HIP_TRY(e, launch_free_list(e->stream, pf->stamp, pf->npages, pf->stamp_now, pf->freelist, pstate));
+            PagedEkfArgs a;
+            a.pool = pf->pool;
+            a.pt_in = pf->pt[pc];
+            a.pt_out = pf->pt[1 - pc];
+            a.nb = pf->nb;
+            a.anc = anc;
+            a.n = n;
+            a.nlandmarks = L;
+            a.x = dst;
+            a.y = dst + sn;
+            a.th = dst + 2 * sn;
+            a.obs_zx = e->d_obs_zx;
+            a.obs_zy = e->d_obs_zy;
+            a.meas_var = pf->cfg.meas_var;
+            a.loglik = e->ll_buf.as<float>();
+            a.loglik_user = nullptr;
+            a.tpage = tpage;
+            a.tindex = tindex;
+            a.count = count;
+            a.freelist = pf->freelist;
+            a.pool_state = pstate;
+            a.stamp = pf->stamp;
+            a.stamp_now = ++pf->stamp_now;
+            SLAM_HIP_TRY(e, launch_ekf_paged(e->stream, a, e->prof_next(SLAM_PROF_EKF)));
+            e->ll_n = n;
+            pf->pt_cur = 1 - pc;
+            rc = slam_logweight_ekf_dev(e, pf->score, pf->cfg.score_gain, n, pf->logw, d_max);
+        } else {
+            if (anc) {   // the tables follow their particles
+                SLAM_HIP_TRY(e, launch_page_table_gather(e->stream, pf->pt[pc], pf->pt[1 - pc], pf->nb, anc, n));
+                pf->pt_cur = 1 - pc;
+            }
+            rc = slam_logweight_dev(e, pf->score, nullptr, pf->cfg.score_gain, n, pf->logw, d_max);
+        }
+    } else if (ekf && in_place) {
         rc = slam_ekf_update_dev(e, pf->map[mc], pf->map[mc], 5 * (int64_t)pf->Lp, pf->Lp, L, dst, dst + sn, dst + 2 * sn, nullptr, n,
                                  pf->cfg.meas_var, nullptr);
         if (rc != SLAM_OK) return rc;
@@ -434,8 +539,8 @@ int slam_pf_device_view(slam_pf* pf, slam_pf_view* out)
 {
     if (!pf || !out) return SLAM_ERR_INVALID_ARG;
     out->pose = pf->pose[pf->cur];
-    out->map = pf->L ? pf->map[pf->map_cur] : nullptr;
-    out->map_spare = pf->L ? pf->map[1 - pf->map_cur] : nullptr;
+    out->map = pf->L && !pf->paged ? pf->map[pf->map_cur] : nullptr;   // paged maps have no rows to look at: slam_pf_set_map_dev
+    out->map_spare = pf->L && !pf->paged ? pf->map[1 - pf->map_cur] : nullptr;
     out->anc = pf->has_anc ? pf->anc[pf->cur] : nullptr;
     out->row_stride = 5 * (int64_t)pf->Lp;
     out->plane_stride = pf->Lp;
@@ -543,6 +648,19 @@ int slam_pf_get_map_host(slam_pf* pf, float* rows)
     const size_t n = (size_t)pf->n, L = (size_t)pf->L, Lp = (size_t)pf->Lp;
     if (pf->comm)
         if (int rc = finish_exchange(pf)) return rc;   // collective: remote ancestors' rows into the staging tail
+    if (pf->paged) {   // pages -> rows in a scratch buffer (the pending gather applied on the way), then the copy
+        float* dense = nullptr;
+        if (hipMalloc((void**)&dense, 5 * Lp * n * 4) != hipSuccess) return SLAM_ERR_HIP;
+        int rc = SLAM_OK;
+        if (launch_rows_from_pages(pf->e->stream, pf->pool, pf->pt[pf->pt_cur], pf->nb, pf->has_anc ? pf->anc[pf->cur] : nullptr,
+                                   pf->n, dense, 5 * (int64_t)Lp, pf->Lp, pf->L) != hipSuccess)
+            rc = SLAM_ERR_HIP;
+        if (rc == SLAM_OK) rc = slam_engine_sync(pf->e);
+        if (rc == SLAM_OK && hipMemcpy2D(rows, L * 4, dense, Lp * 4, L * 4, 5 * n, hipMemcpyDeviceToHost) != hipSuccess)
+            rc = SLAM_ERR_HIP;
+        (void)hipFree(dense);
+        return rc;
+    }
     const float* src = pf->map[pf->map_cur];
     if (pf->has_anc) {
         int rc = slam_gather_map_dev(pf->e, pf->map[pf->map_cur], pf->map[1 - pf->map_cur], 5 * (int64_t)Lp,

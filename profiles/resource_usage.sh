@@ -2,7 +2,7 @@
 # profiles/resource_usage.sh > profiles/TAG_resource_usage.txt — registers, LDS, scratch and occupancy of every kernel
 # (hipcc -Rpass-analysis=kernel-resource-usage, names demangled); needs no GPU.
 cd "$(dirname "$0")/../hardware-acceleration-of-lidar-slam_amd/csrc"
-for f in score_kernels edt_kernels pf_kernels mapper_kernels; do
+for f in score_kernels edt_kernels pf_kernels paged_kernels mapper_kernels; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math \
       -Rpass-analysis=kernel-resource-usage -c -o /dev/null $f.hip 2>&1 | grep -E "Function Name|VGPRs:|SGPRs:|Occupancy|LDS Size|ScratchSize"
 done | python3 -c "

@@ -27,7 +27,7 @@ def _bench():
     return mod
 
 
-def _run(ess, n=8192, L=60, frames=40, grid=1024, beams=360):
+def _run(ess, paged=False, n=8192, L=60, frames=40, grid=1024, beams=360):
     B = _bench()
     pkg = load_package()
     dev = torch.device("cuda", 0)
@@ -38,6 +38,7 @@ def _run(ess, n=8192, L=60, frames=40, grid=1024, beams=360):
     occ = B.occupancy(grid, float(pixel), float(min_x), float(min_y))
     fr = B.make_frames(frames, beams, lm, rng)
     eng = pkg.Engine(0)
+    eng.pf_paged_set(paged)
     d_occ = torch.from_numpy(occ).to(dev)
     d_edt = torch.empty((grid, grid), dtype=torch.float32, device=dev)
     torch.cuda.synchronize()
@@ -67,9 +68,9 @@ def _run(ess, n=8192, L=60, frames=40, grid=1024, beams=360):
                 pyy=maps[:, 4, :].mean(axis=0), resampled=resampled, frames=frames)
 
 
-@pytest.mark.parametrize("ess", [0.0, 0.1])
-def test_filter_keeps_the_pose_and_learns_the_landmarks(ess):
-    r = _run(ess)
+@pytest.mark.parametrize("ess,paged", [(0.0, False), (0.1, False), (0.0, True)])
+def test_filter_keeps_the_pose_and_learns_the_landmarks(ess, paged):
+    r = _run(ess, paged)
     print(f"ess={ess}: pose error last 10 frames max {r['err_xy'][-10:].max():.4f} m / {r['err_th'][-10:].max():.5f} rad, "
           f"over all frames {r['err_xy'].max():.4f} m; landmark error mean {r['lm_err'].mean():.4f} max {r['lm_err'].max():.4f} m; "
           f"P_xx mean {r['pxx'].mean():.2e}; frames resampled {r['resampled']} of {r['frames']}")
