@@ -647,7 +647,10 @@ def main():
                      "note": ("in a running filter the rows of repeated resample ancestors are re-read from L2: "
                               "`logical_rate_gbs` (SURVEY 8d's 40 B per particle and observed landmark / launch time) is then "
                               "not an HBM rate; `achieved` is, see `achieved_basis`; `no_reuse` is the kernel streaming "
-                              "every row from HBM" if kern.startswith("ekf") else
+                              "every row from HBM" if kern.startswith("ekf_update") else
+                              "paged maps: the update reads the touched pages of the ancestors (shared pages out of L2) and writes "
+                              "fresh pages; `logical_rate_gbs` is SURVEY 8d's 40 B per particle and observed landmark / launch time"
+                              if kern.startswith("ekf") else
                               "EDT gathers are served by L2 / Infinity Cache: logical-byte rate, not HBM traffic"),
                      "avg_launch_ms": dur_ms, "avg_event_bracket_ms": raw_ms,
                      "event_bracket_overhead_ms": bracket_overhead_ms,
