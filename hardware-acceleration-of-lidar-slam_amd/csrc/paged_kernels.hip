@@ -34,13 +34,6 @@ enum { kPoolFree = 0,    // entries in the free list
        kPoolRenew = 2,   // this frame: the list is made anew before the update takes from it
        kPoolBase = 3 };  // this frame: first entry the update takes
 
-__device__ __forceinline__ float wave_xor_tree_sum(float v)   // t[j] = t[j] + t[j ^ s], s = 1 .. 32: all lanes equal
-{
-#pragma unroll
-    for (int s = 1; s < 64; s <<= 1) v = v + __shfl_xor(v, s, 64);
-    return v;
-}
-
 // The pages a frame touches: page b is touched when one of its landmarks has an observation (table form: NaN = none).
 // One workgroup, one landmark per thread and step: a page is a 32-lane half of a wavefront, "touched" a ballot.
 // tpage[0 .. T) ascending, tindex[b] = position of page b in tpage or -1, count[0] = T.
@@ -97,69 +90,55 @@ __global__ __launch_bounds__(1024) void page_list_kernel(const float* __restrict
     }
 }
 
-// One wavefront = one particle.  (1) its new page-table row: the ancestor's entries, fresh pages for the touched ones,
-// every named page stamped; (2) the touched pages, two at a time (lanes 0-31 / 32-63 = the 32 landmarks of a page).
+// HALF a wavefront = one particle (32 lanes = the 32 landmarks of a page).  (1) its new page-table row: the ancestor's
+// entries, fresh pages for the touched ones, every named page stamped; (2) the touched pages one after the other.  A
+// particle's work is a handful of dependent round trips (ancestor -> table -> page -> store) and little else, so the
+// kernel's time is the number of wavefronts times those round trips: two particles per wavefront halve it (one particle
+// per wavefront, two pages per pass: 91 us at 64k x 500 with 32 observed).
 __global__ __launch_bounds__(kWaves * 64) void ekf_paged_kernel(PagedEkfArgs a)
 {
-    __shared__ float s_acc[kWaves][128];
+    __shared__ float s_acc[kWaves][2][128];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int i = blockIdx.x * kWaves + wave;
-    if (i >= a.n) return;
+    const int half = lane >> 5, slot = lane & 31;
+    const int first_of_wave = ((int)blockIdx.x * kWaves + wave) << 1;
+    const int i_raw = first_of_wave + half;
+    if (first_of_wave >= a.n) return;
+    const bool alive = i_raw < a.n;            // the upper half of the last wavefront may have no particle: it stores nothing
+    const int i = alive ? i_raw : a.n - 1;
     const int src = a.anc ? a.anc[i] : i;
     const int T = __builtin_amdgcn_readfirstlane(a.count[0]);
     const int32_t* __restrict__ row_in = a.pt_in + (int64_t)src * a.nb;
     int32_t* __restrict__ row_out = a.pt_out + (int64_t)i * a.nb;
     const int fbase = __builtin_amdgcn_readfirstlane(a.pool_state[kPoolBase]);
     const int32_t* __restrict__ fresh = a.freelist + fbase + (int64_t)i * T;   // this particle's T fresh pages
-    for (int b = lane; b < a.nb; b += 64) {
-        const int t = a.tindex[b];
-        const int32_t page = t < 0 ? row_in[b] : fresh[t];
-        row_out[b] = page;
-        a.stamp[page] = a.stamp_now;   // named by a table of this frame (same value from every writer)
-    }
+    if (alive)
+        for (int b = slot; b < a.nb; b += 32) {
+            const int t = a.tindex[b];
+            const int32_t page = t < 0 ? row_in[b] : fresh[t];
+            row_out[b] = page;
+            a.stamp[page] = a.stamp_now;   // named by a table of this frame (same value from every writer)
+        }
     float st, ct;
     det_sincosf(a.th[i], st, ct);
     const float s = st, c = ct, px = a.x[i], py = a.y[i], q = a.meas_var;
-    s_acc[wave][lane] = 0.0f;
-    s_acc[wave][lane + 64] = 0.0f;
-    const int half = lane >> 5, slot = lane & 31;
-    struct Loaded {   // one pair of touched pages in flight: this lane's landmark of its page
-        float mx, my, pxx, pxy, pyy, zx, zy;
-        float* pout;
-        int k;        // log-likelihood accumulator of the landmark (l mod 128)
-        bool valid;
-    };
-    // page pairs whose loads are issued before the first is used: 1 (measured at 64k x 500, 32 observed: 91 us; 2: 106 us,
-    // 3: 114 us, 4: 139 us — 47 / 66 / 76 / 86 registers)
-    constexpr int kIter = 1;
-    for (int c0 = 0; c0 < T; c0 += 64) {   // 64 touched pages at a time: lane t holds what page c0 + t needs
-        const int tl = c0 + lane < T ? c0 + lane : T - 1;
+    float* acc = s_acc[wave][half];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[slot + 32 * k] = 0.0f;
+    for (int c0 = 0; c0 < T; c0 += 32) {   // 32 touched pages at a time: lane t of the half holds what page c0 + t needs
+        const int tl = c0 + slot < T ? c0 + slot : T - 1;
         const int my_b = a.tpage[tl];
         const int my_old = row_in[my_b], my_new = fresh[tl];
-        const int tc = T - c0 < 64 ? T - c0 : 64;
-        auto load = [&](int t0) {
-            Loaded v;
-            const int t = t0 + half;
-            v.valid = t < tc;
-            const int tt = v.valid ? t : t0;
-            const int b = __shfl(my_b, tt, 64);
+        const int tc = T - c0 < 32 ? T - c0 : 32;
+        for (int t = 0; t < tc; ++t) {
+            const int from = (half << 5) + t;
+            const int b = __shfl(my_b, from, 64);
             const int l = b * kPage + slot;
-            const float* __restrict__ pin = a.pool + (int64_t)__shfl(my_old, tt, 64) * kPageFloats + slot;
-            v.pout = a.pool + (int64_t)__shfl(my_new, tt, 64) * kPageFloats + slot;
-            v.mx = pin[0 * kPage];
-            v.my = pin[1 * kPage];
-            v.pxx = pin[2 * kPage];
-            v.pxy = pin[3 * kPage];
-            v.pyy = pin[4 * kPage];
+            const float* __restrict__ pin = a.pool + (int64_t)__shfl(my_old, from, 64) * kPageFloats + slot;
+            float* __restrict__ pout = a.pool + (int64_t)__shfl(my_new, from, 64) * kPageFloats + slot;
+            const float mx = pin[0 * kPage], my = pin[1 * kPage], pxx = pin[2 * kPage], pxy = pin[3 * kPage], pyy = pin[4 * kPage];
             const bool in = l < a.nlandmarks;
-            v.zx = in ? a.obs_zx[l] : __builtin_nanf("");
-            v.zy = in ? a.obs_zy[l] : __builtin_nanf("");
-            v.k = (b & 3) * kPage + slot;
-            return v;
-        };
-        auto apply = [&](const Loaded& v) {
-            const float mx = v.mx, my = v.my, pxx = v.pxx, pxy = v.pxy, pyy = v.pyy, zx = v.zx, zy = v.zy;
+            const float zx = in ? a.obs_zx[l] : __builtin_nanf(""), zy = in ? a.obs_zy[l] : __builtin_nanf("");
             const bool ob = zx == zx && zy == zy;
             // the arithmetic of ekf_batches (pf_kernels.hip), one landmark per lane
             const float dx = mx - px, dy = my - py;
@@ -192,31 +171,28 @@ __global__ __launch_bounds__(kWaves * 64) void ekf_paged_kernel(PagedEkfArgs a)
             r2 = ob ? r2 : pxx;
             r3 = ob ? r3 : pxy;
             r4 = ob ? r4 : pyy;
-            if (v.valid) {
-                v.pout[0 * kPage] = r0;
-                v.pout[1 * kPage] = r1;
-                v.pout[2 * kPage] = r2;
-                v.pout[3 * kPage] = r3;
-                v.pout[4 * kPage] = r4;
+            if (alive) {
+                pout[0 * kPage] = r0;
+                pout[1 * kPage] = r1;
+                pout[2 * kPage] = r2;
+                pout[3 * kPage] = r3;
+                pout[4 * kPage] = r4;
             }
-            // accumulator l mod 128, in order of l: the lower page of the pair first (the two pages may share accumulators)
-            if (half == 0 && ob) s_acc[wave][v.k] = s_acc[wave][v.k] + term;
-            __builtin_amdgcn_wave_barrier();
-            if (half == 1 && v.valid && ob) s_acc[wave][v.k] = s_acc[wave][v.k] + term;
-            __builtin_amdgcn_wave_barrier();
-        };
-        for (int tb = 0; tb < tc; tb += 2 * kIter) {
-            Loaded v[kIter];
-#pragma unroll
-            for (int it = 0; it < kIter; ++it)
-                if (tb + 2 * it < tc) v[it] = load(tb + 2 * it);
-#pragma unroll
-            for (int it = 0; it < kIter; ++it)
-                if (tb + 2 * it < tc) apply(v[it]);
+            // accumulator l mod 128, in order of l: a particle's pages come one per pass, in ascending order
+            const int k = (b & 3) * kPage + slot;
+            if (ob) acc[k] = acc[k] + term;
         }
     }
-    const float total = wave_xor_tree_sum(s_acc[wave][lane] + s_acc[wave][lane + 64]);
-    if (lane == 0) {
+    // the specification's reduction — t[j] = acc[j] + acc[j + 64], then t[j] += t[j ^ s] for s = 1 .. 32 — on 32 lanes: a
+    // lane holds t[slot] and t[slot + 32]; the steps s <= 16 stay inside each, the last one adds the two
+    float u0 = acc[slot] + acc[slot + 64], u1 = acc[slot + 32] + acc[slot + 96];
+#pragma unroll
+    for (int sft = 1; sft < 32; sft <<= 1) {
+        u0 = u0 + __shfl_xor(u0, sft, 64);
+        u1 = u1 + __shfl_xor(u1, sft, 64);
+    }
+    const float total = u0 + u1;
+    if (slot == 0 && alive) {
         a.loglik[i] = total;
         if (a.loglik_user) a.loglik_user[i] = total;
     }
@@ -365,7 +341,7 @@ hipError_t launch_ekf_paged(hipStream_t stream, const PagedEkfArgs& a, const Eve
 {
     if (a.n <= 0) return hipSuccess;
     if (ev) (void)hipEventRecord(ev->start, stream);
-    ekf_paged_kernel<<<(a.n + kWaves - 1) / kWaves, kWaves * 64, 0, stream>>>(a);
+    ekf_paged_kernel<<<(a.n + 2 * kWaves - 1) / (2 * kWaves), kWaves * 64, 0, stream>>>(a);
     if (ev) (void)hipEventRecord(ev->stop, stream);
     return hipGetLastError();
 }
