@@ -46,7 +46,9 @@ __global__ __launch_bounds__(1024) void page_list_kernel(const float* __restrict
     if (threadIdx.x == 0) s_base = 0;
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int l0 = 0; l0 < nb * kPage; l0 += 1024) {   // 32 pages per step, two per wavefront
+    constexpr int kPerWave = 64 / kPage;                       // pages per wavefront and step
+    constexpr unsigned long long kMask = (1ull << kPage) - 1ull;   // (kPage < 64)
+    for (int l0 = 0; l0 < nb * kPage; l0 += 1024) {   // 1024 / kPage pages per step
         const int l = l0 + (int)threadIdx.x;
         bool ob = false;
         if (l < L) {
@@ -54,17 +56,23 @@ __global__ __launch_bounds__(1024) void page_list_kernel(const float* __restrict
             ob = vx == vx && vy == vy;
         }
         const unsigned long long m = __ballot(ob);
-        const int t_lo = (uint32_t)m != 0u ? 1 : 0, t_hi = (uint32_t)(m >> 32) != 0u ? 1 : 0;
-        if (lane == 0) s_wave[wave] = t_lo + t_hi;
+        int touched_before = 0, touched_mine = 0, touched_all = 0;   // pages of this wavefront: below mine / mine / all
+#pragma unroll
+        for (int g = 0; g < kPerWave; ++g) {
+            const int tg = (m >> (g * kPage) & kMask) != 0ull ? 1 : 0;
+            touched_all += tg;
+            if (g < lane / kPage) touched_before += tg;
+            if (g == lane / kPage) touched_mine = tg;
+        }
+        if (lane == 0) s_wave[wave] = touched_all;
         __syncthreads();
         int off = s_base;
         for (int w = 0; w < wave; ++w) off += s_wave[w];
-        const int b = (l0 >> 5) + 2 * wave + (lane >> 5);
-        if ((lane & 31) == 0 && b < nb) {
-            const bool touched = lane ? t_hi : t_lo;
-            const int t = off + (lane ? t_lo : 0);
-            tindex[b] = touched ? t : -1;
-            if (touched) tpage[t] = b;
+        const int b = l0 / kPage + kPerWave * wave + lane / kPage;
+        if (lane % kPage == 0 && b < nb) {
+            const int t = off + touched_before;
+            tindex[b] = touched_mine ? t : -1;
+            if (touched_mine) tpage[t] = b;
         }
         __syncthreads();
         if (threadIdx.x == 0) {
@@ -97,11 +105,13 @@ __global__ __launch_bounds__(1024) void page_list_kernel(const float* __restrict
 // per wavefront, two pages per pass: 91 us at 64k x 500 with 32 observed).
 __global__ __launch_bounds__(kWaves * 64) void ekf_paged_kernel(PagedEkfArgs a)
 {
-    __shared__ float s_acc[kWaves][2][128];
+    constexpr int kGroups = 64 / kPage;          // particles per wavefront: kPage lanes = the landmarks of a page
+    constexpr int kAccPages = 128 / kPage;       // pages per round of the 128 log-likelihood accumulators
+    __shared__ float s_acc[kWaves][kGroups][128];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int half = lane >> 5, slot = lane & 31;
-    const int first_of_wave = ((int)blockIdx.x * kWaves + wave) << 1;
+    const int half = lane / kPage, slot = lane % kPage;   // `half`: this lane's particle of the wavefront
+    const int first_of_wave = ((int)blockIdx.x * kWaves + wave) * kGroups;
     const int i_raw = first_of_wave + half;
     if (first_of_wave >= a.n) return;
     const bool alive = i_raw < a.n;            // the upper half of the last wavefront may have no particle: it stores nothing
@@ -113,7 +123,7 @@ __global__ __launch_bounds__(kWaves * 64) void ekf_paged_kernel(PagedEkfArgs a)
     const int fbase = __builtin_amdgcn_readfirstlane(a.pool_state[kPoolBase]);
     const int32_t* __restrict__ fresh = a.freelist + fbase + (int64_t)i * T;   // this particle's T fresh pages
     if (alive)
-        for (int b = slot; b < a.nb; b += 32) {
+        for (int b = slot; b < a.nb; b += kPage) {
             const int t = a.tindex[b];
             const int32_t page = t < 0 ? row_in[b] : fresh[t];
             row_out[b] = page;
@@ -124,14 +134,14 @@ __global__ __launch_bounds__(kWaves * 64) void ekf_paged_kernel(PagedEkfArgs a)
     const float s = st, c = ct, px = a.x[i], py = a.y[i], q = a.meas_var;
     float* acc = s_acc[wave][half];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) acc[slot + 32 * k] = 0.0f;
-    for (int c0 = 0; c0 < T; c0 += 32) {   // 32 touched pages at a time: lane t of the half holds what page c0 + t needs
+    for (int k = 0; k < kAccPages; ++k) acc[slot + kPage * k] = 0.0f;
+    for (int c0 = 0; c0 < T; c0 += kPage) {   // kPage touched pages at a time: lane t of the group holds what page c0 + t needs
         const int tl = c0 + slot < T ? c0 + slot : T - 1;
         const int my_b = a.tpage[tl];
         const int my_old = row_in[my_b], my_new = fresh[tl];
-        const int tc = T - c0 < 32 ? T - c0 : 32;
+        const int tc = T - c0 < kPage ? T - c0 : kPage;
         for (int t = 0; t < tc; ++t) {
-            const int from = (half << 5) + t;
+            const int from = half * kPage + t;
             const int b = __shfl(my_b, from, 64);
             const int l = b * kPage + slot;
             const float* __restrict__ pin = a.pool + (int64_t)__shfl(my_old, from, 64) * kPageFloats + slot;
@@ -179,19 +189,25 @@ __global__ __launch_bounds__(kWaves * 64) void ekf_paged_kernel(PagedEkfArgs a)
                 pout[4 * kPage] = r4;
             }
             // accumulator l mod 128, in order of l: a particle's pages come one per pass, in ascending order
-            const int k = (b & 3) * kPage + slot;
+            const int k = (b & (kAccPages - 1)) * kPage + slot;
             if (ob) acc[k] = acc[k] + term;
         }
     }
-    // the specification's reduction — t[j] = acc[j] + acc[j + 64], then t[j] += t[j ^ s] for s = 1 .. 32 — on 32 lanes: a
-    // lane holds t[slot] and t[slot + 32]; the steps s <= 16 stay inside each, the last one adds the two
-    float u0 = acc[slot] + acc[slot + 64], u1 = acc[slot + 32] + acc[slot + 96];
+    // the specification's reduction — t[j] = acc[j] + acc[j + 64], then t[j] += t[j ^ s] for s = 1 .. 32 — on kPage lanes: a
+    // lane holds t[slot + kPage m]; the steps s < kPage run across the lanes on each of them, the steps s >= kPage pair
+    // them inside the lane (a + b is the same float either way round)
+    float u[64 / kPage];
 #pragma unroll
-    for (int sft = 1; sft < 32; sft <<= 1) {
-        u0 = u0 + __shfl_xor(u0, sft, 64);
-        u1 = u1 + __shfl_xor(u1, sft, 64);
-    }
-    const float total = u0 + u1;
+    for (int m = 0; m < 64 / kPage; ++m) u[m] = acc[slot + kPage * m] + acc[slot + kPage * m + 64];
+#pragma unroll
+    for (int sft = 1; sft < kPage; sft <<= 1)
+#pragma unroll
+        for (int m = 0; m < 64 / kPage; ++m) u[m] = u[m] + __shfl_xor(u[m], sft, 64);
+#pragma unroll
+    for (int w = 1; w < 64 / kPage; w <<= 1)
+#pragma unroll
+        for (int m = 0; m < 64 / kPage; m += 2 * w) u[m] = u[m] + u[m + w];
+    const float total = u[0];
     if (slot == 0 && alive) {
         a.loglik[i] = total;
         if (a.loglik_user) a.loglik_user[i] = total;
@@ -341,7 +357,8 @@ hipError_t launch_ekf_paged(hipStream_t stream, const PagedEkfArgs& a, const Eve
 {
     if (a.n <= 0) return hipSuccess;
     if (ev) (void)hipEventRecord(ev->start, stream);
-    ekf_paged_kernel<<<(a.n + 2 * kWaves - 1) / (2 * kWaves), kWaves * 64, 0, stream>>>(a);
+    constexpr int per_block = kWaves * (64 / kPage);
+    ekf_paged_kernel<<<(a.n + per_block - 1) / per_block, kWaves * 64, 0, stream>>>(a);
     if (ev) (void)hipEventRecord(ev->stop, stream);
     return hipGetLastError();
 }
