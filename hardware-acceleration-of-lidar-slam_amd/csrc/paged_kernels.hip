@@ -27,7 +27,7 @@ namespace {
 
 constexpr int kPage = kPageLandmarks;          // landmarks per page
 constexpr int kPageFloats = 5 * kPage;         // floats per page: planes mu_x | mu_y | P_xx | P_xy | P_yy
-constexpr int kWaves = 4;                      // particles per workgroup
+constexpr int kWaves = 4;                      // wavefronts per workgroup (64 / kPage particles each)
 // PoolState (device, kPoolStateWords int32): bookkeeping of the free list between frames, all of it on the device
 enum { kPoolFree = 0,    // entries in the free list
        kPoolUsed = 1,    // ... of which handed out already
@@ -35,7 +35,7 @@ enum { kPoolFree = 0,    // entries in the free list
        kPoolBase = 3 };  // this frame: first entry the update takes
 
 // The pages a frame touches: page b is touched when one of its landmarks has an observation (table form: NaN = none).
-// One workgroup, one landmark per thread and step: a page is a 32-lane half of a wavefront, "touched" a ballot.
+// One workgroup, one landmark per thread and step: a page is kPage neighbouring lanes of a wavefront, "touched" a ballot.
 // tpage[0 .. T) ascending, tindex[b] = position of page b in tpage or -1, count[0] = T.
 __global__ __launch_bounds__(1024) void page_list_kernel(const float* __restrict__ zx, const float* __restrict__ zy, int L,
                                                          int nb, int32_t* __restrict__ tpage, int32_t* __restrict__ tindex,
