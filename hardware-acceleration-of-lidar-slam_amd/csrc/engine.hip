@@ -1003,6 +1003,15 @@ int slam_migrate_pack_dev(slam_engine* e, int n_local, int rank, int world, cons
                           int64_t pose_ld, const float* d_map, int64_t row_stride, int plane_stride, int nlandmarks,
                           float* d_out)
 {
+    return slam_migrate_pack_paged(e, n_local, rank, world, plan, d_pose, pose_ld, d_map, row_stride, plane_stride, nlandmarks,
+                                   d_out, nullptr, 0);
+}
+
+// d_pt != nullptr: d_map is a page pool and the particles' landmarks sit behind page tables of nb entries (pf_session.hip)
+int slam_migrate_pack_paged(slam_engine* e, int n_local, int rank, int world, const int32_t* plan, const float* d_pose,
+                            int64_t pose_ld, const float* d_map, int64_t row_stride, int plane_stride, int nlandmarks,
+                            float* d_out, const int32_t* d_pt, int nb)
+{
     ENTER(e);
     if (n_local <= 0 || world < 1 || world > kMaxRanks || rank < 0 || rank >= world || !plan || nlandmarks < 0 ||
         !d_pose || (nlandmarks > 0 && (!d_map || plane_stride < nlandmarks || row_stride < 5 * (int64_t)plane_stride)))
@@ -1014,7 +1023,7 @@ int slam_migrate_pack_dev(slam_engine* e, int n_local, int rank, int world, cons
     if (!make_plan(mp, base, plan + 1, world) || plan[1 + rank] != 0) return SLAM_ERR_INVALID_ARG;
     if (mp.off[world] > 0 && !d_out) return SLAM_ERR_INVALID_ARG;
     HIP_TRY(launch_migrate_pack(e->stream, e->shard_buf.as<int32_t>(), n_local, mp, d_pose, pose_ld, d_map, row_stride,
-                                plane_stride, nlandmarks, d_out));
+                                plane_stride, nlandmarks, d_out, d_pt, nb));
     return SLAM_OK;
 }
 

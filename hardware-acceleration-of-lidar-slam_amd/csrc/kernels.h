@@ -127,7 +127,8 @@ int pool_state_words();
 hipError_t launch_page_list(hipStream_t stream, const float* zx, const float* zy, int L, int nb, int32_t* tpage, int32_t* tindex,
                             int32_t* count, int n, int32_t* pool_state);
 hipError_t launch_ekf_paged(hipStream_t stream, const PagedEkfArgs& a, const EventPair* ev = nullptr);
-hipError_t launch_page_table_gather(hipStream_t stream, const int32_t* pt_in, int32_t* pt_out, int nb, const int32_t* anc, int n);
+hipError_t launch_page_table_gather(hipStream_t stream, const int32_t* pt_in, int32_t* pt_out, int nb, const int32_t* anc, int n,
+                                    uint32_t* stamp, uint32_t stamp_now);
 // free list = pages whose stamp differs from `live`, the stamp of the last update (in no particular order); does
 // nothing unless launch_page_list asked for it
 hipError_t launch_free_list(hipStream_t stream, const uint32_t* stamp, int npages, uint32_t live, int32_t* freelist,
@@ -138,6 +139,13 @@ hipError_t launch_rows_from_pages(hipStream_t stream, const float* pool, const i
                                   float* rows, int64_t row_stride, int plane_stride, int nlandmarks);
 hipError_t launch_pages_reset(hipStream_t stream, float* pool, int32_t* pt, int64_t nentries, int32_t* freelist, int npages,
                               int32_t* pool_state);
+// Sharded sessions: `want` pages for the rows about to be unpacked (pool_state then says where in the list they start and
+// whether launch_free_list, to be called behind it, has to make a new list first), and the unpack itself: record p of
+// `in` (pose + 5 x nlandmarks floats, as launch_migrate_pack writes them) -> table row n + p on fresh pages, stamped `live`
+hipError_t launch_pool_reserve(hipStream_t stream, int32_t* pool_state, int64_t want);
+hipError_t launch_migrate_unpack_paged(hipStream_t stream, const float* in, int total, int n, float* pose, int64_t pose_ld,
+                                       float* pool, int32_t* pt, int nb, int nlandmarks, const int32_t* freelist,
+                                       const int32_t* pool_state, uint32_t* stamp, uint32_t live);
 
 hipError_t launch_logweight(hipStream_t stream, const float* score, const float* loglik, float gain, int n,
                             float* logw, float* block_max_scratch, float* d_max, const float* carry = nullptr,
@@ -200,7 +208,8 @@ hipError_t launch_ancestors_sharded(hipStream_t stream, const int32_t* first_all
                                     int32_t* host_heads = nullptr);
 hipError_t launch_migrate_pack(hipStream_t stream, const int32_t* scratch, int n, const MigratePlan& plan,
                                const float* pose, int64_t pose_ld, const float* map, int64_t row_stride,
-                               int plane_stride, int nlandmarks, float* out);
+                               int plane_stride, int nlandmarks, float* out,
+                               const int32_t* pt = nullptr, int nb = 0);
 hipError_t launch_migrate_unpack(hipStream_t stream, const float* in, const MigratePlan& plan, int n, float* pose,
                                  int64_t pose_ld, float* map, int64_t row_stride, int plane_stride, int nlandmarks);
 hipError_t launch_argmax(hipStream_t stream, const float* v, int n, int32_t* idx_out, float* val_out);

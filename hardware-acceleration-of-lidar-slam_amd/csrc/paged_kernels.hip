@@ -34,6 +34,19 @@ enum { kPoolFree = 0,    // entries in the free list
        kPoolRenew = 2,   // this frame: the list is made anew before the update takes from it
        kPoolBase = 3 };  // this frame: first entry the update takes
 
+// `want` fresh pages for whoever calls (one thread): they come from the part of the free list nobody has been given yet —
+// or, when that is too short, from a list made anew by free_list_kernel (launched behind the caller, it looks at the
+// flag); such a list always holds at least half the pool.
+__device__ __forceinline__ void pool_reserve(int32_t* __restrict__ pool_state, int64_t want)
+{
+    const bool renew = (int64_t)pool_state[kPoolUsed] + want > (int64_t)pool_state[kPoolFree];
+    pool_state[kPoolRenew] = renew ? 1 : 0;
+    if (renew) pool_state[kPoolFree] = 0;   // the list kernel adds its tiles' counts to it
+    const int first = renew ? 0 : pool_state[kPoolUsed];
+    pool_state[kPoolBase] = first;
+    pool_state[kPoolUsed] = first + (int)want;
+}
+
 // The pages a frame touches: page b is touched when one of its landmarks has an observation (table form: NaN = none).
 // One workgroup, one landmark per thread and step: a page is kPage neighbouring lanes of a wavefront, "touched" a ballot.
 // tpage[0 .. T) ascending, tindex[b] = position of page b in tpage or -1, count[0] = T.
@@ -85,17 +98,34 @@ __global__ __launch_bounds__(1024) void page_list_kernel(const float* __restrict
     if (threadIdx.x == 0) {
         const int T = s_base;
         count[0] = T;
-        // Where this frame's n * T fresh pages come from (PoolState): the part of the free list nobody has been given yet —
-        // or, when that is too short, a list made anew by free_list_kernel (launched behind this kernel, it looks at the
-        // flag), which always holds at least n * nb pages.
-        const int64_t want = (int64_t)n * T;
-        const bool renew = (int64_t)pool_state[kPoolUsed] + want > (int64_t)pool_state[kPoolFree];
-        pool_state[kPoolRenew] = renew ? 1 : 0;
-        if (renew) pool_state[kPoolFree] = 0;   // the list kernel adds its tiles' counts to it
-        const int first = renew ? 0 : pool_state[kPoolUsed];
-        pool_state[kPoolBase] = first;
-        pool_state[kPoolUsed] = first + (int)want;
+        pool_reserve(pool_state, (int64_t)n * T);   // this frame's n * T fresh pages
     }
+}
+
+__global__ void pool_reserve_kernel(int32_t* __restrict__ pool_state, int64_t want) { pool_reserve(pool_state, want); }
+
+// Received rows -> fresh pages behind table rows n .. n + total - 1 (one workgroup per record).  The pages get the stamp
+// of the last update: they are in use from now on, whatever a free list made before the next update finds.
+__global__ __launch_bounds__(256) void migrate_unpack_paged_kernel(const float* __restrict__ in, int total, int n,
+                                                                   float* __restrict__ pose, int64_t pose_ld,
+                                                                   float* __restrict__ pool, int32_t* __restrict__ pt, int nb,
+                                                                   int nlandmarks, const int32_t* __restrict__ freelist,
+                                                                   const int32_t* __restrict__ pool_state,
+                                                                   uint32_t* __restrict__ stamp, uint32_t live)
+{
+    const int p = blockIdx.x;
+    if (p >= total) return;
+    const float* __restrict__ rec = in + (int64_t)(3 + 5 * nlandmarks) * p;
+    if (threadIdx.x < 3) pose[threadIdx.x * pose_ld + n + p] = rec[threadIdx.x];
+    const int32_t* __restrict__ mine = freelist + pool_state[kPoolBase] + (int64_t)p * nb;
+    for (int b = threadIdx.x; b < nb; b += 256) {
+        pt[(int64_t)(n + p) * nb + b] = mine[b];
+        stamp[mine[b]] = live;
+    }
+    for (int pl = 0; pl < 5; ++pl)
+        for (int l = threadIdx.x; l < nb * kPage; l += 256)   // the tail of the last page: landmarks that do not exist
+            pool[(int64_t)mine[l / kPage] * kPageFloats + pl * kPage + l % kPage] =
+                l < nlandmarks ? rec[3 + pl * nlandmarks + l] : (pl == 2 ? -1.0f : 0.0f);
 }
 
 // HALF a wavefront = one particle (32 lanes = the 32 landmarks of a page).  (1) its new page-table row: the ancestor's
@@ -214,14 +244,18 @@ __global__ __launch_bounds__(kWaves * 64) void ekf_paged_kernel(PagedEkfArgs a)
     }
 }
 
-// A frame without observations: the tables follow their particles, nothing else moves.
+// A frame without observations: the tables follow their particles, nothing else moves.  Every page the new tables name
+// gets the new stamp, like in an update: "in use" always means "named by the latest generation of tables".
 __global__ __launch_bounds__(256) void page_table_gather_kernel(const int32_t* __restrict__ pt_in, int32_t* __restrict__ pt_out,
-                                                                int nb, const int32_t* __restrict__ anc, int n)
+                                                                int nb, const int32_t* __restrict__ anc, int n,
+                                                                uint32_t* __restrict__ stamp, uint32_t stamp_now)
 {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (int64_t)n * nb) return;
     const int i = (int)(idx / nb), b = (int)(idx - (int64_t)i * nb);
-    pt_out[idx] = pt_in[(int64_t)(anc ? anc[i] : i) * nb + b];
+    const int32_t page = pt_in[(int64_t)(anc ? anc[i] : i) * nb + b];
+    pt_out[idx] = page;
+    stamp[page] = stamp_now;
 }
 
 // ---- free list = pages without the latest stamp (every update stamps every page its new tables name, so at any time the
@@ -363,10 +397,11 @@ hipError_t launch_ekf_paged(hipStream_t stream, const PagedEkfArgs& a, const Eve
     return hipGetLastError();
 }
 
-hipError_t launch_page_table_gather(hipStream_t stream, const int32_t* pt_in, int32_t* pt_out, int nb, const int32_t* anc, int n)
+hipError_t launch_page_table_gather(hipStream_t stream, const int32_t* pt_in, int32_t* pt_out, int nb, const int32_t* anc, int n,
+                                    uint32_t* stamp, uint32_t stamp_now)
 {
     if (n <= 0 || nb <= 0) return hipSuccess;
-    page_table_gather_kernel<<<blocks256((int64_t)n * nb), 256, 0, stream>>>(pt_in, pt_out, nb, anc, n);
+    page_table_gather_kernel<<<blocks256((int64_t)n * nb), 256, 0, stream>>>(pt_in, pt_out, nb, anc, n, stamp, stamp_now);
     return hipGetLastError();
 }
 
@@ -376,6 +411,22 @@ hipError_t launch_free_list(hipStream_t stream, const uint32_t* stamp, int npage
                             int32_t* pool_state)
 {
     free_list_kernel<<<(npages + kFreeTile - 1) / kFreeTile, 256, 0, stream>>>(stamp, npages, live, freelist, pool_state);
+    return hipGetLastError();
+}
+
+hipError_t launch_pool_reserve(hipStream_t stream, int32_t* pool_state, int64_t want)
+{
+    pool_reserve_kernel<<<1, 1, 0, stream>>>(pool_state, want);
+    return hipGetLastError();
+}
+
+hipError_t launch_migrate_unpack_paged(hipStream_t stream, const float* in, int total, int n, float* pose, int64_t pose_ld,
+                                       float* pool, int32_t* pt, int nb, int nlandmarks, const int32_t* freelist,
+                                       const int32_t* pool_state, uint32_t* stamp, uint32_t live)
+{
+    if (total <= 0) return hipSuccess;
+    migrate_unpack_paged_kernel<<<total, 256, 0, stream>>>(in, total, n, pose, pose_ld, pool, pt, nb, nlandmarks, freelist,
+                                                          pool_state, stamp, live);
     return hipGetLastError();
 }
 

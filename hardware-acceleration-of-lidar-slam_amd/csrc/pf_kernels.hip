@@ -1424,7 +1424,8 @@ __global__ __launch_bounds__(kBlock) void migrate_pack_kernel(const int32_t* __r
                                                               MigratePlan plan, const float* __restrict__ pose,
                                                               int64_t pose_ld, const float* __restrict__ map,
                                                               int64_t row_stride, int plane_stride, int nlandmarks,
-                                                              float* __restrict__ out)
+                                                              float* __restrict__ out, const int32_t* __restrict__ pt,
+                                                              int nb)
 {
     const int p = blockIdx.x;
     int d = 0;
@@ -1438,6 +1439,14 @@ __global__ __launch_bounds__(kBlock) void migrate_pack_kernel(const int32_t* __r
     const int loc = lo;
     float* __restrict__ rec = out + (int64_t)(3 + 5 * nlandmarks) * p;
     if (threadIdx.x < 3) rec[threadIdx.x] = pose[threadIdx.x * pose_ld + loc];
+    if (pt) {   // paged maps: `map` is the page pool, the particle's landmarks sit behind its page table (paged_kernels.hip)
+        const int32_t* __restrict__ tab = pt + (int64_t)loc * nb;
+        for (int pl = 0; pl < 5; ++pl)
+            for (int l = threadIdx.x; l < nlandmarks; l += kBlock)
+                rec[3 + pl * nlandmarks + l] = map[(int64_t)tab[l / kPageLandmarks] * (5 * kPageLandmarks) + pl * kPageLandmarks +
+                                                   l % kPageLandmarks];
+        return;
+    }
     const float* __restrict__ row = map + (int64_t)loc * row_stride;
     for (int pl = 0; pl < 5; ++pl)
         for (int l = threadIdx.x; l < nlandmarks; l += kBlock) rec[3 + pl * nlandmarks + l] = row[pl * plane_stride + l];
@@ -1820,7 +1829,7 @@ hipError_t launch_ancestors_sharded(hipStream_t stream, const int32_t* first_all
 // plan.lo[d] = send_base[d] (the P value of the first particle sent to d), plan.off = running record offsets
 hipError_t launch_migrate_pack(hipStream_t stream, const int32_t* scratch, int n, const MigratePlan& plan,
                                const float* pose, int64_t pose_ld, const float* map, int64_t row_stride,
-                               int plane_stride, int nlandmarks, float* out)
+                               int plane_stride, int nlandmarks, float* out, const int32_t* pt, int nb)
 {
     const int total = plan.off[plan.world];
     if (total <= 0) return hipSuccess;
@@ -1828,7 +1837,7 @@ hipError_t launch_migrate_pack(hipStream_t stream, const int32_t* scratch, int n
     const int32_t* pfx = scratch + n;
     const int32_t* boff = pfx + 2 * (int64_t)n;
     migrate_pack_kernel<<<total, kBlock, 0, stream>>>(pfx, boff, ntiles, n, plan, pose, pose_ld, map, row_stride,
-                                                     plane_stride, nlandmarks, out);
+                                                     plane_stride, nlandmarks, out, pt, nb);
     return hipGetLastError();
 }
 

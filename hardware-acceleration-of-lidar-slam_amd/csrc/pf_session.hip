@@ -61,7 +61,7 @@ struct slam_pf {
     // ---- paged maps (slam_pf_paged_set before the session is made; one GPU): copy-on-write pages behind a page table
     // per particle instead of one row per particle (paged_kernels.hip); map[] stays unallocated
     bool paged = false;
-    int nb = 0, npages = 0;         // pages per particle; pages in the pool (2 * n * nb: never fewer than n * nb are free)
+    int nb = 0, npages = 0;         // pages per particle; pages in the pool (2 * cap * nb: never fewer than half are free)
     float* pool = nullptr;          // [npages][5][32]
     int32_t* pt[2] = { nullptr, nullptr };   // [n][nb] page tables, current and next
     int pt_cur = 0;
@@ -120,16 +120,25 @@ int migrate(slam_pf* pf)
     pf->rows_received = (int)rtot;
     if (int rc = grow(pf, &pf->sbuf, &pf->sbuf_floats, (size_t)(rec * stot))) return rc;
     if (int rc = grow(pf, &pf->rbuf, &pf->rbuf_floats, (size_t)(rec * rtot))) return rc;
-    const float* mp = L ? pf->map[pf->map_cur] : nullptr;
+    const float* mp = L ? (pf->paged ? pf->pool : pf->map[pf->map_cur]) : nullptr;
     if (stot)
-        if (int rc = slam_migrate_pack_dev(e, n, pf->rank, G, plan, pf->pose[pf->cur], n, mp, 5 * (int64_t)pf->Lp, pf->Lp, L,
-                                           pf->sbuf))
+        if (int rc = slam_migrate_pack_paged(e, n, pf->rank, G, plan, pf->pose[pf->cur], n, mp, 5 * (int64_t)pf->Lp, pf->Lp, L,
+                                             pf->sbuf, pf->paged ? pf->pt[pf->pt_cur] : nullptr, pf->nb))
             return rc;
     if (int rc = comm_all_to_all_f32(pf->comm, pf->sbuf, sfl, pf->rbuf, rfl)) return rc;
-    if (rtot)
+    if (rtot && pf->paged) {
+        // fresh pages for the received rows (a new free list first if the old one runs short), table rows n .. n + rtot - 1
+        int32_t* pstate = pf->page_scratch + 2 * pf->nb + 1;
+        SLAM_HIP_TRY(e, launch_pool_reserve(e->stream, pstate, rtot * pf->nb));
+        SLAM_HIP_TRY(e, launch_free_list(e->stream, pf->stamp, pf->npages, pf->stamp_now, pf->freelist, pstate));
+        SLAM_HIP_TRY(e, launch_migrate_unpack_paged(e->stream, pf->rbuf, (int)rtot, n, pf->pose_stage, pf->cap, pf->pool,
+                                                    pf->pt[pf->pt_cur], pf->nb, L, pf->freelist, pstate, pf->stamp,
+                                                    pf->stamp_now));
+    } else if (rtot) {
         if (int rc = slam_migrate_unpack_dev(e, pf->rbuf, G, rcnt, n, pf->pose_stage, pf->cap,
                                              L ? pf->map[pf->map_cur] : nullptr, 5 * (int64_t)pf->Lp, pf->Lp, L))
             return rc;
+    }
     return SLAM_OK;
 }
 
@@ -205,10 +214,10 @@ int create_common(slam_engine* e, const slam_pf_config* cfg, slam_comm* comm, in
     }
     const size_t n = (size_t)pf->n, L = (size_t)pf->L, Lp = (size_t)pf->Lp, cap = (size_t)pf->cap, G = (size_t)pf->world;
     bool ok = true;
-    pf->paged = e->pf_paged && !comm && pf->L > 0;
+    pf->paged = e->pf_paged && pf->L > 0;
     if (pf->paged) {
         pf->nb = pf->Lp / kPageLandmarks;
-        const int64_t np = 2 * (int64_t)pf->n * pf->nb;
+        const int64_t np = 2 * (int64_t)pf->cap * pf->nb;   // table rows (with the staging tail) never name more than half
         if (np > 0x7fffffff) {
             delete pf;
             return SLAM_ERR_CAPACITY;
@@ -225,7 +234,7 @@ int create_common(slam_engine* e, const slam_pf_config* cfg, slam_comm* comm, in
         ok = ok && dev_alloc((void**)&pf->pose[b], 3 * n * 4) == hipSuccess;
         ok = ok && dev_alloc((void**)&pf->anc[b], n * 4) == hipSuccess;
         if (L && !pf->paged) ok = ok && dev_alloc((void**)&pf->map[b], 5 * Lp * cap * 4) == hipSuccess;
-        if (pf->paged) ok = ok && dev_alloc((void**)&pf->pt[b], n * (size_t)pf->nb * 4) == hipSuccess;
+        if (pf->paged) ok = ok && dev_alloc((void**)&pf->pt[b], cap * (size_t)pf->nb * 4) == hipSuccess;
         if (comm) ok = ok && dev_alloc((void**)&pf->pose_idx[b], n * 4) == hipSuccess;
     }
     ok = ok && dev_alloc((void**)&pf->score, n * 4) == hipSuccess && dev_alloc((void**)&pf->logw, n * 4) == hipSuccess &&
@@ -475,7 +484,8 @@ int slam_pf_step(slam_pf* pf, int slot, const float dp[3], int use_observations)
             rc = slam_logweight_ekf_dev(e, pf->score, pf->cfg.score_gain, n, pf->logw, d_max);
         } else {
             if (anc) {   // the tables follow their particles
-                SLAM_HIP_TRY(e, launch_page_table_gather(e->stream, pf->pt[pc], pf->pt[1 - pc], pf->nb, anc, n));
+                SLAM_HIP_TRY(e, launch_page_table_gather(e->stream, pf->pt[pc], pf->pt[1 - pc], pf->nb, anc, n, pf->stamp,
+                                                         ++pf->stamp_now));
                 pf->pt_cur = 1 - pc;
             }
             rc = slam_logweight_dev(e, pf->score, nullptr, pf->cfg.score_gain, n, pf->logw, d_max);

@@ -427,7 +427,7 @@ int slam_pf_set_map_dev(slam_pf *pf, const float *d_rows, int64_t row_stride, in
  * landmark.  For frames that observe few of many landmarks (a row per particle rewrites every row on every resampling
  * frame); results are bit-identical to a row-per-particle session.  Such a session has no rows to look at:
  * slam_pf_device_view gives map = NULL, maps go in and out through slam_pf_set_map_* / slam_pf_get_map_host.
- * Sharded sessions keep rows. */
+ * Sharded sessions work the same way (a migrating particle travels with all its pages, as a row does). */
 int slam_pf_paged_set(slam_engine *e, int on);
 int slam_pf_is_paged(const slam_pf *pf);
 /* one frame against grid `slot`; asynchronous */

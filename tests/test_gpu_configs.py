@@ -167,7 +167,7 @@ def test_ekf_long_rows_small_n(eng, orc, L, Lp):
 
 
 # ------------------------------------------------------------------ the sharded C session (slam_pf_create_sharded)
-def _run_c_session_ranks(world, n_total, L, frames, transport="local", recv_capacity=0, ess=0.0, inplace_form=-1):
+def _run_c_session_ranks(world, n_total, L, frames, transport="local", recv_capacity=0, ess=0.0, inplace_form=-1, paged=False):
     """`world` ranks of the C-level sharded session in THIS process, one host thread per rank, all on cuda:0
     (in-process transport), or a one-rank RCCL communicator.  Returns the concatenated population."""
     import threading
@@ -189,6 +189,7 @@ def _run_c_session_ranks(world, n_total, L, frames, transport="local", recv_capa
         try:
             eng = pkg.Engine(0)
             eng.ekf_inplace_form_set(inplace_form)   # frames that keep their population: whole rows / the compact observation list
+            eng.pf_paged_set(paged)                  # landmark maps as copy-on-write pages instead of one row per particle
             eng.grid_set_dev(0, d_edt, gm)
             eng.scan_upload(bx, by)
             comm = None

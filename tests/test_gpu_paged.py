@@ -107,6 +107,26 @@ def test_paged_session_many_frames_of_free_list_turnover():
         assert a[2] == b[2] and a[1] == b[1]
 
 
+@pytest.mark.parametrize("world,n_total,L,ess", [(2, 4096, 6, 0.0), (4, 4096, 40, 0.0), (3, 3000, 6, 0.0), (4, 4096, 6, 0.5),
+                                                 (8, 16384, 100, 0.0)])
+def test_sharded_paged_session_equals_one_rank_on_rows(world, n_total, L, ess):
+    """Paged maps in a SHARDED session (ranks = threads on this card, in-process transport): a migrating particle travels
+    with all its pages and lands on fresh pages behind a staging table row.  Poses, maps and the heaviest particle equal
+    the single-GPU row session's, bit for bit; rows really travel."""
+    from test_gpu_configs import _run_c_session_ranks
+
+    frames = 9
+    one = _run_c_session_ranks(1, n_total, L, frames, transport=None, ess=ess)[0]
+    many = _run_c_session_ranks(world, n_total, L, frames, ess=ess, paged=True)
+    assert np.array_equal(bits(np.concatenate([p["pose"] for p in many], axis=1)), bits(one["pose"]))
+    assert np.array_equal(bits(np.concatenate([p["map"] for p in many], axis=0)), bits(one["map"]))
+    for p in many:
+        assert p["best"][2] == one["best"][2] and p["best"][1] == one["best"][1]
+        assert np.array_equal(bits(p["mean"]), bits(one["mean"]))
+    if not ess:
+        assert max(max(p["rows"]) for p in many) > 10
+
+
 def test_paged_session_set_map_dev_and_views():
     """slam_pf_set_map_dev (rows on the device -> pages), slam_pf_get_map_host back; a paged session shows no rows."""
     pkg = load_package()
