@@ -421,7 +421,7 @@ int slam_pf_set_poses_host(slam_pf *pf, const float *x, const float *y, const fl
 int slam_pf_set_map_host(slam_pf *pf, const float *rows /* [n_particles][5][n_landmarks] */);
 /* the same from device memory: rows [n_particles][5 planes][plane_stride] floats, row_stride floats apart; asynchronous */
 int slam_pf_set_map_dev(slam_pf *pf, const float *d_rows, int64_t row_stride, int plane_stride);
-/* Paged maps (one GPU).  A session made after slam_pf_paged_set(e, 1) keeps every particle's landmarks behind a page
+/* Paged maps.  A session made after slam_pf_paged_set(e, 1) keeps every particle's landmarks behind a page
  * table — pages of 32 landmarks (640 bytes), shared between the offspring of an ancestor until one of them is written:
  * a resample copies 4 bytes per 32 landmarks, and a frame's update rewrites only the pages that hold an observed
  * landmark.  For frames that observe few of many landmarks (a row per particle rewrites every row on every resampling
