@@ -395,8 +395,10 @@ int slam_pf_set_map_dev(slam_pf* pf, const float* d_rows, int64_t row_stride, in
                                                pf->pt[pf->pt_cur], pf->freelist, pf->npages, pf->page_scratch + 2 * pf->nb + 1));
         return SLAM_OK;
     }
-    SLAM_HIP_TRY(e, hipMemcpy2DAsync(pf->map[pf->map_cur], (size_t)pf->Lp * 4, d_rows, (size_t)plane_stride * 4, (size_t)pf->L * 4,
-                                     5 * (size_t)pf->n, hipMemcpyDeviceToDevice, e->stream));
+    for (int pl = 0; pl < 5; ++pl)   // plane by plane: one 2-D copy each whatever the caller's row stride is
+        SLAM_HIP_TRY(e, hipMemcpy2DAsync(pf->map[pf->map_cur] + (size_t)pl * pf->Lp, 5 * (size_t)pf->Lp * 4,
+                                         d_rows + (size_t)pl * plane_stride, (size_t)row_stride * 4, (size_t)pf->L * 4,
+                                         (size_t)pf->n, hipMemcpyDeviceToDevice, e->stream));
     return SLAM_OK;
 }
 
