@@ -131,6 +131,8 @@ SIGNATURES = {
     "slam_pf_best": (_i, [_vp, _fp, _fp, C.POINTER(C.c_int32)]),
     "slam_pf_get_poses_host": (_i, [_vp, _vp, _vp, _vp]),
     "slam_pf_get_map_host": (_i, [_vp, _vp]),
+    "slam_pf_get_map_rows_host": (_i, [_vp, _vp, _i, _vp]),
+    "slam_pf_paged_device_view": (_i, [_vp, _vp]),
 }
 
 _LIB = None
@@ -444,7 +446,12 @@ class PfConfig(C.Structure):
     """``slam_pf_config``"""
 
     _fields_ = [("n_particles", C.c_int32), ("n_landmarks", C.c_int32), ("sigma", C.c_float * 3),
-                ("meas_var", C.c_float), ("score_gain", C.c_float), ("seed", C.c_uint64), ("resample_ess_frac", C.c_float)]
+                ("meas_var", C.c_float), ("score_gain", C.c_float), ("seed", C.c_uint64), ("resample_ess_frac", C.c_float),
+                ("map_layout", C.c_int32)]
+
+
+MAP_AUTO, MAP_ROWS, MAP_PAGES = 0, 1, 2   # slam_map_layout
+_LAYOUTS = {"auto": MAP_AUTO, "rows": MAP_ROWS, "pages": MAP_PAGES, None: MAP_AUTO}
 
 
 COMM_ID_BYTES = 128
@@ -454,7 +461,16 @@ class PfView(C.Structure):
     """``slam_pf_view``"""
 
     _fields_ = [("pose", C.c_void_p), ("map", C.c_void_p), ("map_spare", C.c_void_p), ("anc", C.c_void_p), ("row_stride", C.c_int64),
-                ("plane_stride", C.c_int32), ("map_rows", C.c_int32)]
+                ("plane_stride", C.c_int32), ("map_rows", C.c_int32), ("score", C.c_void_p), ("logw", C.c_void_p),
+                ("loglik", C.c_void_p)]
+
+
+class PfPagedView(C.Structure):
+    """``slam_pf_paged_view``"""
+
+    _fields_ = [("pool", C.c_void_p), ("table", C.c_void_p), ("freelist", C.c_void_p), ("state", C.c_void_p),
+                ("stamp", C.c_void_p), ("stamp_now", C.c_uint32), ("page_landmarks", C.c_int32),
+                ("pages_per_particle", C.c_int32), ("table_rows", C.c_int32), ("npages", C.c_int64)]
 
 
 class DeviceArray:
@@ -533,9 +549,12 @@ class PfSession:
     of a population sharded over several GPUs (``n_particles`` = this rank's share); every call is then collective."""
 
     def __init__(self, engine: Engine, n_particles, n_landmarks=0, sigma=(0.01, 0.01, 0.002), meas_var=0.01,
-                 score_gain=1.0, seed=1, comm: Comm | None = None, recv_capacity: int = 0, resample_ess_frac: float = 0.0):
+                 score_gain=1.0, seed=1, comm: Comm | None = None, recv_capacity: int = 0, resample_ess_frac: float = 0.0,
+                 map_layout: str | int | None = None):
+        """map_layout: "auto" (default: the session chooses), "rows" or "pages" (``slam_map_layout``)."""
         self.e, self.n, self.L, self.comm = engine, n_particles, n_landmarks, comm
-        cfg = PfConfig(n_particles, n_landmarks, (C.c_float * 3)(*sigma), meas_var, score_gain, seed, resample_ess_frac)
+        cfg = PfConfig(n_particles, n_landmarks, (C.c_float * 3)(*sigma), meas_var, score_gain, seed, resample_ess_frac,
+                       _LAYOUTS.get(map_layout, map_layout))
         h = C.c_void_p()
         if comm is None:
             engine._ck(engine.lib.slam_pf_create(engine.h, C.byref(cfg), C.byref(h)), "pf_create")
@@ -561,7 +580,21 @@ class PfSession:
                 "map": DeviceArray(v.map, shape, "<f4", self) if v.map else None,
                 "map_spare": DeviceArray(v.map_spare, shape, "<f4", self) if v.map_spare else None,
                 "anc": DeviceArray(v.anc, (self.n,), "<i4", self) if v.anc else None,
+                "score": DeviceArray(v.score, (self.n,), "<f4", self) if v.score else None,
+                "logw": DeviceArray(v.logw, (self.n,), "<f4", self) if v.logw else None,
+                "loglik": DeviceArray(v.loglik, (self.n,), "<f4", self) if v.loglik else None,
                 "plane_stride": v.plane_stride, "row_stride": v.row_stride}
+
+    def paged_view(self):
+        """``slam_pf_paged_device_view``: the page pool, tables, stamps and free list of a session that is on pages."""
+        v = PfPagedView()
+        self.e._ck(self.e.lib.slam_pf_paged_device_view(self.h, C.byref(v)), "pf_paged_device_view")
+        P, nb = int(v.npages), v.pages_per_particle
+        return {"pool": DeviceArray(v.pool, (P, 5, v.page_landmarks), "<f4", self),
+                "table": DeviceArray(v.table, (v.table_rows, nb), "<i4", self),
+                "freelist": DeviceArray(v.freelist, (P,), "<i4", self), "state": DeviceArray(v.state, (4,), "<i4", self),
+                "stamp": DeviceArray(v.stamp, (P,), "<i4", self), "stamp_now": int(v.stamp_now),
+                "page_landmarks": v.page_landmarks, "pages_per_particle": nb, "table_rows": v.table_rows, "npages": P}
 
     def close(self):
         if getattr(self, "h", None):
@@ -611,6 +644,13 @@ class PfSession:
     def maps(self):
         m = np.empty((self.n, 5, self.L), np.float32)
         self.e._ck(self.e.lib.slam_pf_get_map_host(self.h, _ptr(m)), "pf_get_map")
+        return m
+
+    def map_rows(self, particles):
+        """``slam_pf_get_map_rows_host``: the maps of the chosen current particles, [len][5][n_landmarks]."""
+        sel = _np(particles, np.int32)
+        m = np.empty((len(sel), 5, self.L), np.float32)
+        self.e._ck(self.e.lib.slam_pf_get_map_rows_host(self.h, _ptr(sel), len(sel), _ptr(m)), "pf_get_map_rows")
         return m
 
 

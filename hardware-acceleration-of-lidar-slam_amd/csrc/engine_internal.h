@@ -127,6 +127,7 @@ struct slam_engine {
     int32_t* d_hobs = nullptr;
     int ekf_inplace_form = -1;   // slam_ekf_inplace_form_set: -1 by the feedback, 0 whole rows, 1 observed landmarks only
     int64_t ekf_inplace_launches[2] = { 0, 0 };
+    int live_sessions = 0;     // slam_pf sessions alive on this engine (at most one: the stages keep per-population state here)
     bool pf_paged = false;     // slam_pf_paged_set: sessions made from now on keep their maps as copy-on-write pages
     int ekf_form = -1;         // slam_ekf_form_set: -1 choose by the feedback, 0 row per wavefront, 1 / 2 grouped by 4 / 2
     int64_t ekf_form_launches[2] = { 0, 0 };   // out-of-place launches so far: [0] one wavefront per particle, [1] grouped

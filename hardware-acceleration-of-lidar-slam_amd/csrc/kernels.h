@@ -131,8 +131,11 @@ hipError_t launch_page_table_gather(hipStream_t stream, const int32_t* pt_in, in
                                     uint32_t* stamp, uint32_t stamp_now);
 // free list = pages whose stamp differs from `live`, the stamp of the last update (in no particular order); does
 // nothing unless launch_page_list asked for it
+// h_short (optional, mapped host memory): set to 1 when a list made anew turns out shorter than the reservation
 hipError_t launch_free_list(hipStream_t stream, const uint32_t* stamp, int npages, uint32_t live, int32_t* freelist,
-                            int32_t* pool_state);
+                            int32_t* pool_state, int32_t* h_short = nullptr);
+// out[k] = anc[sel[k]] (anc == nullptr: sel[k])
+hipError_t launch_compose_index(hipStream_t stream, const int32_t* sel, const int32_t* anc, int count, int32_t* out);
 hipError_t launch_pages_from_rows(hipStream_t stream, const float* rows, int64_t row_stride, int plane_stride, int nlandmarks,
                                   int nb, int n, float* pool, int32_t* pt, int32_t* freelist, int npages, int32_t* pool_state);
 hipError_t launch_rows_from_pages(hipStream_t stream, const float* pool, const int32_t* pt, int nb, const int32_t* anc, int n,

@@ -32,7 +32,9 @@ constexpr int kWaves = 4;                      // wavefronts per workgroup (64 /
 enum { kPoolFree = 0,    // entries in the free list
        kPoolUsed = 1,    // ... of which handed out already
        kPoolRenew = 2,   // this frame: the list is made anew before the update takes from it
-       kPoolBase = 3 };  // this frame: first entry the update takes
+       kPoolBase = 3,    // this frame: first entry the update takes
+       kPoolTicket = 4,  // workgroups of free_list_kernel that have added their share (left at zero)
+       kPoolShort = 5 }; // set (and never cleared) when a list made anew was shorter than what had been reserved from it
 
 // `want` fresh pages for whoever calls (one thread): they come from the part of the free list nobody has been given yet —
 // or, when that is too short, from a list made anew by free_list_kernel (launched behind the caller, it looks at the
@@ -266,8 +268,13 @@ __global__ __launch_bounds__(256) void page_table_gather_kernel(const int32_t* _
 // them).
 constexpr int kFreeTile = 8192;
 
+// The reservation is checked against the finished list by the last workgroup to arrive: tables never name more than half the
+// pool, so a new list always holds what a frame takes — if that invariant were ever broken the update would hand out pages
+// that are still in use, so the shortfall is reported (pool_state[kPoolShort] and, when given, a word in mapped host memory
+// that slam_pf_step turns into SLAM_ERR_CAPACITY) instead of passing silently.
 __global__ __launch_bounds__(256) void free_list_kernel(const uint32_t* __restrict__ stamp, int npages, uint32_t live,
-                                                        int32_t* __restrict__ freelist, int32_t* __restrict__ pool_state)
+                                                        int32_t* __restrict__ freelist, int32_t* __restrict__ pool_state,
+                                                        int32_t* __restrict__ h_short)
 {
     __shared__ int s_w[4];
     __shared__ int s_base;
@@ -304,6 +311,18 @@ __global__ __launch_bounds__(256) void free_list_kernel(const uint32_t* __restri
 #pragma unroll
     for (int k = 0; k < kPer; ++k)
         if (freebits >> k & 1u) freelist[out++] = p0 + k;
+    if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(&pool_state[kPoolTicket], 1) == (int)gridDim.x - 1) {   // every workgroup's share is in
+            __threadfence();
+            pool_state[kPoolTicket] = 0;
+            const int have = __hip_atomic_load(&pool_state[kPoolFree], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (have < pool_state[kPoolUsed]) {
+                pool_state[kPoolShort] = 1;
+                if (h_short) *h_short = 1;
+            }
+        }
+    }
 }
 
 // ---- rows <-> pages (set / get of whole maps; not on the frame path)
@@ -359,6 +378,8 @@ __global__ __launch_bounds__(256) void pages_reset_kernel(float* __restrict__ po
         pool_state[kPoolUsed] = 0;
         pool_state[kPoolRenew] = 0;
         pool_state[kPoolBase] = 0;
+        pool_state[kPoolTicket] = 0;
+        pool_state[kPoolShort] = 0;
     }
 }
 
@@ -373,7 +394,17 @@ __global__ __launch_bounds__(256) void free_iota_kernel(int32_t* __restrict__ ou
         pool_state[kPoolUsed] = 0;
         pool_state[kPoolRenew] = 0;
         pool_state[kPoolBase] = 0;
+        pool_state[kPoolTicket] = 0;
+        pool_state[kPoolShort] = 0;
     }
+}
+
+// out[k] = anc[sel[k]] (or sel[k]): the source rows of a few chosen particles with the pending gather applied
+__global__ __launch_bounds__(256) void compose_index_kernel(const int32_t* __restrict__ sel, const int32_t* __restrict__ anc,
+                                                            int count, int32_t* __restrict__ out)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k < count) out[k] = anc ? anc[sel[k]] : sel[k];
 }
 
 inline int blocks256(int64_t n) { return (int)((n + 255) / 256); }
@@ -405,12 +436,19 @@ hipError_t launch_page_table_gather(hipStream_t stream, const int32_t* pt_in, in
     return hipGetLastError();
 }
 
-int pool_state_words() { return 4; }
+int pool_state_words() { return 6; }
+
+hipError_t launch_compose_index(hipStream_t stream, const int32_t* sel, const int32_t* anc, int count, int32_t* out)
+{
+    if (count <= 0) return hipSuccess;
+    compose_index_kernel<<<blocks256(count), 256, 0, stream>>>(sel, anc, count, out);
+    return hipGetLastError();
+}
 
 hipError_t launch_free_list(hipStream_t stream, const uint32_t* stamp, int npages, uint32_t live, int32_t* freelist,
-                            int32_t* pool_state)
+                            int32_t* pool_state, int32_t* h_short)
 {
-    free_list_kernel<<<(npages + kFreeTile - 1) / kFreeTile, 256, 0, stream>>>(stamp, npages, live, freelist, pool_state);
+    free_list_kernel<<<(npages + kFreeTile - 1) / kFreeTile, 256, 0, stream>>>(stamp, npages, live, freelist, pool_state, h_short);
     return hipGetLastError();
 }
 

@@ -52,7 +52,8 @@ struct slam_pf {
     int rows_received = 0;
     // results a host asks for every frame (heaviest particle, posterior mean): written by ONE kernel to mapped host
     // memory behind a sequence number — no device-to-host copies, no stream synchronisation
-    float* h_res = nullptr;         // pinned + mapped: 8 x 8 bytes of payload, then the sequence number
+    float* h_res = nullptr;         // pinned + mapped: 8 x 8 bytes of payload, the sequence number (word 16), and word 20:
+                                    // "a free list came out shorter than its reservation" (paged maps; see free_list_kernel)
     float* d_hres = nullptr;        // the same memory as the device sees it
     uint32_t res_seq = 0;
     float* res_dev = nullptr;       // device copy of the payload (what the ranks all-gather)
@@ -71,6 +72,10 @@ struct slam_pf {
     int32_t* page_scratch = nullptr;   // tpage[nb] | tindex[nb] | count | the free list's bookkeeping (pool_state_words())
     bool gated = false;             // cfg.resample_ess_frac in (0, 1): a frame resamples only when its ESS is low
     int64_t frames_resampled = 0;   // (as far as the host has looked: one frame behind)
+    bool counted = false;           // this session holds the engine's one session slot
+    bool last_ekf = false;          // the last frame ran the landmark update (its log-likelihoods are in the engine)
+    int32_t* sel = nullptr;         // grow-only scratch of slam_pf_get_map_rows_host: chosen particles | their source rows
+    int sel_cap = 0;
 };
 
 namespace {
@@ -130,7 +135,8 @@ int migrate(slam_pf* pf)
         // fresh pages for the received rows (a new free list first if the old one runs short), table rows n .. n + rtot - 1
         int32_t* pstate = pf->page_scratch + 2 * pf->nb + 1;
         SLAM_HIP_TRY(e, launch_pool_reserve(e->stream, pstate, rtot * pf->nb));
-        SLAM_HIP_TRY(e, launch_free_list(e->stream, pf->stamp, pf->npages, pf->stamp_now, pf->freelist, pstate));
+        SLAM_HIP_TRY(e, launch_free_list(e->stream, pf->stamp, pf->npages, pf->stamp_now, pf->freelist, pstate,
+                                         reinterpret_cast<int32_t*>(pf->d_hres) + 20));
         SLAM_HIP_TRY(e, launch_migrate_unpack_paged(e->stream, pf->rbuf, (int)rtot, n, pf->pose_stage, pf->cap, pf->pool,
                                                     pf->pt[pf->pt_cur], pf->nb, L, pf->freelist, pstate, pf->stamp,
                                                     pf->stamp_now));
@@ -188,9 +194,14 @@ int gathered_copy_out(slam_pf* pf, const float* d_src, const int32_t* idx, float
 
 int create_common(slam_engine* e, const slam_pf_config* cfg, slam_comm* comm, int recv_capacity, slam_pf** out)
 {
-    if (!e || !cfg || !out || cfg->n_particles <= 0 || cfg->n_landmarks < 0 || !(cfg->meas_var > 0.0f))
+    if (!e || !cfg || !out || cfg->n_particles <= 0 || cfg->n_landmarks < 0 || !(cfg->meas_var > 0.0f) ||
+        cfg->map_layout < SLAM_MAP_AUTO || cfg->map_layout > SLAM_MAP_PAGES)
         return SLAM_ERR_INVALID_ARG;
     *out = nullptr;
+    if (e->live_sessions > 0) {   // the stages keep per-population state in the engine (gate, carried weights, exchange plan)
+        snprintf(e->err, sizeof e->err, "this engine already runs a particle-filter session: one session per engine");
+        return SLAM_ERR_NOT_READY;
+    }
     if (comm && comm_engine(comm) != e) return SLAM_ERR_INVALID_ARG;
     if (int rc = slam_engine_sync(e)) return rc;   // also selects the engine's device
     slam_pf* pf = new (std::nothrow) slam_pf();
@@ -214,11 +225,11 @@ int create_common(slam_engine* e, const slam_pf_config* cfg, slam_comm* comm, in
     }
     const size_t n = (size_t)pf->n, L = (size_t)pf->L, Lp = (size_t)pf->Lp, cap = (size_t)pf->cap, G = (size_t)pf->world;
     bool ok = true;
-    pf->paged = e->pf_paged && pf->L > 0;
+    pf->paged = pf->L > 0 && (cfg->map_layout == SLAM_MAP_PAGES || (cfg->map_layout == SLAM_MAP_AUTO && e->pf_paged));
     if (pf->paged) {
         pf->nb = pf->Lp / kPageLandmarks;
         const int64_t np = 2 * (int64_t)pf->cap * pf->nb;   // table rows (with the staging tail) never name more than half
-        if (np > 0x7fffffff) {
+        if (np > 0x7fffffff - 8192) {   // page numbers are int32, and free_list_kernel's last tile may look 8191 past the end
             delete pf;
             return SLAM_ERR_CAPACITY;
         }
@@ -271,6 +282,8 @@ int create_common(slam_engine* e, const slam_pf_config* cfg, slam_comm* comm, in
         slam_pf_destroy(pf);
         return rc;
     }
+    e->live_sessions++;
+    pf->counted = true;
     *out = pf;
     return SLAM_OK;
 }
@@ -294,6 +307,7 @@ int slam_pf_destroy(slam_pf* pf)
 {
     if (!pf) return SLAM_OK;
     (void)slam_engine_sync(pf->e);
+    if (pf->counted) pf->e->live_sessions--;
     if (pf->comm) {
         (void)comm_all_gather_finish(pf->comm);
         (void)slam_engine_sync(pf->e);
@@ -311,7 +325,7 @@ int slam_pf_destroy(slam_pf* pf)
                      (void*)pf->rbuf, (void*)pf->res_dev, (void*)pf->sums_acc, pf->res_all })
         (void)hipFree(p);
     for (void* p : { (void*)pf->pool, (void*)pf->pt[0], (void*)pf->pt[1], (void*)pf->freelist, (void*)pf->stamp,
-                     (void*)pf->page_scratch })
+                     (void*)pf->page_scratch, (void*)pf->sel })
         (void)hipFree(p);
     if (pf->h_res) (void)hipHostFree(pf->h_res);
     delete pf;
@@ -409,6 +423,10 @@ int slam_pf_step(slam_pf* pf, int slot, const float dp[3], int use_observations)
     if (!pf || !dp) return SLAM_ERR_INVALID_ARG;
     slam_engine* e = pf->e;
     slam_comm* comm = pf->comm;
+    if (pf->paged && __atomic_load_n(reinterpret_cast<int32_t*>(pf->h_res) + 20, __ATOMIC_ACQUIRE) != 0) {
+        snprintf(e->err, sizeof e->err, "paged maps: a free list was shorter than the pages reserved from it (pool invariant broken)");
+        return SLAM_ERR_CAPACITY;
+    }
     const int n = pf->n, L = pf->L, cur = pf->cur, nxt = 1 - cur;
     const size_t sn = (size_t)n;
     const float* src = pf->pose[cur];
@@ -456,7 +474,8 @@ int slam_pf_step(slam_pf* pf, int slot, const float dp[3], int use_observations)
             int32_t *tpage = pf->page_scratch, *tindex = tpage + pf->nb, *count = tindex + pf->nb, *pstate = count + 1;
             SLAM_HIP_TRY(e, launch_page_list(e->stream, e->d_obs_zx, e->d_obs_zy, L, pf->nb, tpage, tindex, count, n, pstate));
             // a new free list when the old one runs short (decided on the device; the pages in use carry the last stamp)
-            SLAM_HIP_TRY(e, launch_free_list(e->stream, pf->stamp, pf->npages, pf->stamp_now, pf->freelist, pstate));
+            SLAM_HIP_TRY(e, launch_free_list(e->stream, pf->stamp, pf->npages, pf->stamp_now, pf->freelist, pstate,
+                                             reinterpret_cast<int32_t*>(pf->d_hres) + 20));
             PagedEkfArgs a;
             a.pool = pf->pool;
             a.pt_in = pf->pt[pc];
@@ -539,6 +558,7 @@ int slam_pf_step(slam_pf* pf, int slot, const float dp[3], int use_observations)
     }
     pf->cur = nxt;
     pf->has_anc = true;
+    pf->last_ekf = ekf;
     pf->frame++;
     return SLAM_OK;
 }
@@ -557,6 +577,26 @@ int slam_pf_device_view(slam_pf* pf, slam_pf_view* out)
     out->row_stride = 5 * (int64_t)pf->Lp;
     out->plane_stride = pf->Lp;
     out->map_rows = pf->cap;
+    out->score = pf->has_anc ? pf->score : nullptr;
+    out->logw = pf->has_anc ? pf->logw : nullptr;
+    out->loglik = pf->has_anc && pf->last_ekf && pf->e->ll_n == pf->n ? pf->e->ll_buf.as<float>() : nullptr;
+    return SLAM_OK;
+}
+
+int slam_pf_paged_device_view(slam_pf* pf, slam_pf_paged_view* out)
+{
+    if (!pf || !out) return SLAM_ERR_INVALID_ARG;
+    if (!pf->paged) return SLAM_ERR_NOT_READY;
+    out->pool = pf->pool;
+    out->table = pf->pt[pf->pt_cur];
+    out->freelist = pf->freelist;
+    out->state = pf->page_scratch + 2 * pf->nb + 1;
+    out->stamp = pf->stamp;
+    out->stamp_now = pf->stamp_now;
+    out->page_landmarks = kPageLandmarks;
+    out->pages_per_particle = pf->nb;
+    out->table_rows = pf->cap;
+    out->npages = pf->npages;
     return SLAM_OK;
 }
 
@@ -682,6 +722,48 @@ int slam_pf_get_map_host(slam_pf* pf, float* rows)
     }
     if (int rc = slam_engine_sync(pf->e)) return rc;
     return hipMemcpy2D(rows, L * 4, src, Lp * 4, L * 4, 5 * n, hipMemcpyDeviceToHost) == hipSuccess ? SLAM_OK : SLAM_ERR_HIP;
+}
+
+int slam_pf_get_map_rows_host(slam_pf* pf, const int32_t* particle, int count, float* rows)
+{
+    if (!pf || !pf->L || count < 0 || (count > 0 && (!particle || !rows))) return SLAM_ERR_INVALID_ARG;
+    for (int k = 0; k < count; ++k)
+        if (particle[k] < 0 || particle[k] >= pf->n) return SLAM_ERR_INVALID_ARG;
+    slam_engine* e = pf->e;
+    if (pf->comm)
+        if (int rc = finish_exchange(pf)) return rc;   // collective: remote ancestors' rows into the staging tail
+    if (count == 0) return SLAM_OK;
+    SLAM_HIP_TRY(e, hipSetDevice(e->device));
+    if (pf->sel_cap < count) {
+        SLAM_HIP_TRY(e, hipStreamSynchronize(e->stream));
+        if (pf->sel) (void)hipFree(pf->sel);
+        pf->sel = nullptr;
+        pf->sel_cap = 0;
+        SLAM_HIP_TRY(e, hipMalloc((void**)&pf->sel, 2 * sizeof(int32_t) * (size_t)count));
+        pf->sel_cap = count;
+    }
+    const size_t L = (size_t)pf->L, Lp = (size_t)pf->Lp;
+    float* dense = nullptr;
+    SLAM_HIP_TRY(e, hipMalloc((void**)&dense, 5 * Lp * (size_t)count * 4));
+    int32_t *sel = pf->sel, *src = pf->sel + pf->sel_cap;
+    int rc = SLAM_OK;
+    auto ok = [&](hipError_t err, const char* what) {
+        if (err != hipSuccess && rc == SLAM_OK) rc = slam_engine_fail_hip(e, err, what);
+        return err == hipSuccess;
+    };
+    if (ok(hipMemcpyAsync(sel, particle, sizeof(int32_t) * (size_t)count, hipMemcpyHostToDevice, e->stream), "copy of the particle list") &&
+        ok(launch_compose_index(e->stream, sel, pf->has_anc ? pf->anc[pf->cur] : nullptr, count, src), "compose_index")) {
+        if (pf->paged)
+            ok(launch_rows_from_pages(e->stream, pf->pool, pf->pt[pf->pt_cur], pf->nb, src, count, dense, 5 * (int64_t)Lp, pf->Lp, pf->L),
+               "rows_from_pages");
+        else
+            ok(launch_gather_map(e->stream, pf->map[pf->map_cur], dense, 5 * (int64_t)Lp, 5 * (int64_t)Lp, pf->Lp, pf->Lp, pf->L, src,
+                                 count), "gather_map");
+    }
+    if (rc == SLAM_OK) ok(hipStreamSynchronize(e->stream), "hipStreamSynchronize");
+    if (rc == SLAM_OK) ok(hipMemcpy2D(rows, L * 4, dense, Lp * 4, L * 4, 5 * (size_t)count, hipMemcpyDeviceToHost), "hipMemcpy2D");
+    (void)hipFree(dense);
+    return rc;
 }
 
 }  // extern "C"

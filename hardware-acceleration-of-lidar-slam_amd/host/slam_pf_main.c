@@ -99,7 +99,7 @@ static void *rank_main(void *arg)
         }
     }
     /* motion noise of the order of the reference's fine lattice step (0.025 m, 0.004363 rad; main.c:833) */
-    const slam_pf_config cfg = { n, 0, { 0.01f, 0.01f, 0.002f }, 1.0f, 0.25f, run->seed, run->ess_frac };
+    const slam_pf_config cfg = { n, 0, { 0.01f, 0.01f, 0.002f }, 1.0f, 0.25f, run->seed, run->ess_frac, SLAM_MAP_AUTO };
     if (world > 1 || run->use_rccl || run->group) {
         if (run->group) CHECK(slam_comm_create_local(eng, run->group, rank, &comm));
         else CHECK(slam_comm_create_rccl(eng, rank, world, run->comm_id, &comm));

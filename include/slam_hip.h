@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define SLAM_ABI_VERSION 2
+#define SLAM_ABI_VERSION 3
 
 typedef enum {
     SLAM_OK = 0,
@@ -369,7 +369,13 @@ typedef struct {
     float score_gain;      /* logw = loglik - score_gain * score */
     uint64_t seed;
     float resample_ess_frac;   /* in (0, 1): resample only when ESS < frac * N (slam_resample_gate_set); 0 = every frame */
+    int32_t map_layout;        /* slam_map_layout: how the landmark maps are kept (0 = SLAM_MAP_AUTO) */
 } slam_pf_config;
+/* Landmark maps: ONE ROW PER PARTICLE (a resampling frame rewrites every row in full: the fastest form when a frame
+ * observes most landmarks) or COPY-ON-WRITE PAGES behind a page table per particle (a resampling frame copies table
+ * entries and rewrites only the pages that hold an observed landmark: the fastest form when a frame observes few of
+ * many).  Both give the same bits.  SLAM_MAP_AUTO lets the session choose and change its mind while it runs. */
+typedef enum { SLAM_MAP_AUTO = 0, SLAM_MAP_ROWS = 1, SLAM_MAP_PAGES = 2 } slam_map_layout;
 
 int slam_pf_create(slam_engine *e, const slam_pf_config *cfg, slam_pf **out);
 
@@ -421,13 +427,15 @@ int slam_pf_set_poses_host(slam_pf *pf, const float *x, const float *y, const fl
 int slam_pf_set_map_host(slam_pf *pf, const float *rows /* [n_particles][5][n_landmarks] */);
 /* the same from device memory: rows [n_particles][5 planes][plane_stride] floats, row_stride floats apart; asynchronous */
 int slam_pf_set_map_dev(slam_pf *pf, const float *d_rows, int64_t row_stride, int plane_stride);
-/* Paged maps.  A session made after slam_pf_paged_set(e, 1) keeps every particle's landmarks behind a page
- * table — pages of 32 landmarks (640 bytes), shared between the offspring of an ancestor until one of them is written:
- * a resample copies 4 bytes per 32 landmarks, and a frame's update rewrites only the pages that hold an observed
- * landmark.  For frames that observe few of many landmarks (a row per particle rewrites every row on every resampling
- * frame); results are bit-identical to a row-per-particle session.  Such a session has no rows to look at:
- * slam_pf_device_view gives map = NULL, maps go in and out through slam_pf_set_map_* / slam_pf_get_map_host.
- * Sharded sessions work the same way (a migrating particle travels with all its pages, as a row does). */
+/* Paged maps (SLAM_MAP_PAGES): every particle's landmarks sit behind a page table — pages of 32 landmarks (640 bytes),
+ * shared between the offspring of an ancestor until one of them is written: a resample copies 4 bytes per 32 landmarks,
+ * and a frame's update rewrites only the pages that hold an observed landmark.  For frames that observe few of many
+ * landmarks (a row per particle rewrites every row on every resampling frame); results are bit-identical to a
+ * row-per-particle session.  While a session is on pages it has no rows to look at: slam_pf_device_view gives map = NULL,
+ * maps go in and out through slam_pf_set_map_* / slam_pf_get_map_host / slam_pf_get_map_rows_host.  Sharded sessions work
+ * the same way (a migrating particle travels with all its pages, as a row does).
+ * slam_pf_paged_set(e, 1): sessions created on this engine from now on with map_layout = SLAM_MAP_AUTO are kept on pages
+ * (as if created with SLAM_MAP_PAGES); 0 restores AUTO's own choice.  slam_pf_is_paged: the layout right now. */
 int slam_pf_paged_set(slam_engine *e, int on);
 int slam_pf_is_paged(const slam_pf *pf);
 /* one frame against grid `slot`; asynchronous */
@@ -460,11 +468,36 @@ typedef struct {
     const int32_t *anc;
     int64_t row_stride;
     int32_t plane_stride, map_rows;   /* map_rows = n_particles + staging rows (sharded) */
+    /* what the last slam_pf_step left behind, indexed like `pose` (i.e. BEFORE the pending gather): the scan-match
+     * score, the log-weight and — when that frame used observations, else NULL — the EKF log-likelihood of every
+     * particle; NULL before the first frame */
+    const float *score, *logw, *loglik;
 } slam_pf_view;
 int slam_pf_device_view(slam_pf *pf, slam_pf_view *out);
 /* current particles with the pending resample gather applied; synchronises */
 int slam_pf_get_poses_host(slam_pf *pf, float *x, float *y, float *theta);
 int slam_pf_get_map_host(slam_pf *pf, float *rows /* [n_particles][5][n_landmarks] */);
+/* The maps of SOME particles (a host usually wants the heaviest particle's map, not a million of them):
+ * rows[k] = the landmarks of current particle particle[k] (0 <= particle[k] < n_particles, repeats allowed), pending
+ * gather applied, whatever the layout; synchronises.  Sharded: collective like slam_pf_get_map_host (the exchange of
+ * the last frame is completed first), indices are local. */
+int slam_pf_get_map_rows_host(slam_pf *pf, const int32_t *particle, int count, float *rows /* [count][5][n_landmarks] */);
+
+/* Inspection of a session that is on pages right now (tests, debugging; SLAM_ERR_NOT_READY when it is on rows).  Device
+ * pointers into the session's own state, valid until the next slam_pf_* call that changes the layout:
+ *   pool[npages][5][page_landmarks]  the pages;  table[table_rows][pages_per_particle]: page of (particle, block) for the
+ *   CURRENT particles before the pending gather (rows n_particles .. table_rows - 1: staging rows of a sharded session);
+ *   stamp[npages]: pages named by the current tables carry stamp_now;  freelist[]: entries [state[1], state[0]) are pages
+ *   nobody names, entries [state[3], state[1]) were handed out by the last update;  state = {free, used, renewed, base}. */
+typedef struct {
+    const float *pool;
+    const int32_t *table, *freelist, *state;
+    const uint32_t *stamp;
+    uint32_t stamp_now;
+    int32_t page_landmarks, pages_per_particle, table_rows;
+    int64_t npages;
+} slam_pf_paged_view;
+int slam_pf_paged_device_view(slam_pf *pf, slam_pf_paged_view *out);
 
 /* ------------------------------------------------------------------ mapper: the reference's frame loop in one call
  * (SURVEY.md §8f rows N1 + N2).  One slam_mapper_next_frame = one iteration of the reference's loop
