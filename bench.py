@@ -1,18 +1,23 @@
 #!/usr/bin/env python3
 """bench.py — particle-updates/s of the particle-filter frame loop on synthetic 360-beam scans.
 
-    python bench.py [--gpus N --steps K --warmup W]                 (N = 1)
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-           --master-port P bench.py --gpus N --steps K --warmup W    (N > 1, one rank per GPU, RCCL)
+    python bench.py [--gpus N --steps K --warmup W]
+        N = 1: this process.  N > 1 without a launcher: bench.py starts `python -m torch.distributed.run --nnodes=1
+        --nproc-per-node N --master-addr 127.0.0.1 ...` on itself BEFORE anything touches the GPU and relays rank 0's line.
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W           (the driver's form: one rank per GPU, RCCL over xGMI)
+    python bench.py --gpus N --transport local [--device-index 0]
+        rehearsal: N ranks as threads of this process sharing ONE card through the in-process transport
+        (slam_comm_create_local) — the whole sharded code path except RCCL itself; the number it prints is not a
+        scaling figure (the ranks share a GPU).
 
-A "step" is one whole frame of the hot path over one batch of synthetic input: motion sample ->
-scan-match score (the reference's FastMatch inner loop, Subsystem_1/main.c:459-518, for every
-particle) -> per-particle x per-landmark 2x2 EKF over ALL landmarks -> weight normalisation ->
-systematic resample (gathers fused into the next frame's motion/EKF kernels) -> migration between
-GPUs.  Workload = BASELINE.json configs[1] per GPU: 65536 particles, 360 beams, 500 landmarks,
-1024 x 1024 EDT grid; weak scaling (per-GPU work fixed).  Particles, maps, EDT and scan are resident
-in HBM when the timed region starts, and so is the sensor data of every frame (360 beams + 500
-observations = 8.9 KB per frame; --host-sensor sends it over PCIe frame by frame instead).
+A "step" is one whole frame of the hot path over one batch of synthetic input — ONE call into the C session
+(slam_pf_step): motion sample -> scan-match score (the reference's FastMatch inner loop, Subsystem_1/main.c:459-518, for
+every particle) -> per-particle x per-landmark 2x2 EKF -> weight normalisation -> systematic resample (gathers fused into
+the next frame's motion / EKF kernels) -> exchange between GPUs.  Workload = BASELINE.json configs[1] per GPU: 65536
+particles, 360 beams, 500 landmarks all observed, 1024 x 1024 EDT grid; weak scaling (per-GPU work fixed) unless
+--scaling strong.  Particles, maps, EDT and scan are resident in HBM when the timed region starts, and so is the sensor
+data of every frame (--host-sensor sends its 8.9 KB over PCIe frame by frame instead).
 value = N_total_particles * K / max-over-ranks wall time.
 
 Other workloads (never the default; used to fill BASELINE.md):
@@ -20,25 +25,34 @@ Other workloads (never the default; used to fill BASELINE.md):
     --mode ekf     EKF sweep only (north-star roofline case: --particles 1048576 --landmarks 1000)
     --scaling strong --particles-total 1048576 --landmarks 1000
                    the north-star target: N ranks split the SAME problem (what ">= 6x at 8 GPUs" is defined on)
+    --observed 32 [--map-layout rows|pages|auto]   the K-nearest end-to-end variant of SURVEY 8(d)
 
-One JSON line on stdout (rank 0), including
-  roofline     — dominant kernel: launch duration from HIP events recorded on the kernel's own stream inside the
-                 timed region (slam_profile_* in the C ABI).  `achieved` is the HBM traffic rate when the PMC traffic of
-                 this workload is on file (profiles/traffic.json), else the algorithmic-byte rate; `logical_rate_gbs` is
-                 always the algorithmic-byte rate (40 B per particle and OBSERVED landmark); `no_reuse` is a
-                 short sweep of the same kernel on the same buffers with identity ancestors, run after the timed region
-                 (nothing comes out of L2 there: the streaming figure); `read_only_frac` is the north star's definition
-                 (20 B x n x L_observed / t / peak) on that sweep
-  cpu_baseline — the CPU port of the same frame loop (oracle/, single thread) timed on this host
-                 on a bounded sample (rank 0, N = 1 only); cpu_baseline_threads: the same port with its per-particle
-                 stages on up to 16 host threads (SURVEY 8d's optional "all cores" line), about 8 s more
+One JSON line on stdout (rank 0).  Beyond the contract's fields:
+  roofline      dominant kernel of the timed region: launch duration from HIP events on the kernel's own stream
+                (slam_profile_*).  `achieved` names its basis and the kernel it belongs to (`achieved_basis`,
+                `achieved_kernel`): HBM traffic from a PMC record of this workload and kernel (profiles/traffic.json)
+                over the live duration; else the no-reuse sweep; else algorithmic bytes.  `logical_rate_gbs` is always
+                SURVEY 8(d)'s algorithmic bytes over the live duration.
+  stage_avg_ms  every stage of a frame through the ABI's per-stage timers (a short pass after the timed region)
+  north_star, copy_ceiling, end_to_end_obs32   (N = 1, default workload) bounded extra legs after the timed region:
+                the EKF sweep at 1 048 576 x 1 000, a pure copy of the same shape, and the configs[1] frame with the 32
+                nearest landmarks observed on rows and on pages.  They never touch `value`.
+  cpu_baseline  the CPU port of the same frame loop (oracle/, one thread) on a bounded sample; cpu_baseline_threads:
+                its per-particle stages on up to 16 host threads; cpu_baseline_main_c: the reference's own pipeline
+                (main.c rows A1-A8) on this host's CPU — the compiled reference when oracle/_ref/ travelled here, and
+                the oracle's restatement — beside the engine's drop-in programs on the same scans.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import re
+import socket
+import subprocess
 import sys
+import tempfile
+import threading
 import time
 from pathlib import Path
 
@@ -52,6 +66,7 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured
 # synthetic world: 15 x 11 m room with two boxes, in the reference's pose convention
 ROOM = (-3.0, -5.5, 12.0, 5.5)
 BOXES = [(5.0, 2.0, 7.0, 3.5), (2.0, -4.0, 3.0, -3.0)]
+SIGMA, MEAS_VAR, SCORE_GAIN = (0.01, 0.01, 0.002), 0.02 ** 2 * 4, 0.02
 
 
 def raycast(px, py, ang):
@@ -134,6 +149,37 @@ def make_frames(nframes, nbeams, landmarks, rng, observed=0):
     return frames
 
 
+def make_landmarks(L, rng):
+    lm = np.stack([rng.uniform(ROOM[0] + 0.5, ROOM[2] - 0.5, L), rng.uniform(ROOM[1] + 0.5, ROOM[3] - 0.5, L)], 1)
+    if L:   # landmark ids in discovery order along a sweep of the room: neighbours in space are neighbours in the map rows
+        lm = lm[np.argsort(morton(lm), kind="stable")]
+    return lm
+
+
+def build_inputs(args):
+    """Everything synthetic, as numpy (identical on every rank; made once per process)."""
+    rng = np.random.default_rng(4321)
+    L = 0 if args.mode == "score" else args.landmarks
+    landmarks = make_landmarks(L, rng)
+    pixel = np.float32(20.48 / args.grid)
+    min_x, min_y = np.float32(-4.24), np.float32(-10.24)
+    occ = occupancy(args.grid, float(pixel), float(min_x), float(min_y))
+    nframes = args.steps + args.warmup + 12   # + the short per-stage timing pass after the timed region
+    frames = make_frames(nframes, args.beams, landmarks, rng, args.observed)
+    return dict(L=L, landmarks=landmarks, pixel=pixel, min_x=min_x, min_y=min_y, occ=occ, frames=frames)
+
+
+# ------------------------------------------------------------------------------------------------ CPU baselines
+def host_cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(args, occ, meta_t, frames, landmarks, budget_s=12.0):
     """The CPU port (oracle/, TEST INFRASTRUCTURE used here only as the reported baseline): the same
     frame loop, single thread, on a bounded sample of the workload."""
@@ -160,28 +206,20 @@ def cpu_baseline(args, occ, meta_t, frames, landmarks, budget_s=12.0):
     t0 = time.perf_counter()
     while True:
         fr = frames[done % len(frames)]
-        x, y, th = oracle.motion_sample(x, y, th, anc, n, 0, fr["dp"], args.sigma, 1234, done)
+        x, y, th = oracle.motion_sample(x, y, th, anc, n, 0, fr["dp"], SIGMA, 1234, done)
         score, _ = oracle.score_poses_det(m, edt, fr["bx"], fr["by"], x, y, th)
         ll = None
         if L and args.mode != "score":
-            mp, ll = oracle.ekf_update(mp, x, y, th, anc, fr["ids"], fr["zx"], fr["zy"], args.meas_var)
-        logw, mx = oracle.logweight(score, ll, args.score_gain)
+            mp, ll = oracle.ekf_update(mp, x, y, th, anc, fr["ids"], fr["zx"], fr["zy"], MEAS_VAR)
+        logw, mx = oracle.logweight(score, ll, SCORE_GAIN)
         wq, _ = oracle.quantise_weights(logw, mx)
         anc = oracle.resample(wq, 1234, done)
         done += 1
         el = time.perf_counter() - t0
         if el > budget_s and done >= 3:
             break
-    model = "unknown"
-    try:
-        for ln in open("/proc/cpuinfo"):
-            if ln.startswith("model name"):
-                model = ln.split(":", 1)[1].strip()
-                break
-    except OSError:
-        pass
     return {"value": n * done / el, "unit": "particle-updates/s", "cores": 1, "kind": "port",
-            "host_cpu": model, "host_cores_total": os.cpu_count(),
+            "host_cpu": host_cpu_model(), "host_cores_total": os.cpu_count(),
             "sample": f"{n} particles x {done} frames of the same workload ({args.beams} beams, {L} landmarks, "
                       f"{args.grid}^2 EDT), oracle/ C port, 1 thread, {el:.1f} s"}
 
@@ -223,7 +261,7 @@ def cpu_baseline_threads(args, occ, meta_t, frames, landmarks, budget_s=8.0):
         sl = slice(c * per, (c + 1) * per)
         a = None if anc is None else anc[sl]
         src = pose if a is not None else [p[sl] for p in pose]   # ancestors index the whole population
-        x, y, th = oracle.motion_sample(src[0], src[1], src[2], a, per, c * per, fr["dp"], args.sigma, 1234, frame)
+        x, y, th = oracle.motion_sample(src[0], src[1], src[2], a, per, c * per, fr["dp"], SIGMA, 1234, frame)
         for k, v in enumerate((x, y, th)):
             new[k][sl] = v
         score[sl] = oracle.score_poses_det(m, edt, fr["bx"], fr["by"], x, y, th)[0]
@@ -232,7 +270,7 @@ def cpu_baseline_threads(args, occ, meta_t, frames, landmarks, budget_s=8.0):
             lib.orc_ekf_update(mp if a is not None else mp[sl], mp2[sl], 5 * L, L, L, x, y, th,
                                a.ctypes.data_as(C.c_void_p) if a is not None else None, per, ids,
                                np.ascontiguousarray(fr["zx"], np.float32), np.ascontiguousarray(fr["zy"], np.float32), len(ids),
-                               args.meas_var, ll[sl])
+                               MEAS_VAR, ll[sl])
 
     with ThreadPoolExecutor(T) as pool:
         t0 = time.perf_counter()
@@ -244,7 +282,7 @@ def cpu_baseline_threads(args, occ, meta_t, frames, landmarks, budget_s=8.0):
                 mp, mp2 = mp2, mp
             elif L and anc is not None:
                 mp = mp[anc]
-            logw, mx = oracle.logweight(score, ll if use_ekf else None, args.score_gain)
+            logw, mx = oracle.logweight(score, ll if use_ekf else None, SCORE_GAIN)
             wq, _ = oracle.quantise_weights(logw, mx)
             anc = np.ascontiguousarray(oracle.resample(wq, 1234, done), np.int32)
             done += 1
@@ -254,6 +292,60 @@ def cpu_baseline_threads(args, occ, meta_t, frames, landmarks, budget_s=8.0):
     return {"value": n * done / el, "unit": "particle-updates/s", "cores": T, "kind": "port",
             "sample": f"{n} particles x {done} frames of the same workload, oracle/ C port, per-particle stages on {T} host "
                       f"threads (weights and resample on one), {el:.1f} s"}
+
+
+def cpu_baseline_main_c():
+    """SURVEY 8(d)'s CPU baseline of the reference's OWN pipeline (main.c rows A1-A8: parse, clean-up, transform, local
+    map, raster, EDT, 27-pose matcher x 10, key-frame test, map append) on this host, one thread, on the 1000-frame
+    synthetic parity set (regenerated here by oracle/gen_dataset, libm-free, 1079 beams) — beside the engine's two
+    drop-in programs on the same scans in the same run.  `main_cpu` is the oracle's restatement (kind "port") with the
+    reference's naive EDT (main.c:223-269) and with the scatter EDT (main_accelerated.c:215-283); `reference` is the
+    compiled, unmodified main.c when oracle/_ref/main_ref travelled to this box.  One scan = 270 pose evaluations
+    (2 matcher calls x 5 passes x 27 candidates)."""
+    import oracle
+
+    out = {"dataset": "synthetic parity set, 1000 frames x 1079 beams (oracle/gen_dataset)", "cores": 1,
+           "host_cpu": host_cpu_model(), "pose_evals_per_scan": 270}
+    pat = re.compile(r"frames (\d+)\s+wall ([\d.]+) s(?:\s+edt ([\d.]+) s / (\d+) calls\s+match ([\d.]+) s / (\d+) calls)?")
+    with tempfile.TemporaryDirectory() as td:
+        csv, mp = Path(td) / "parity.csv", Path(td) / "map.csv"
+        info = json.loads((ROOT / "tests" / "golden" / "datasets.json").read_text())["parity"]
+        oracle.run_tool("gen_dataset", csv, *info["gen_args"])
+
+        def parse(stderr):
+            m = pat.search(stderr)
+            if not m:
+                return None
+            frames, wall = int(m.group(1)), float(m.group(2))
+            r = {"frames": frames, "wall_s": wall, "scans_per_s": (frames - 1) / wall, "pose_evals_per_s": 270 * (frames - 1) / wall}
+            if m.group(3):
+                r["edt_ms_per_call"] = 1e3 * float(m.group(3)) / max(int(m.group(4)), 1)
+                r["match_ms_per_call"] = 1e3 * float(m.group(5)) / max(int(m.group(6)), 1)
+            return r
+
+        for variant, name in ((0, "naive"), (1, "scatter")):
+            r = oracle.run_tool("main_cpu", csv, 1000, 1079, variant, mp, capture_output=True, text=True)
+            out[f"main_cpu_{name}_edt"] = parse(r.stderr)
+        naive, scat = out["main_cpu_naive_edt"], out["main_cpu_scatter_edt"]
+        out.update({"kind": "port", "scans_per_s": naive["scans_per_s"], "pose_evals_per_s": naive["pose_evals_per_s"],
+                    "edt_ms_per_call_naive": naive["edt_ms_per_call"], "edt_ms_per_call_scatter": scat["edt_ms_per_call"]})
+        ref = ROOT / "oracle" / "_ref" / "main_ref"
+        if ref.exists():   # the reference itself, compiled in the build container from the sources where they lie
+            t0 = time.perf_counter()
+            r = subprocess.run([str(ref)], env=dict(os.environ, ORACLE_DATASET=str(csv), ORACLE_MAP_OUT=str(mp)),
+                               capture_output=True, text=True)
+            wall = time.perf_counter() - t0
+            if r.returncode == 0:
+                out["reference"] = {"kind": "reference", "program": "Subsystem_1/main.c (gcc -O2, unmodified)", "frames": 1000,
+                                    "wall_s": wall, "scans_per_s": 999 / wall, "pose_evals_per_s": 270 * 999 / wall}
+        exe = ROOT / "hardware-acceleration-of-lidar-slam_amd" / "lib" / "slam_main"
+        for flag, name in ((None, "slam_main"), ("--mapper", "slam_main_mapper")):
+            cmd = [str(exe)] + ([flag] if flag else []) + [str(csv), "1000", "1079", str(mp)]
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            out[name] = parse(r.stderr) if r.returncode == 0 else {"error": r.stderr.strip()[-200:]}
+        if out.get("slam_main") and "scans_per_s" in out["slam_main"]:
+            out["drop_in_speedup_vs_main_cpu"] = out["slam_main"]["scans_per_s"] / naive["scans_per_s"]
+    return out
 
 
 class stdout_to_stderr:
@@ -271,7 +363,515 @@ class stdout_to_stderr:
         return False
 
 
-def main():
+# ------------------------------------------------------------------------------------------------ ranks
+class SingleCtx:
+    """One rank in this process; torch.distributed only when torchrun started several of us."""
+    threads = False
+
+    def __init__(self, args):
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.dev_index = local_rank if args.device_index is None else args.device_index
+        self.transport = "rccl"
+        self.dist = None
+
+    def init(self, torch, dev):
+        if self.world > 1:
+            import torch.distributed as dist
+
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            with stdout_to_stderr():
+                dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=dev)
+                dist.barrier()   # RCCL initialises lazily: do it (and print its banner) here, not in the timed region
+            self.dist = dist
+        self.torch, self.dev = torch, dev
+
+    def make_comm(self, pkg, eng, force):
+        if self.world == 1 and not force:
+            return None
+        # rendezvous token of the engine's own RCCL communicator: made by rank 0, handed out through the process group
+        # torchrun set up (used for nothing else but this, the barriers and the final timing reduction)
+        torch = self.torch
+        uid = torch.zeros(pkg.COMM_ID_BYTES, dtype=torch.uint8, device=self.dev)
+        if self.rank == 0:
+            uid = torch.tensor(list(pkg.comm_unique_id()), dtype=torch.uint8, device=self.dev)
+        if self.world > 1:
+            self.dist.broadcast(uid, src=0)
+        with stdout_to_stderr():   # RCCL prints its version banner to stdout; stdout carries ONE JSON line
+            return pkg.Comm.rccl(eng, self.rank, self.world, bytes(uid.cpu().tolist()))
+
+    def barrier(self):
+        self.torch.cuda.synchronize()
+        if self.world > 1:
+            self.dist.barrier()
+            self.torch.cuda.synchronize()
+
+    def max_over_ranks(self, v):
+        if self.world == 1:
+            return float(v)
+        t = self.torch.tensor([v], dtype=self.torch.float64, device=self.dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t[0])
+
+    def finish(self):
+        if self.dist is not None and self.dist.is_initialized():
+            self.dist.destroy_process_group()
+
+
+class ThreadShared:
+    def __init__(self, pkg, world):
+        self.group = pkg.LocalGroup(world)
+        self.bar = threading.Barrier(world)
+        self.vals = [0.0] * world
+        self.lock = threading.Lock()
+        self.failed = False
+
+
+class ThreadCtx:
+    """One rank = one thread of this process; every rank on the same card, exchanges through slam_comm_create_local."""
+    threads = True
+    transport = "local (in-process, one card shared by all ranks)"
+
+    def __init__(self, args, rank, shared):
+        self.world, self.rank, self.shared = args.gpus, rank, shared
+        self.dev_index = 0 if args.device_index is None else args.device_index
+
+    def init(self, torch, dev):
+        self.torch, self.dev = torch, dev
+
+    def make_comm(self, pkg, eng, force):
+        return pkg.Comm.local(eng, self.shared.group, self.rank)
+
+    def barrier(self):
+        self.torch.cuda.synchronize()
+        self.shared.bar.wait(timeout=300)
+        self.torch.cuda.synchronize()
+
+    def max_over_ranks(self, v):
+        self.shared.vals[self.rank] = float(v)
+        self.shared.bar.wait(timeout=300)
+        m = max(self.shared.vals)
+        self.shared.bar.wait(timeout=300)
+        return m
+
+    def finish(self):
+        pass
+
+
+# ------------------------------------------------------------------------------------------------ one rank
+def fill_maps(torch, m0, landmarks, L, dev, n):
+    """Plausible maps [n][5][Lp]: every landmark near its true place with a loose covariance."""
+    lm = torch.from_numpy(landmarks.astype(np.float32)).to(dev)
+    for i0 in range(0, n, 65536):                     # in chunks: the temporaries of a 1M x 1k map are 4 GB each
+        i1 = min(i0 + 65536, n)
+        m0[i0:i1, 0, :L] = lm[:, 0] + 0.1 * torch.randn((i1 - i0, L), device=dev)
+        m0[i0:i1, 1, :L] = lm[:, 1] + 0.1 * torch.randn((i1 - i0, L), device=dev)
+    m0[:n, 2, :L] = 0.05
+    m0[:n, 3, :L] = 0.0
+    m0[:n, 4, :L] = 0.05
+
+
+def obs_tables(torch, frames, L, dev):
+    """Observation tables indexed by landmark, one per frame (NaN = not observed)."""
+    tab = np.full((len(frames), 2, L), np.nan, np.float32)
+    for k, f in enumerate(frames):
+        tab[k, 0, f["ids"]] = f["zx"]
+        tab[k, 1, f["ids"]] = f["zy"]
+    return torch.from_numpy(tab).to(dev)
+
+
+def run_rank(args, ctx, inp):
+    import torch
+
+    from __graft_entry__ import load_package
+
+    pkg = load_package()
+    world, rank = ctx.world, ctx.rank
+    if not torch.cuda.is_available():
+        sys.exit("bench.py: no GPU visible; the engine has no CPU fallback")
+    dev_index = ctx.dev_index
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    ctx.init(torch, dev)
+
+    eng = pkg.Engine(dev_index)
+    eng.ekf_form_set(args.ekf_form)
+    L, landmarks, frames = inp["L"], inp["landmarks"], inp["frames"]
+    pixel, min_x, min_y, occ = inp["pixel"], inp["min_x"], inp["min_y"], inp["occ"]
+
+    d_occ = torch.from_numpy(occ).to(dev)
+    d_edt = torch.empty((args.grid, args.grid), dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    eng.edt_dev(d_occ, args.grid, args.grid, args.grid, 10.0, d_edt)
+    meta = pkg.grid_meta(args.grid, args.grid, args.grid, pixel, min_x, min_y)
+    eng.grid_set_dev(0, d_edt, meta)
+
+    n = args.particles
+    comm = ctx.make_comm(pkg, eng, args.force_collectives)
+    pf = pkg.PfSession(eng, n, L, sigma=SIGMA, meas_var=MEAS_VAR, score_gain=SCORE_GAIN, seed=1234, comm=comm,
+                       resample_ess_frac=args.ess, map_layout=args.map_layout)
+    Lp = (L + 31) // 32 * 32
+
+    def views():
+        """(pose [3][n], current map [rows][5][Lp] or None, spare map, pending gather index or None) as torch tensors."""
+        v = pf.device_view()
+        t = {k: (torch.as_tensor(v[k], device=dev) if v[k] is not None else None) for k in ("pose", "map", "map_spare", "anc")}
+        return t["pose"], t["map"], t["map_spare"], t["anc"]
+
+    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    p0 = true_pose(0)
+    init = [(p0[k] + s * torch.randn(n, generator=g)).numpy() for k, s in ((0, 0.05), (1, 0.05), (2, 0.01))]
+    if args.presort_poses:
+        cell = 4.0 * float(pixel)
+        key = np.lexsort((np.floor(init[0] / cell), np.floor(init[1] / cell), np.floor(init[2] / (cell / 8.0))))
+        init = [a[key] for a in init]
+    pf.set_poses(*init)
+    if L:
+        rows_now = views()[1]
+        # a session on pages has no rows to write into: the same rows are made in a scratch tensor and handed over once
+        m0 = rows_now if rows_now is not None else torch.empty((n, 5, Lp), dtype=torch.float32, device=dev)
+        fill_maps(torch, m0, landmarks, L, dev, n)
+        if rows_now is None:
+            torch.cuda.synchronize()
+            pf.set_map_dev(m0, 5 * Lp, Lp)
+            eng.sync()
+        del m0, rows_now
+    score_t = torch.zeros(n, dtype=torch.float32, device=dev)
+    count_t = torch.zeros(n, dtype=torch.int32, device=dev)
+    loglik_t = torch.zeros(n, dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+
+    # sensor data of every frame resident in HBM before the timed region (bench contract); --host-sensor
+    # uploads it frame by frame through the host-buffer entry points instead (8.9 KB per frame over PCIe)
+    d_scan = torch.from_numpy(np.stack([np.stack([f["bx"], f["by"]]) for f in frames])).to(dev)        # [F][2][B]
+    d_z = obs_tables(torch, frames, L, dev) if L else None                                              # [F][2][L]
+    # per-frame views of the resident sensor data, made once (a tensor slice costs microseconds of host time)
+    scan_v = [(d_scan[k, 0], d_scan[k, 1]) for k in range(len(frames))]
+    obs_v = [(d_z[k, 0], d_z[k, 1]) for k in range(len(frames))] if L else None
+
+    sweep = {}
+
+    def one_step(k):
+        fr = frames[k]
+        if args.host_sensor:
+            eng.scan_upload(fr["bx"], fr["by"])
+            obs, obs_dev = ((fr["ids"], fr["zx"], fr["zy"]) if L else None), None
+        else:
+            eng.scan_set_dev(scan_v[k][0], scan_v[k][1], args.beams)
+            obs, obs_dev = None, (obs_v[k] if L else None)
+        if args.mode == "pf":
+            if obs_dev:
+                eng.obs_set_dev(*obs_dev, L)
+            elif obs:
+                eng.obs_upload(*obs, L)
+            pf.step(0, fr["dp"], L > 0)
+            return
+        if not sweep:
+            p, a, b, _ = views()
+            sweep.update(pose=p, maps=(a, b))
+        p = sweep["pose"]
+        if args.mode == "score":
+            eng.score_poses_dev(0, p[0], p[1], p[2], n, score_t, count_t)
+        else:   # ekf sweep: out of place, ping-pong between the two map buffers
+            if obs_dev:
+                eng.obs_set_dev(*obs_dev, L)
+            else:
+                eng.obs_upload(*obs, L)
+            eng.ekf_update_dev(sweep["maps"][k & 1], sweep["maps"][1 - (k & 1)], 5 * Lp, Lp, L, p[0], p[1], p[2], None, n,
+                               MEAS_VAR, loglik_t)
+
+    for k in range(args.warmup):
+        one_step(k)
+    ctx.barrier()
+    dominant = eng.PROF_SCORE if args.mode == "score" or L == 0 else eng.PROF_EKF
+    timed = {"dominant": (dominant,), "all": (eng.PROF_SCORE, eng.PROF_EKF), "none": ()}[args.events]
+    eng.profile_enable(*timed)
+    for kk in range(eng.PROF_COUNT):
+        eng.profile_read(kk)
+    migrated = 0
+    forms0 = eng.ekf_form_counts() + eng.ekf_inplace_form_counts()
+    t0 = time.perf_counter()
+    for k in range(args.warmup, args.warmup + args.steps):
+        one_step(k)
+        migrated += pf.rows_received() if args.mode == "pf" else 0
+    ctx.barrier()
+    elapsed = time.perf_counter() - t0
+    eng.profile_enable()
+    forms1 = eng.ekf_form_counts() + eng.ekf_inplace_form_counts()
+    forms = tuple(b - a for a, b in zip(forms0, forms1))   # EKF launches of the timed region, by kernel (out of place x2, in place x2)
+    paged_in_region = pf.is_paged()
+    elapsed = ctx.max_over_ranks(elapsed)
+    migrated = ctx.max_over_ranks(migrated / max(args.steps, 1))
+
+    score_ms, score_n = eng.profile_read(eng.PROF_SCORE)
+    ekf_ms, ekf_n = eng.profile_read(eng.PROF_EKF)
+    # A start/stop event bracket around ONE kernel also contains the stream's marker handling; an empty bracket
+    # measures it (~5-7 us).  Both are reported; the kernel duration used for the roofline is bracket - empty
+    # bracket, which is what rocprofv3's kernel trace of the same process shows (profiles/README.md).
+    bracket_overhead_ms = eng.profile_bracket_overhead()
+
+    def kernel_ms(total_ms, launches):
+        return max(total_ms / max(launches, 1) - bracket_overhead_ms, 0.0)
+
+    # every stage of a frame through the per-stage timers: a short extra pass, outside the timing (the trajectory simply
+    # continues; the brackets cost stream time, which is why the timed region carries only the dominant kernel's)
+    eng.profile_enable(*range(eng.PROF_COUNT))
+    extra = min(10, args.steps)
+    for k in range(extra):
+        one_step(args.warmup + args.steps + k)
+    eng.profile_enable()
+    stage_avg_ms = {}
+    for kk in range(eng.PROF_COUNT):
+        ms, cnt = eng.profile_read(kk)
+        if cnt:
+            stage_avg_ms[eng.PROF_NAMES[kk]] = {"avg_ms": kernel_ms(ms, cnt), "per_frame": cnt / max(extra, 1)}
+        if kk == eng.PROF_SCORE and not score_n:
+            score_ms, score_n = ms, cnt
+        if kk == eng.PROF_EKF and not ekf_n:
+            ekf_ms, ekf_n = ms, cnt
+    n_total = n * world
+    value = n_total * args.steps / elapsed
+
+    # how much of the population the resample kept distinct (the rows of repeated ancestors come out of L2 or stay in
+    # registers, which is what makes the in-filter EKF faster than a sweep): one torch.unique, outside the timed region
+    distinct_frac = None
+    torch.cuda.synchronize()
+    if args.mode == "pf" and views()[3] is not None:
+        distinct_frac = torch.unique(views()[3]).numel() / n
+
+    # the same EKF kernel WITHOUT ancestor sharing: identity ancestors on the same buffers, after the timed region.
+    # Every row is read from HBM once and written once: the streaming figure of the kernel.
+    L_obs = args.observed if 0 < args.observed < L else L
+    score_bytes = (12 + 4 * args.beams + 4) * n              # pose read + one EDT gather per beam + score write
+    ekf_bytes = 40 * n * L_obs                               # SURVEY 8(d): 20 B read + 20 B written per (particle, OBSERVED landmark)
+    no_reuse = None
+    if L and args.mode != "score" and not args.no_sweep and views()[1] is not None:
+        eng.profile_enable(eng.PROF_EKF)
+        eng.profile_read(eng.PROF_EKF)
+        p, ma, mb, _ = views()
+        base = args.warmup + args.steps
+        for k in range(12):
+            eng.obs_set_dev(*obs_v[(base + k) % len(frames)], L)
+            eng.ekf_update_dev((ma, mb)[k & 1], (mb, ma)[k & 1], 5 * Lp, Lp, L, p[0], p[1], p[2], None, n, MEAS_VAR, loglik_t)
+        eng.profile_enable()
+        nr_ms, nr_n = eng.profile_read(eng.PROF_EKF)
+        t_nr = kernel_ms(nr_ms, nr_n)
+        if t_nr > 0:
+            # an out-of-place launch rewrites EVERY row whatever was observed: its HBM bytes are 40 B x n x Lp
+            moved = ekf_bytes if L_obs == L else 40 * n * Lp
+            no_reuse = {"kernel": "ekf_update_kernel (identity ancestors: no row is shared), same buffers and observations",
+                        "achieved": moved / (t_nr * 1e-3) / 1e9, "frac": moved / (t_nr * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        "avg_launch_ms": t_nr, "launches": int(nr_n), "bytes_per_launch": moved,
+                        "algorithmic_bytes_per_launch": ekf_bytes,
+                        "read_only_frac": 20 * n * L_obs / (t_nr * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        del p, ma, mb
+
+    # the engine picks among kernels that give the same bits (DESIGN.md §5); name the one that ran
+    if paged_in_region:
+        ekf_name = "ekf_paged_kernel"
+    elif forms[2] + forms[3] > forms[0] + forms[1]:
+        ekf_name = "ekf_sparse_kernel" if forms[3] > forms[2] else "ekf_update_kernel (in place)"
+    else:
+        ekf_name = "ekf_update_group_kernel" if forms[1] > forms[0] else "ekf_update_kernel"
+    if ekf_n and (ekf_ms >= score_ms or args.mode == "ekf"):
+        kern, raw_ms, dur_ms, alg = ekf_name, ekf_ms / ekf_n, kernel_ms(ekf_ms, ekf_n), ekf_bytes
+    else:
+        kern, raw_ms, dur_ms, alg = ("score_poses_kernel", score_ms / max(score_n, 1), kernel_ms(score_ms, score_n), score_bytes)
+    logical = alg / (dur_ms * 1e-3) / 1e9 if dur_ms > 0 else 0.0
+    # HBM bytes per launch from rocprofv3 --pmc runs of this same command (profiles/collect_pmc.sh): used only when the
+    # record is for this workload AND this kernel
+    traffic, traffic_src = None, None
+    tfile = ROOT / "profiles" / "traffic.json"
+    if tfile.exists():
+        key = (f"{args.mode}:{n}:{args.beams}:{L}:{args.grid}" + (":paged" if paged_in_region else "")
+               + (f":obs{L_obs}" if L_obs != L else "") + (f":ess{args.ess}" if 0 < args.ess < 1 else ""))
+        rec = json.loads(tfile.read_text()).get(key, {})
+        if rec.get("kernel", kern).split("<")[0] == kern.split(" ")[0]:
+            traffic, traffic_src = rec.get("bytes_per_launch"), rec.get("source")
+    if traffic and dur_ms > 0:
+        achieved, a_kernel = traffic / (dur_ms * 1e-3) / 1e9, kern
+        basis = f"hbm_traffic (PMC record of this workload and kernel, {traffic_src}) / this run's launch time"
+    elif kern.startswith("ekf_update") and no_reuse and args.mode == "pf":
+        achieved, a_kernel = no_reuse["achieved"], no_reuse["kernel"]
+        basis = "no_reuse sweep (no PMC record for this workload and kernel): HBM bytes of a launch without shared rows / its launch time"
+    else:
+        achieved, a_kernel, basis = logical, kern, "algorithmic bytes / launch time in the timed region"
+    if no_reuse:
+        ro_frac, ro_basis = no_reuse["read_only_frac"], "no-reuse sweep"
+    elif kern.startswith("ekf") and dur_ms > 0:
+        ro_frac, ro_basis = 20 * n * L_obs / (dur_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "in-filter launches of the timed region"
+    else:
+        ro_frac, ro_basis = None, None
+    out = {
+        "metric": "particle-updates/sec (N_particles x scans/s) on 360-beam lidar",
+        "value": value, "unit": "particle-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": {"pf": ("BASELINE configs[1]" if (n, L, args.beams, args.grid) == (65536, 500, 360, 1024)
+                                       else "particle filter") + ": full frame (motion, scan-match score, EKF, weights, resample)",
+                                "score": "scan-match score only", "ekf": "EKF sweep only"}[args.mode],
+                   "mode": args.mode, "particles_per_gpu": n, "particles_total": n_total, "beams": args.beams,
+                   "landmarks": L, "landmarks_observed_per_frame": L_obs,
+                   "edt_grid": f"{args.grid}x{args.grid}",
+                   "parallelism": f"particle-shard x{world}" + (" (multi-GPU code path forced)" if args.force_collectives else ""),
+                   "transport": ctx.transport if (world > 1 or args.force_collectives) else None,
+                   "scaling": args.scaling,
+                   "rows_received_per_frame_max_rank": migrated if world > 1 else 0,
+                   "distinct_ancestor_frac": distinct_frac,
+                   "resample_ess_frac": args.ess,
+                   "map_layout": {"requested": args.map_layout, "in_timed_region": "pages (copy-on-write, 32 landmarks)" if paged_in_region else "rows"},
+                   "frames_resampled": (pf.frames_resampled() if 0 < args.ess < 1 else None)},
+        "roofline": {"bound": "hbm", "kernel": kern, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "achieved_basis": basis, "achieved_kernel": a_kernel,
+                     "algorithmic_bytes_per_launch": alg, "logical_rate_gbs": logical,
+                     "logical_frac": logical / HBM_PEAK_GBS,
+                     "no_reuse": no_reuse,
+                     # the north star's own definition: 20 B x n x L_observed / t / peak
+                     "read_only_frac": ro_frac, "read_only_basis": ro_basis,
+                     "note": ("in a running filter the rows of repeated resample ancestors are re-read from L2 or kept in "
+                              "registers: `logical_rate_gbs` (SURVEY 8d's 40 B per particle and observed landmark / launch time) is "
+                              "then not an HBM rate; `achieved` is one, see `achieved_basis` / `achieved_kernel`; `no_reuse` is the "
+                              "row kernel streaming every row from HBM" if kern.startswith("ekf_update") else
+                              "paged maps: the update reads the touched pages of the ancestors (shared pages out of L2) and writes "
+                              "fresh pages; `logical_rate_gbs` is SURVEY 8d's 40 B per particle and observed landmark / launch time"
+                              if kern.startswith("ekf") else
+                              "EDT gathers are served by L2 / Infinity Cache: logical-byte rate, not HBM traffic"),
+                     "avg_launch_ms": dur_ms, "avg_event_bracket_ms": raw_ms,
+                     "event_bracket_overhead_ms": bracket_overhead_ms,
+                     "launches": int(ekf_n if kern.startswith("ekf") else score_n),
+                     "ekf_launches_by_kernel": {"ekf_update_kernel": forms[0], "ekf_update_group_kernel": forms[1],
+                                                "ekf_update_kernel(in place)": forms[2], "ekf_sparse_kernel": forms[3]},
+                     "other_kernel_avg_ms": {"score_poses_kernel": kernel_ms(score_ms, score_n),
+                                             ekf_name: kernel_ms(ekf_ms, ekf_n)}},
+        "stage_avg_ms": stage_avg_ms,
+    }
+    torch.cuda.synchronize()
+    pf.close()
+    if comm:
+        comm.close()
+    del d_scan, d_z, scan_v, obs_v, sweep
+    torch.cuda.empty_cache()
+
+    legs_ok = rank == 0 and world == 1 and not ctx.threads
+    if legs_ok and args.mode == "pf" and not args.no_extra_legs and not args.force_collectives:
+        try:
+            out.update(extra_legs(args, torch, pkg, eng, dev, inp, kernel_ms))
+        except Exception as ex:   # a leg that fails must not cost the headline line
+            out["extra_legs_error"] = f"{type(ex).__name__}: {ex}"
+    if legs_ok and not args.no_cpu_baseline:
+        meta_t = (float(pixel), float(min_x), float(min_y))
+        out["cpu_baseline"] = cpu_baseline(args, occ, meta_t, frames, landmarks)
+        out["cpu_baseline_threads"] = cpu_baseline_threads(args, occ, meta_t, frames, landmarks)
+        try:
+            out["cpu_baseline_main_c"] = cpu_baseline_main_c()
+        except Exception as ex:
+            out["cpu_baseline_main_c"] = {"error": f"{type(ex).__name__}: {ex}"}
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    torch.cuda.synchronize()
+    ctx.finish()
+    eng.close()
+    return out
+
+
+def extra_legs(args, torch, pkg, eng, dev, inp, kernel_ms):
+    """Bounded legs after the headline's timed region (N = 1): the north-star sweep, the copy ceiling of the same shape on
+    the same box, and the configs[1] frame with the 32 nearest landmarks observed on rows and on pages."""
+    res = {}
+    # ---- (a) + (b): 1 048 576 x 1 000, every landmark observed, identity ancestors: 20 GB read + 20 GB written per launch
+    n, L, Lp = 1048576, 1000, 1024
+    free_b, _ = torch.cuda.mem_get_info(dev)
+    if free_b > 2.2 * n * 5 * Lp * 4:
+        rng = np.random.default_rng(7)
+        lm = make_landmarks(L, rng)
+        a = torch.empty((n, 5, Lp), dtype=torch.float32, device=dev)
+        b = torch.empty((n, 5, Lp), dtype=torch.float32, device=dev)
+        a[:, :, L:] = 0.0
+        fill_maps(torch, a, lm, L, dev, n)
+        p0 = true_pose(0)
+        pose = torch.stack([p0[k] + s * torch.randn(n, device=dev) for k, s in ((0, 0.05), (1, 0.05), (2, 0.01))]).float().contiguous()
+        fr = make_frames(12, args.beams, lm, rng, 0)
+        tabs = obs_tables(torch, fr, L, dev)
+        ll = torch.empty(n, dtype=torch.float32, device=dev)
+        torch.cuda.synchronize()
+        eng.ekf_form_set(0)
+        for k in range(2):   # warm-up
+            eng.obs_set_dev(tabs[k, 0], tabs[k, 1], L)
+            eng.ekf_update_dev((a, b)[k & 1], (b, a)[k & 1], 5 * Lp, Lp, L, pose[0], pose[1], pose[2], None, n, MEAS_VAR, ll)
+        eng.profile_enable(eng.PROF_EKF)
+        eng.profile_read(eng.PROF_EKF)
+        for k in range(12):
+            eng.obs_set_dev(tabs[k, 0], tabs[k, 1], L)
+            eng.ekf_update_dev((a, b)[k & 1], (b, a)[k & 1], 5 * Lp, Lp, L, pose[0], pose[1], pose[2], None, n, MEAS_VAR, ll)
+        eng.profile_enable()
+        ms, cnt = eng.profile_read(eng.PROF_EKF)
+        t = kernel_ms(ms, cnt)
+        eng.ekf_form_set(args.ekf_form)
+        res["north_star"] = {"what": "EKF sweep (--mode ekf form): ekf_update_kernel, identity ancestors, every landmark observed",
+                             "particles": n, "landmarks": L, "launches": int(cnt), "avg_launch_ms": t,
+                             "no_reuse_frac": 40 * n * L / (t * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             "read_only_frac": 20 * n * L / (t * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             "target_read_only_frac": 0.40}
+        tc = eng.profile_copy_ceiling(a, b, n, Lp, 8)
+        tc_small = eng.profile_copy_ceiling(a, b, 65536, 512, 20)
+        res["copy_ceiling"] = {"what": "pure copy with the update's access shape on this box (slam_profile_copy_ceiling): "
+                                       "20 B read + 20 B written per (row, column), no arithmetic",
+                               "rows": n, "columns": Lp, "ms_per_copy": tc,
+                               "read_write_gbs": 40 * n * Lp / (tc * 1e-3) / 1e9,
+                               "copy_ceiling_read_only_frac": 20 * n * Lp / (tc * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                               "at_65536x512": {"ms_per_copy": tc_small,
+                                                "copy_ceiling_read_only_frac": 20 * 65536 * 512 / (tc_small * 1e-3) / 1e9 / HBM_PEAK_GBS}}
+        res["north_star"]["fraction_of_copy_ceiling"] = (tc * L / Lp) / t   # the copy moves 1 024 columns, the sweep's algorithmic bytes are 1 000
+        del a, b, pose, tabs, ll
+        torch.cuda.empty_cache()
+    else:
+        res["north_star"] = {"skipped": f"needs 43 GB of HBM, {free_b / 1e9:.0f} GB free"}
+
+    # ---- (c) configs[1] with the 32 nearest landmarks observed, every frame resampled: rows against pages
+    n, L, Lp = 65536, 500, 512
+    rng = np.random.default_rng(4321)
+    lm = make_landmarks(L, rng)
+    steps, warm = 40, 12
+    fr = make_frames(steps + warm, args.beams, lm, rng, 32)
+    d_scan = torch.from_numpy(np.stack([np.stack([f["bx"], f["by"]]) for f in fr])).to(dev)
+    tabs = obs_tables(torch, fr, L, dev)
+    e2e = {"what": "configs[1] (65536 x 500, 360 beams, 1024^2 EDT) with the 32 nearest landmarks observed per frame, every "
+                   "frame resampled: whole frames on the C session", "steps": steps}
+    for layout in ("rows", "pages", "auto"):
+        ses = pkg.PfSession(eng, n, L, sigma=SIGMA, meas_var=MEAS_VAR, score_gain=SCORE_GAIN, seed=1234, map_layout=layout)
+        g = torch.Generator(device="cpu").manual_seed(1234)
+        p0 = true_pose(0)
+        ses.set_poses(*[(p0[k] + s * torch.randn(n, generator=g)).numpy() for k, s in ((0, 0.05), (1, 0.05), (2, 0.01))])
+        m0 = torch.zeros((n, 5, Lp), dtype=torch.float32, device=dev)
+        fill_maps(torch, m0, lm, L, dev, n)
+        torch.cuda.synchronize()
+        ses.set_map_dev(m0, 5 * Lp, Lp)
+        eng.sync()
+        del m0
+        for k in range(steps + warm):
+            if k == warm:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+            eng.scan_set_dev(d_scan[k, 0], d_scan[k, 1], args.beams)
+            eng.obs_set_dev(tabs[k, 0], tabs[k, 1], L)
+            ses.step(0, fr[k]["dp"], True)
+        torch.cuda.synchronize()
+        e2e[f"{layout}_ms"] = 1e3 * (time.perf_counter() - t0) / steps
+        e2e[f"{layout}_ended_on"] = "pages" if ses.is_paged() else "rows"
+        ses.close()
+    res["end_to_end_obs32"] = e2e
+    return res
+
+
+# ------------------------------------------------------------------------------------------------ launching
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
@@ -286,13 +886,14 @@ def main():
     ap.add_argument("--landmarks", type=int, default=500)
     ap.add_argument("--grid", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--driver", choices=["c", "py"], default="c",
-                    help="c (default): the C session slam_pf_* — one call per frame, several GPUs: the engine issues every RCCL "
-                         "exchange itself.  py: pf.py on the stage entry points with torch.distributed (rehearsal with gloo)")
+    ap.add_argument("--no-extra-legs", action="store_true",
+                    help="skip the bounded legs after the timed region (north-star sweep, copy ceiling, 32-observed frames)")
     ap.add_argument("--no-sweep", action="store_true",
                     help="skip the no-reuse EKF sweep after the timed region (so that a kernel trace of this run holds in-filter launches only)")
-    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, production) | gloo (functional rehearsal)")
-    ap.add_argument("--device-index", type=int, default=None, help="force every rank onto this GPU (rehearsal only)")
+    ap.add_argument("--transport", choices=["rccl", "local"], default="rccl",
+                    help="rccl (default): one process per GPU, RCCL over xGMI.  local: rehearsal, all ranks are threads of this "
+                         "process on ONE card (--device-index, default 0), exchanging through slam_comm_create_local")
+    ap.add_argument("--device-index", type=int, default=None, help="force every rank onto this GPU (--transport local)")
     ap.add_argument("--host-sensor", action="store_true", help="upload scan + observations from the host every frame")
     ap.add_argument("--events", choices=["dominant", "all", "none"], default="dominant",
                     help="kernels bracketed by HIP events inside the timed region (a pair costs a few us of stream time)")
@@ -300,381 +901,83 @@ def main():
                     help="landmarks seen per frame: 0 = all (default, the roofline workload), K = the K nearest")
     ap.add_argument("--ess", type=float, default=0.0,
                     help="ESS-gated resampling: resample only in frames whose effective sample size is below ESS * N "
-                         "(0 = every frame, the default and the headline workload); --driver c")
+                         "(0 = every frame, the default and the headline workload)")
     ap.add_argument("--presort-poses", action="store_true",
-                    help="experiment, --mode score: upload the poses grouped by 4-pixel / matching-heading cells (what a "
-                         "spatial ordering of the lanes would buy the scorer)")
+                    help="experiment, --mode score: upload the poses grouped by 4-pixel / matching-heading cells")
     ap.add_argument("--ekf-form", type=int, default=-1, choices=[-1, 0, 1, 2],
                     help="out-of-place EKF kernel: -1 the engine chooses (default), 0 one wavefront per particle, 1 / 2 per 4 / 2 particles")
-    ap.add_argument("--paged", action="store_true",
-                    help="C session, one GPU: landmark maps as copy-on-write pages (slam_pf_paged_set) instead of one row per "
-                         "particle: for frames that observe few of many landmarks (--observed K); no no-reuse sweep")
+    ap.add_argument("--map-layout", choices=["auto", "rows", "pages"], default="auto",
+                    help="slam_pf_config.map_layout: auto (default: the session chooses and may change while it runs), rows, pages")
+    ap.add_argument("--paged", action="store_true", help="= --map-layout pages")
     ap.add_argument("--force-collectives", action="store_true",
                     help="diagnostics, --gpus 1 only: run the multi-GPU code path (every RCCL collective, the sharded index "
                          "kernels, the plan read-back) on a one-rank group to price its control overhead")
-    ap.add_argument("--stats", action="store_true",
-                    help="diagnostics: print the number of distinct resample ancestors per frame (synchronises; not for timing)")
     args = ap.parse_args()
-    args.sigma = (0.01, 0.01, 0.002)
-    args.meas_var = 0.02 ** 2 * 4
-    args.score_gain = 0.02
+    if args.paged:
+        args.map_layout = "pages"
+    if args.mode != "pf":
+        args.map_layout = "rows"   # the sweeps run on the session's row buffers
+    return args
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch N>1 with torch.distributed.run")
+
+def main():
+    args = parse_args()
+    world_env = os.environ.get("WORLD_SIZE")
+    if args.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    if args.transport == "local" and world_env is not None and int(world_env) > 1:
+        sys.exit("bench.py: --transport local runs its ranks as threads of ONE process; do not start it under torchrun")
     if args.scaling == "strong":
-        if not args.particles_total or args.particles_total % world:
+        if not args.particles_total or args.particles_total % args.gpus:
             sys.exit("bench.py: --scaling strong needs --particles-total divisible by the number of ranks")
-        args.particles = args.particles_total // world
+        args.particles = args.particles_total // args.gpus
 
-    import torch
-    import torch.distributed as dist
+    if args.gpus > 1 and args.transport == "rccl" and world_env is None:
+        # No launcher around us: become one.  Nothing in this process has touched the GPU yet (numpy only), the ranks are
+        # fresh child processes; their rank 0 prints the JSON line on the stdout we share.
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(free_port()), str(Path(__file__).resolve())] + sys.argv[1:]
+        sys.exit(subprocess.run(cmd).returncode)
 
-    from __graft_entry__ import load_package
+    if args.transport == "local" and args.gpus > 1:
+        from __graft_entry__ import load_package
 
-    pkg = load_package()
-    from hardware_acceleration_of_lidar_slam_amd.pf import HipOps, ParticleFilter
+        import torch
 
-    if not torch.cuda.is_available():
-        sys.exit("bench.py: no GPU visible; the engine has no CPU fallback")
-    dev_index = local_rank if args.device_index is None else args.device_index
-    torch.cuda.set_device(dev_index)
-    dev = torch.device("cuda", dev_index)
-    if world == 1 and args.force_collectives and args.driver == "py":
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group(args.dist_backend, rank=0, world_size=1, **({"device_id": dev} if args.dist_backend == "nccl" else {}))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        with stdout_to_stderr():
-            if args.dist_backend == "nccl":
-                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-                dist.barrier()   # RCCL initialises lazily: do it (and print its banner) here, not in the timed region
-            else:
-                dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
-
-    eng = pkg.Engine(dev_index)
-    eng.ekf_form_set(args.ekf_form)
-    if args.paged:
-        if args.driver != "c" or world > 1 or args.force_collectives or args.mode != "pf":
-            sys.exit("bench.py: --paged is for the C session on one GPU, --mode pf")
-        eng.pf_paged_set(True)
-        args.no_sweep = True
-    use_c = args.driver == "c"
-    if use_c and args.dist_backend != "nccl":
-        sys.exit("bench.py: --driver c exchanges over RCCL; use --driver py for a gloo rehearsal")
-    if use_c and args.stats:
-        sys.exit("bench.py: --stats needs --driver py (the C session keeps its weights to itself)")
-    ops = None
-    if not use_c:
-        ops = HipOps(eng)
-        ops.bind_stream()   # the py driver shares torch's current stream; the C session runs on the engine's own
-
-    # ---- synthetic inputs (identical on every rank)
-    rng = np.random.default_rng(4321)
-    L = 0 if args.mode == "score" else args.landmarks
-    landmarks = np.stack([rng.uniform(ROOM[0] + 0.5, ROOM[2] - 0.5, L), rng.uniform(ROOM[1] + 0.5, ROOM[3] - 0.5, L)], 1)
-    if L:   # landmark ids in discovery order along a sweep of the room: neighbours in space are neighbours in the map rows
-        landmarks = landmarks[np.argsort(morton(landmarks), kind="stable")]
-    pixel = np.float32(20.48 / args.grid)
-    min_x, min_y = np.float32(-4.24), np.float32(-10.24)
-    occ = occupancy(args.grid, float(pixel), float(min_x), float(min_y))
-    nframes = args.steps + args.warmup + 10   # + the short per-kernel timing pass after the timed region
-    frames = make_frames(nframes, args.beams, landmarks, rng, args.observed)
-
-    d_occ = torch.from_numpy(occ).to(dev)
-    d_edt = torch.empty((args.grid, args.grid), dtype=torch.float32, device=dev)
-    torch.cuda.synchronize()
-    eng.edt_dev(d_occ, args.grid, args.grid, args.grid, 10.0, d_edt)
-    meta = pkg.grid_meta(args.grid, args.grid, args.grid, pixel, min_x, min_y)
-    eng.grid_set_dev(0, d_edt, meta)
-
-    n = args.particles
-    multi_path = world > 1 or args.force_collectives
-    comm = None
-    if use_c:
-        if multi_path:
-            # rendezvous token of the engine's own RCCL communicator: made by rank 0, handed out through the process
-            # group torchrun set up (used for nothing else but this, the barriers and the final timing reduction)
-            uid = torch.zeros(pkg.COMM_ID_BYTES, dtype=torch.uint8, device=dev)
-            if rank == 0:
-                uid = torch.tensor(list(pkg.comm_unique_id()), dtype=torch.uint8, device=dev)
-            if world > 1:
-                dist.broadcast(uid, src=0)
-            with stdout_to_stderr():   # RCCL prints its version banner to stdout; stdout carries ONE JSON line
-                comm = pkg.Comm.rccl(eng, rank, world, bytes(uid.cpu().tolist()))
-        pf = pkg.PfSession(eng, n, L, sigma=args.sigma, meas_var=args.meas_var, score_gain=args.score_gain, seed=1234, comm=comm,
-                           resample_ess_frac=args.ess)
-        Lp = (L + 31) // 32 * 32
-    else:
-        pf = ParticleFilter(ops, n, L, device=dev, rank=rank, world=world, seed=1234, sigma=args.sigma,
-                            meas_var=args.meas_var, score_gain=args.score_gain, grid_slot=0,
-                            force_collectives=args.force_collectives and world == 1)
-        Lp = pf.Lp
-
-    def views():
-        """(pose [3][n], current map [rows][5][Lp], spare map, pending gather index or None) as torch tensors."""
-        if use_c:
-            v = pf.device_view()
-            t = {k: (torch.as_tensor(v[k], device=dev) if v[k] is not None else None) for k in ("pose", "map", "map_spare", "anc")}
-            return t["pose"], t["map"], t["map_spare"], t["anc"]
-        return pf.pose[pf.cur], (pf.map[pf.cur] if L else None), (pf.map[1 - pf.cur] if L else None), pf.src_idx
-
-    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
-    p0 = true_pose(0)
-    init = [(p0[k] + s * torch.randn(n, generator=g)).numpy() for k, s in ((0, 0.05), (1, 0.05), (2, 0.01))]
-    if args.presort_poses:
-        cell = 4.0 * float(pixel)
-        key = np.lexsort((np.floor(init[0] / cell), np.floor(init[1] / cell), np.floor(init[2] / (cell / 8.0))))
-        init = [a[key] for a in init]
-    pf.set_poses(*init)
-    if L:
-        lm = torch.from_numpy(landmarks.astype(np.float32)).to(dev)
-        paged = use_c and pf.is_paged()
-        # paged maps have no rows to write into: the same rows are made in a scratch tensor and handed over once
-        m0 = torch.empty((n, 5, Lp), dtype=torch.float32, device=dev) if paged else views()[1]   # [particle][plane][Lp]
-        for i0 in range(0, n, 65536):                     # in chunks: the temporaries of a 1M x 1k map are 4 GB each
-            i1 = min(i0 + 65536, n)
-            m0[i0:i1, 0, :L] = lm[:, 0] + 0.1 * torch.randn((i1 - i0, L), device=dev)
-            m0[i0:i1, 1, :L] = lm[:, 1] + 0.1 * torch.randn((i1 - i0, L), device=dev)
-        m0[:n, 2, :L] = 0.05
-        m0[:n, 3, :L] = 0.0
-        m0[:n, 4, :L] = 0.05
-        if paged:
-            torch.cuda.synchronize()
-            pf.set_map_dev(m0, 5 * Lp, Lp)
-            eng.sync()
-            del m0
-    score_t = torch.zeros(n, dtype=torch.float32, device=dev)
-    count_t = torch.zeros(n, dtype=torch.int32, device=dev)
-    loglik_t = torch.zeros(n, dtype=torch.float32, device=dev)
-    torch.cuda.synchronize()
-
-    # sensor data of every frame resident in HBM before the timed region (bench contract); --host-sensor
-    # uploads it frame by frame through the host-buffer entry points instead (8.9 KB per frame over PCIe)
-    d_scan = torch.from_numpy(np.stack([np.stack([f["bx"], f["by"]]) for f in frames])).to(dev)        # [F][2][B]
-    if L:   # observation tables indexed by landmark (NaN = not observed; here every landmark is observed)
-        tab = np.full((len(frames), 2, L), np.nan, np.float32)
-        for k, f in enumerate(frames):
-            tab[k, 0, f["ids"]] = f["zx"]
-            tab[k, 1, f["ids"]] = f["zy"]
-        d_z = torch.from_numpy(tab).to(dev)                                                              # [F][2][L]
-
-    # per-frame views of the resident sensor data, made once (a tensor slice costs microseconds of host time)
-    scan_v = [(d_scan[k, 0], d_scan[k, 1]) for k in range(len(frames))]
-    obs_v = [(d_z[k, 0], d_z[k, 1]) for k in range(len(frames))] if L else None
-
-    sweep_pose, sweep_maps = None, None
-
-    def one_step(k):
-        nonlocal sweep_pose, sweep_maps
-        fr = frames[k]
-        if args.host_sensor:
-            eng.scan_upload(fr["bx"], fr["by"])
-            obs, obs_dev = ((fr["ids"], fr["zx"], fr["zy"]) if L else None), None
-        else:
-            eng.scan_set_dev(scan_v[k][0], scan_v[k][1], args.beams)
-            obs, obs_dev = None, (obs_v[k] if L else None)
-        if args.mode == "pf" and use_c:
-            if obs_dev:
-                eng.obs_set_dev(*obs_dev, L)
-            elif obs:
-                eng.obs_upload(*obs, L)
-            pf.step(0, fr["dp"], L > 0)
-        elif args.mode == "pf":
-            pf.step(fr["dp"], obs, obs_dev)
-            if args.stats:
-                w = torch.exp((pf.logw - pf.logw.max()).double())
-                print(f"[stats] rank {rank} frame {k}: distinct ancestors {torch.unique(pf.src_idx).numel()} of {n}, "
-                      f"ESS {float(w.sum() ** 2 / (w * w).sum()):.1f}, received rows {pf.migrated_last}", file=sys.stderr)
-        else:
-            if sweep_pose is None:
-                sweep_pose, a, b, _ = views()
-                sweep_maps = (a, b)
-            p = sweep_pose
-            if args.mode == "score":
-                eng.score_poses_dev(0, p[0], p[1], p[2], n, score_t, count_t)
-            else:   # ekf sweep: out of place, ping-pong between the two map buffers
-                if obs_dev:
-                    eng.obs_set_dev(*obs_dev, L)
-                else:
-                    eng.obs_upload(*obs, L)
-                eng.ekf_update_dev(sweep_maps[k & 1], sweep_maps[1 - (k & 1)], 5 * Lp, Lp, L, p[0], p[1], p[2], None, n,
-                                   args.meas_var, loglik_t)
-
-    def rows_received():
-        return (pf.rows_received() if use_c else pf.migrated_last) if args.mode == "pf" else 0
-
-    def barrier():
+        pkg = load_package()
+        inp = build_inputs(args)
+        torch.cuda.init()   # the HIP runtime comes up ONCE, here, not in N threads at the same time
+        torch.cuda.set_device(0 if args.device_index is None else args.device_index)
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
+        shared = ThreadShared(pkg, args.gpus)
+        results, errors = [None] * args.gpus, []
 
-    for k in range(args.warmup):
-        one_step(k)
-    barrier()
-    dominant = eng.PROF_SCORE if args.mode == "score" or L == 0 else eng.PROF_EKF
-    timed = {"dominant": (dominant,), "all": (eng.PROF_SCORE, eng.PROF_EKF), "none": ()}[args.events]
-    eng.profile_enable(*timed)
-    for kk in (eng.PROF_SCORE, eng.PROF_EKF):
-        eng.profile_read(kk)
-    migrated = 0
-    forms0 = eng.ekf_form_counts() + eng.ekf_inplace_form_counts()
-    t0 = time.perf_counter()
-    for k in range(args.warmup, args.warmup + args.steps):
-        one_step(k)
-        migrated += rows_received()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    eng.profile_enable()
-    forms1 = eng.ekf_form_counts() + eng.ekf_inplace_form_counts()
-    forms = tuple(b - a for a, b in zip(forms0, forms1))   # EKF launches of the timed region, by kernel (out of place x2, in place x2)
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t[0])
-        t[0] = migrated / max(args.steps, 1)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        migrated = float(t[0])
+        def work(r):
+            try:
+                results[r] = run_rank(args, ThreadCtx(args, r, shared), inp)
+            except BaseException as ex:   # a rank that dies must not leave the others inside a rendezvous
+                errors.append((r, ex))
+                shared.bar.abort()
 
-    score_ms, score_n = eng.profile_read(eng.PROF_SCORE)
-    ekf_ms, ekf_n = eng.profile_read(eng.PROF_EKF)
-    # A start/stop event bracket around ONE kernel also contains the stream's marker handling; an empty bracket
-    # measures it (~5-7 us).  Both are reported; the kernel duration used for the roofline is bracket - empty
-    # bracket, which is what rocprofv3's kernel trace of the same process shows (profiles/README.md).
-    bracket_overhead_ms = eng.profile_bracket_overhead()
-    if args.events != "all":   # the kernels not timed inside the region: a short extra pass, outside the timing
-        eng.profile_enable(eng.PROF_SCORE, eng.PROF_EKF)
-        for k in range(min(10, args.steps)):
-            one_step(args.warmup + args.steps + k)   # the trajectory simply continues (no wrap-around)
-        eng.profile_enable()
-        s2, n2 = eng.profile_read(eng.PROF_SCORE)
-        e2, m2 = eng.profile_read(eng.PROF_EKF)
-        if not score_n:
-            score_ms, score_n = s2, n2
-        if not ekf_n:
-            ekf_ms, ekf_n = e2, m2
-    n_total = n * world
-    value = n_total * args.steps / elapsed
+        th = [threading.Thread(target=work, args=(r,), name=f"rank{r}") for r in range(args.gpus)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        shared.group.close()
+        if errors:
+            for r, ex in errors:
+                print(f"bench.py: rank {r} failed: {type(ex).__name__}: {ex}", file=sys.stderr)
+            sys.exit(1)
+        print(json.dumps(results[0]))
+        return
 
-    def kernel_ms(total_ms, launches):
-        return max(total_ms / max(launches, 1) - bracket_overhead_ms, 0.0)
-
-    # how much of the population the resample kept distinct (the rows of repeated ancestors come out of L2, which is
-    # what makes the in-filter EKF faster than a sweep): one torch.unique, outside the timed region
-    distinct_frac = None
-    torch.cuda.synchronize()
-    if args.mode == "pf" and views()[3] is not None:
-        distinct_frac = torch.unique(views()[3]).numel() / n
-
-    # the same EKF kernel WITHOUT ancestor sharing: identity ancestors on the same buffers, after the timed region.
-    # Every row is read from HBM once and written once: the streaming figure of the kernel.
-    L_obs = args.observed if 0 < args.observed < L else L
-    score_bytes = (12 + 4 * args.beams + 4) * n              # pose read + one EDT gather per beam + score write
-    ekf_bytes = 40 * n * L_obs                               # SURVEY 8(d): 20 B read + 20 B written per (particle, OBSERVED landmark)
-    no_reuse = None
-    if L and args.mode != "score" and not args.no_sweep:
-        eng.profile_enable(eng.PROF_EKF)
-        eng.profile_read(eng.PROF_EKF)
-        p, ma, mb, _ = views()
-        base = args.warmup + args.steps
-        for k in range(12):
-            eng.obs_set_dev(*obs_v[(base + k) % len(frames)], L)
-            eng.ekf_update_dev((ma, mb)[k & 1], (mb, ma)[k & 1], 5 * Lp, Lp, L, p[0], p[1], p[2], None, n,
-                               args.meas_var, loglik_t)
-        eng.profile_enable()
-        nr_ms, nr_n = eng.profile_read(eng.PROF_EKF)
-        t_nr = kernel_ms(nr_ms, nr_n)
-        if t_nr > 0:
-            no_reuse = {"achieved": ekf_bytes / (t_nr * 1e-3) / 1e9, "frac": ekf_bytes / (t_nr * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                        "avg_launch_ms": t_nr, "launches": int(nr_n), "bytes_per_launch": ekf_bytes,
-                        "what": "ekf_update_kernel, identity ancestors (no row is shared), same buffers and observations"}
-
-    # the engine picks one of two out-of-place EKF kernels that give the same bits (DESIGN.md §5); name the one that ran
-    ekf_name = "ekf_update_group_kernel" if forms[1] > forms[0] else "ekf_update_kernel"
-    if args.paged:
-        ekf_name = "ekf_paged_kernel"
-    if ekf_n and (ekf_ms >= score_ms or args.mode == "ekf"):
-        kern, raw_ms, dur_ms, alg = ekf_name, ekf_ms / ekf_n, kernel_ms(ekf_ms, ekf_n), ekf_bytes
-    else:
-        kern, raw_ms, dur_ms, alg = ("score_poses_kernel", score_ms / max(score_n, 1), kernel_ms(score_ms, score_n),
-                                     score_bytes)
-    logical = alg / (dur_ms * 1e-3) / 1e9 if dur_ms > 0 else 0.0
-    traffic, traffic_src = None, None
-    tfile = ROOT / "profiles" / "traffic.json"   # HBM bytes per launch from rocprofv3 --pmc runs of this same command
-    if tfile.exists():
-        key = (f"{args.mode}:{n}:{args.beams}:{L}:{args.grid}" + (":paged" if args.paged else "") + (f":obs{L_obs}" if L_obs != L else "")
-               + (f":ess{args.ess}" if 0 < args.ess < 1 else ""))   # a gated run has its own traffic (none on file: falls back)
-        rec = json.loads(tfile.read_text()).get(key, {})
-        traffic, traffic_src = rec.get("ekf_update_kernel" if kern.startswith("ekf") else kern), rec.get("source")
-    # `achieved`: the rate at which HBM itself was driven when the PMC traffic of this workload is on file; else the
-    # no-reuse sweep of the same kernel (a filter's EKF re-reads shared ancestor rows from L2, so its algorithmic-byte
-    # rate is not an HBM rate and can exceed the peak); the scorer's EDT gathers are cache-resident by design, its
-    # logical rate is reported against the HBM peak because BASELINE.json asks for it.
-    if traffic and dur_ms > 0:
-        achieved, basis = traffic / (dur_ms * 1e-3) / 1e9, f"hbm_traffic (PMC, {traffic_src}) / launch time in the timed region"
-    elif kern.startswith("ekf") and no_reuse and args.mode == "pf":
-        achieved, basis = no_reuse["achieved"], "no_reuse sweep (no PMC traffic on file for this workload)"
-    else:
-        achieved, basis = logical, "algorithmic bytes / launch time in the timed region"
-    t_ro = no_reuse["avg_launch_ms"] if no_reuse else (dur_ms if kern.startswith("ekf") else 0.0)
-    out = {
-        "metric": "particle-updates/sec (N_particles x scans/s) on 360-beam lidar",
-        "value": value, "unit": "particle-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
-        "config": {"workload": {"pf": ("BASELINE configs[1]" if (n, L, args.beams, args.grid) == (65536, 500, 360, 1024)
-                                       else "particle filter") + ": full frame (motion, scan-match score, EKF, weights, resample)",
-                                "score": "scan-match score only", "ekf": "EKF sweep only"}[args.mode],
-                   "mode": args.mode, "particles_per_gpu": n, "particles_total": n_total, "beams": args.beams,
-                   "landmarks": L, "landmarks_observed_per_frame": L_obs,
-                   "edt_grid": f"{args.grid}x{args.grid}", "parallelism": f"particle-shard x{world}" + (" (multi-GPU code path forced)" if args.force_collectives else ""),
-                   "rows_received_per_frame_max_rank": migrated if world > 1 else 0,
-                   "distinct_ancestor_frac": distinct_frac,
-                   "resample_ess_frac": args.ess if use_c else 0.0,
-                   "map_layout": "pages (copy-on-write, 32 landmarks)" if args.paged else "rows",
-                   "frames_resampled": (pf.frames_resampled() if use_c and 0 < args.ess < 1 else None)},
-        "roofline": {"bound": "hbm", "kernel": kern, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "achieved_basis": basis,
-                     "algorithmic_bytes_per_launch": alg, "logical_rate_gbs": logical,
-                     "logical_frac": logical / HBM_PEAK_GBS,
-                     "no_reuse": no_reuse,
-                     # the north star's own definition: 20 B x n x L_observed / t / peak, t from the no-reuse sweep
-                     "read_only_frac": (20 * n * L_obs / (t_ro * 1e-3) / 1e9 / HBM_PEAK_GBS) if t_ro > 0 and L else None,
-                     "note": ("in a running filter the rows of repeated resample ancestors are re-read from L2: "
-                              "`logical_rate_gbs` (SURVEY 8d's 40 B per particle and observed landmark / launch time) is then "
-                              "not an HBM rate; `achieved` is, see `achieved_basis`; `no_reuse` is the kernel streaming "
-                              "every row from HBM" if kern.startswith("ekf_update") else
-                              "paged maps: the update reads the touched pages of the ancestors (shared pages out of L2) and writes "
-                              "fresh pages; `logical_rate_gbs` is SURVEY 8d's 40 B per particle and observed landmark / launch time"
-                              if kern.startswith("ekf") else
-                              "EDT gathers are served by L2 / Infinity Cache: logical-byte rate, not HBM traffic"),
-                     "avg_launch_ms": dur_ms, "avg_event_bracket_ms": raw_ms,
-                     "event_bracket_overhead_ms": bracket_overhead_ms,
-                     "launches": int(ekf_n if kern.startswith("ekf") else score_n),
-                     "ekf_launches_by_kernel": {"ekf_update_kernel": forms[0], "ekf_update_group_kernel": forms[1],
-                                                "ekf_update_kernel(in place)": forms[2], "ekf_sparse_kernel": forms[3]},
-                     "other_kernel_avg_ms": {"score_poses_kernel": kernel_ms(score_ms, score_n),
-                                             "ekf_update_kernel": kernel_ms(ekf_ms, ekf_n)}},
-    }
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args, occ, (float(pixel), float(min_x), float(min_y)), frames, landmarks)
-        out["cpu_baseline_threads"] = cpu_baseline_threads(args, occ, (float(pixel), float(min_x), float(min_y)), frames, landmarks)
-    elif rank == 0:
-        out["cpu_baseline"] = None
-    if rank == 0:
+    ctx = SingleCtx(args)
+    if ctx.world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={ctx.world}")
+    out = run_rank(args, ctx, build_inputs(args))
+    if ctx.rank == 0:
         print(json.dumps(out))
-    torch.cuda.synchronize()
-    if use_c:
-        pf.close()
-        if comm:
-            comm.close()
-    if dist.is_initialized():
-        dist.destroy_process_group()
-    eng.close()
 
 
 if __name__ == "__main__":

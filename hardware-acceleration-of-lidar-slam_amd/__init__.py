@@ -58,6 +58,7 @@ SIGNATURES = {
     "slam_profile_enable": (_i, [_vp, _i]),
     "slam_profile_read": (_i, [_vp, _i, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "slam_profile_bracket_overhead": (_i, [_vp, C.POINTER(C.c_double)]),
+    "slam_profile_copy_ceiling": (_i, [_vp, _vp, _vp, _i64, _i, _i, C.POINTER(C.c_double)]),
     "slam_edt_dev": (_i, [_vp, _vp, _i, _i, _i, _f, _vp]),
     "slam_edt_host": (_i, [_vp, _vp, _i, _i, _i, _f, _vp]),
     "slam_grid_upload_host": (_i, [_vp, _i, _vp, C.POINTER(GridMeta), _f, _vp]),
@@ -114,6 +115,7 @@ SIGNATURES = {
     "slam_local_group_create": (_i, [_i, C.POINTER(_vp)]),
     "slam_local_group_destroy": (_i, [_vp]),
     "slam_comm_create_local": (_i, [_vp, _vp, _i, C.POINTER(_vp)]),
+    "slam_comm_abort": (_i, [_vp]),
     "slam_comm_rank": (_i, [_vp]),
     "slam_comm_world": (_i, [_vp]),
     "slam_comm_destroy": (_i, [_vp]),
@@ -187,7 +189,7 @@ class Engine:
         h = C.c_void_p()
         rc = self.lib.slam_engine_create(device, C.byref(h))
         if rc != SLAM_OK:
-            raise SlamError(rc, "slam_engine_create")
+            raise SlamError(rc, "slam_engine_create", self.lib.slam_last_error(None).decode())
         self.h = h
         self.nbeams = 0
 
@@ -210,7 +212,9 @@ class Engine:
     def sync(self):
         self._ck(self.lib.slam_engine_sync(self.h), "sync")
 
-    PROF_SCORE, PROF_EDT, PROF_EKF = 0, 1, 2
+    PROF_SCORE, PROF_EDT, PROF_EKF, PROF_WEIGHTS, PROF_SCAN, PROF_ANCESTORS, PROF_PLAN, PROF_PACK, PROF_UNPACK = range(9)
+    PROF_COLLECTIVES, PROF_PAGES, PROF_COUNT = 9, 10, 11
+    PROF_NAMES = ("score", "edt", "ekf", "weights", "scan", "ancestors", "plan", "pack", "unpack", "collectives", "pages")
 
     def profile_enable(self, *kernels):
         """profile_enable(PROF_EKF, ...) times those kernels; profile_enable() switches timing off."""
@@ -229,6 +233,14 @@ class Engine:
         """Milliseconds an empty event bracket measures on the engine's stream."""
         ms = C.c_double(0)
         self._ck(self.lib.slam_profile_bracket_overhead(self.h, C.byref(ms)), "profile_bracket_overhead")
+        return ms.value
+
+    def profile_copy_ceiling(self, d_src, d_dst, rows: int, plane_stride: int, reps: int = 12) -> float:
+        """``slam_profile_copy_ceiling``: milliseconds of one pure copy of `rows` rows of 5 x plane_stride floats with the
+        landmark update's access shape."""
+        ms = C.c_double(0)
+        self._ck(self.lib.slam_profile_copy_ceiling(self.h, _ptr(d_src), _ptr(d_dst), rows, plane_stride, reps, C.byref(ms)),
+                 "profile_copy_ceiling")
         return ms.value
 
     # ---------------------------------------------------------------- host-buffer level (drop-in)
@@ -537,6 +549,10 @@ class Comm:
     @property
     def world(self):
         return self.e.lib.slam_comm_world(self.h)
+
+    def abort(self):
+        """``slam_comm_abort``: give up, so that the other ranks fail with SLAM_ERR_COMM instead of waiting."""
+        self.e._ck(self.e.lib.slam_comm_abort(self.h), "comm_abort")
 
     def close(self):
         if getattr(self, "h", None):

@@ -39,4 +39,16 @@ int comm_all_gather_finish(slam_comm* c);
 int comm_all_to_all_f32(slam_comm* c, const float* d_send, const int64_t* send_floats, float* d_recv,
                         const int64_t* recv_floats);
 
+// ---- failure path (RCCL with more than one rank has never run on hardware here: none of this has met a real failure)
+// give up: marks the communicator dead, breaks an in-process group / aborts the RCCL communicator so that the peers
+// do not wait for this rank for ever.  Every later call on the communicator returns SLAM_ERR_COMM.
+int comm_abort(slam_comm* c);
+// SLAM_OK, or SLAM_ERR_COMM when the communicator is dead, its group is broken or RCCL reports an asynchronous error
+// (the communicator is then aborted)
+int comm_poll(slam_comm* c);
+// hipStreamSynchronize / a wait for a flag in mapped host memory that poll the communicator and give up (abort) after
+// SLAM_COMM_TIMEOUT_S seconds (default 120)
+int comm_wait_stream(slam_comm* c);
+int comm_wait_flag(slam_comm* c, const volatile uint32_t* flag, uint32_t seq);
+
 }  // namespace slam

@@ -16,6 +16,7 @@
 #include <limits>
 #include <vector>
 
+#include "comm.h"
 #include "engine_internal.h"
 
 using namespace slam;
@@ -96,27 +97,38 @@ const char* slam_status_string(int status)
     case SLAM_ERR_HIP: return "HIP runtime error";
     case SLAM_ERR_NOT_READY: return "stage inputs not provided yet";
     case SLAM_ERR_CAPACITY: return "capacity exceeded";
+    case SLAM_ERR_COMM: return "exchange between ranks failed";
     default: return "unknown status";
     }
 }
 
-const char* slam_last_error(const slam_engine* e) { return e ? e->err : ""; }
+// why the last slam_engine_create of this thread failed (there is no engine to ask then): slam_last_error(NULL)
+static thread_local char g_create_err[256] = "";
+
+const char* slam_last_error(const slam_engine* e) { return e ? e->err : g_create_err; }
 
 int slam_engine_create(int device, slam_engine** out)
 {
     if (!out) return SLAM_ERR_INVALID_ARG;
     *out = nullptr;
     int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
+    g_create_err[0] = 0;
+    hipError_t herr = hipGetDeviceCount(&ndev);
+    if (herr != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
+        snprintf(g_create_err, sizeof g_create_err, "device %d of %d (hipGetDeviceCount: %s)", device, ndev, hipGetErrorString(herr));
         (void)hipGetLastError();
         return SLAM_ERR_NO_DEVICE;
     }
     hipDeviceProp_t prop;
-    if (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&prop, device) != hipSuccess) {
+    if ((herr = hipSetDevice(device)) != hipSuccess || (herr = hipGetDeviceProperties(&prop, device)) != hipSuccess) {
+        snprintf(g_create_err, sizeof g_create_err, "hipSetDevice / hipGetDeviceProperties(%d): %s", device, hipGetErrorString(herr));
         (void)hipGetLastError();
         return SLAM_ERR_NO_DEVICE;
     }
-    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return SLAM_ERR_NO_DEVICE;   // code objects are gfx950-only
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {   // code objects are gfx950-only
+        snprintf(g_create_err, sizeof g_create_err, "device %d is %s, not gfx950", device, prop.gcnArchName);
+        return SLAM_ERR_NO_DEVICE;
+    }
     slam_engine* e = new (std::nothrow) slam_engine();
     if (!e) return SLAM_ERR_HIP;
     e->device = device;
@@ -139,7 +151,8 @@ int slam_engine_create(int device, slam_engine** out)
         e->scan_buf.ensure(sizeof(float) * 2 * SLAM_MAX_BEAMS) != hipSuccess ||
         hipHostMalloc((void**)&e->h_stage, sizeof(float) * kStageSlots * kStageFloats, hipHostMallocDefault) !=
             hipSuccess) {
-        (void)hipGetLastError();
+        snprintf(g_create_err, sizeof g_create_err, "allocating the engine's buffers on device %d: %s", device,
+                 hipGetErrorString(hipGetLastError()));
         slam_engine_destroy(e);
         return SLAM_ERR_NO_DEVICE;
     }
@@ -255,6 +268,34 @@ int slam_profile_bracket_overhead(slam_engine* e, double* overhead_ms)
     for (auto& x : ev) (void)hipEventDestroy(x);
     *overhead_ms = sum / kPairs;
     return SLAM_OK;
+}
+
+int slam_profile_copy_ceiling(slam_engine* e, const float* d_src, float* d_dst, int64_t rows, int plane_stride, int reps,
+                              double* ms_per_copy)
+{
+    ENTER(e);
+    if (!d_src || !d_dst || d_src == d_dst || rows <= 0 || rows > 0x7fffffff || plane_stride < 128 || plane_stride % 128 ||
+        reps <= 0 || !ms_per_copy)
+        return SLAM_ERR_INVALID_ARG;
+    hipEvent_t a, b;
+    HIP_TRY(hipEventCreate(&a));
+    HIP_TRY(hipEventCreate(&b));
+    int rc = SLAM_OK;
+    auto ok = [&](hipError_t err, const char* what) {
+        if (err != hipSuccess && rc == SLAM_OK) rc = fail_hip(e, err, what);
+        return err == hipSuccess;
+    };
+    for (int r = 0; r < 2 && rc == SLAM_OK; ++r) ok(launch_copy_rows(e->stream, d_src, d_dst, (int)rows, plane_stride), "copy_rows");
+    ok(hipEventRecord(a, e->stream), "hipEventRecord");
+    for (int r = 0; r < reps && rc == SLAM_OK; ++r) ok(launch_copy_rows(e->stream, d_src, d_dst, (int)rows, plane_stride), "copy_rows");
+    ok(hipEventRecord(b, e->stream), "hipEventRecord");
+    ok(hipEventSynchronize(b), "hipEventSynchronize");
+    float ms = 0.0f;
+    if (rc == SLAM_OK) ok(hipEventElapsedTime(&ms, a, b), "hipEventElapsedTime");
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    *ms_per_copy = (double)ms / reps;
+    return rc;
 }
 
 int slam_engine_set_stream(slam_engine* e, void* hip_stream)
@@ -763,6 +804,7 @@ static int logweight_common(slam_engine* e, const float* d_score, const float* d
         HIP_TRY(e->bmax_buf.ensure(sizeof(float) * (size_t)logweight_scratch_floats()));
         HIP_TRY(hipMemsetAsync(e->bmax_buf.p, 0, e->bmax_buf.cap, e->stream));
     }
+    const ProfScope prof(e, SLAM_PROF_WEIGHTS);
     // with a resample gate: the weights of a frame that did not resample carry into this one (device-side decision)
     const bool carry = e->gate_frac_q16 != 0 && e->carry_n == n;
     HIP_TRY(launch_logweight(e->stream, d_score, d_loglik, score_gain, n, d_logw, e->bmax_buf.as<float>(), d_max,
@@ -800,6 +842,7 @@ int slam_quantise_scan_dev(slam_engine* e, const float* d_logw, const float* d_m
         HIP_TRY(e->carry_buf.ensure(sizeof(float) * (size_t)n));
         carry = e->carry_buf.as<float>();
     }
+    const ProfScope prof(e, SLAM_PROF_SCAN);
     HIP_TRY(launch_quantise_scan(e->stream, d_logw, d_max, e->bmax_buf.as<float>(), e->bmax_count, n, cdf, tiles, d_sum,
                                  carry, tiles + ntiles, tiles + 2 * ntiles, e->gate_buf.as<unsigned int>() + 2));
     e->scan_n = n;
@@ -828,6 +871,7 @@ int slam_ancestors_from_scan_dev(slam_engine* e, int n, uint64_t seed, uint32_t 
     const uint64_t* cdf = e->scan_state.as<uint64_t>();
     const uint32_t frac = e->carry_n == n ? e->gate_frac_q16 : 0;   // the gate needs the sums of a gated quantise_scan
     const GateOut gate = frac ? e->gate_next() : GateOut();
+    const ProfScope prof(e, SLAM_PROF_ANCESTORS);
     if (ancestors_from_scan_fits(n)) {
         // the distinct-ancestor count only steers the EKF's kernel choice: made only for populations that have maps
         HIP_TRY(launch_ancestors_from_scan(e->stream, cdf, cdf + n, n, seed, frame, d_anc, frac, gate,
@@ -853,6 +897,7 @@ int slam_offspring_from_scan_sharded_dev(slam_engine* e, int n, const uint64_t* 
     if (e->scan_n != n) return SLAM_ERR_NOT_READY;
     const uint64_t* cdf = e->scan_state.as<uint64_t>();
     const uint32_t frac = e->carry_n == n ? e->gate_frac_q16 : 0;
+    const ProfScope prof(e, SLAM_PROF_ANCESTORS);
     HIP_TRY(launch_offspring_from_scan(e->stream, cdf, cdf + n, n, nullptr, nullptr, d_shard_totals, rank, world, seed,
                                        frame, n_total, d_first, frac, frac ? e->gate_next() : GateOut()));
     return SLAM_OK;
@@ -878,6 +923,11 @@ int slam_resample_happened_host(slam_engine* e, int* resampled)
     if (e->gate_frac_q16 == 0 || e->gate_seq == 0) return SLAM_OK;   // no gate (or no gated stage yet): every frame resamples
     volatile uint32_t* h_seq = reinterpret_cast<volatile uint32_t*>(e->h_gate + 1);
     const uint32_t seq = e->gate_seq;
+    if (e->comm) {   // sharded: the verdict sits behind collectives
+        if (int rc = comm_wait_flag(e->comm, h_seq, seq)) return rc;
+        *resampled = e->h_gate[0] != 0;
+        return SLAM_OK;
+    }
     bool arrived = false;
     for (long spin = 0; spin < 400000000L; ++spin) {   // bounded: a few seconds at most
         if (__atomic_load_n(h_seq, __ATOMIC_ACQUIRE) == seq) { arrived = true; break; }
@@ -964,6 +1014,7 @@ int slam_ancestors_sharded_dev(slam_engine* e, const int32_t* d_first_all, int64
         return SLAM_ERR_INVALID_ARG;
     HIP_TRY(e->shard_buf.ensure(sizeof(int32_t) * (size_t)shard_scan_words(n_local)));
     const uint32_t seq = ++e->plan_seq;
+    const ProfScope prof(e, SLAM_PROF_PLAN);
     HIP_TRY(launch_ancestors_sharded(e->stream, d_first_all, n_total, n_local, rank, world, e->shard_buf.as<int32_t>(),
                                      d_plan, d_src, d_pose_idx, e->d_hplan,
                                      reinterpret_cast<uint32_t*>(e->d_hplan + SLAM_PLAN_WORDS(kMaxRanks)), seq, e->exch_cap,
@@ -987,13 +1038,17 @@ int slam_exchange_plan_host(slam_engine* e, int world, int32_t* plan)
     if (e->plan_seq == 0 || e->plan_world != world) return SLAM_ERR_NOT_READY;
     volatile uint32_t* h_flag = reinterpret_cast<volatile uint32_t*>(e->h_plan + SLAM_PLAN_WORDS(kMaxRanks));
     const uint32_t seq = e->plan_seq;
-    bool arrived = false;
-    for (long spin = 0; spin < 400000000L; ++spin) {   // bounded: a few seconds at most
-        if (__atomic_load_n(h_flag, __ATOMIC_ACQUIRE) == seq) { arrived = true; break; }
-    }
-    if (!arrived) {   // the launch failed or the device is wedged: let the runtime tell us
-        HIP_TRY(hipStreamSynchronize(e->stream));
-        if (__atomic_load_n(h_flag, __ATOMIC_ACQUIRE) != seq) return fail_hip(e, hipErrorUnknown, "exchange plan flag");
+    if (e->comm) {   // the plan kernel sits behind this frame's collectives: poll the communicator while waiting, bounded in time
+        if (int rc = comm_wait_flag(e->comm, h_flag, seq)) return rc;
+    } else {
+        bool arrived = false;
+        for (long spin = 0; spin < 400000000L; ++spin) {   // bounded: a few seconds at most
+            if (__atomic_load_n(h_flag, __ATOMIC_ACQUIRE) == seq) { arrived = true; break; }
+        }
+        if (!arrived) {   // the launch failed or the device is wedged: let the runtime tell us
+            HIP_TRY(hipStreamSynchronize(e->stream));
+            if (__atomic_load_n(h_flag, __ATOMIC_ACQUIRE) != seq) return fail_hip(e, hipErrorUnknown, "exchange plan flag");
+        }
     }
     memcpy(plan, e->h_plan, sizeof(int32_t) * (size_t)SLAM_PLAN_WORDS(world));
     return SLAM_OK;
@@ -1022,6 +1077,7 @@ int slam_migrate_pack_paged(slam_engine* e, int n_local, int rank, int world, co
     for (int q = 0; q < world; ++q) base[q] = plan[1 + 2 * world + q];
     if (!make_plan(mp, base, plan + 1, world) || plan[1 + rank] != 0) return SLAM_ERR_INVALID_ARG;
     if (mp.off[world] > 0 && !d_out) return SLAM_ERR_INVALID_ARG;
+    const ProfScope prof(e, SLAM_PROF_PACK);
     HIP_TRY(launch_migrate_pack(e->stream, e->shard_buf.as<int32_t>(), n_local, mp, d_pose, pose_ld, d_map, row_stride,
                                 plane_stride, nlandmarks, d_out, d_pt, nb));
     return SLAM_OK;
@@ -1039,6 +1095,7 @@ int slam_migrate_unpack_dev(slam_engine* e, const float* d_in, int world, const 
         return SLAM_ERR_INVALID_ARG;
     if (plan.off[world] > 0 && !d_in) return SLAM_ERR_INVALID_ARG;
     if ((int64_t)n_local + plan.off[world] > pose_ld) return SLAM_ERR_CAPACITY;   // pose_ld = particle capacity
+    const ProfScope prof(e, SLAM_PROF_UNPACK);
     HIP_TRY(launch_migrate_unpack(e->stream, d_in, plan, n_local, d_pose, pose_ld, d_map, row_stride, plane_stride,
                                   nlandmarks));
     return SLAM_OK;

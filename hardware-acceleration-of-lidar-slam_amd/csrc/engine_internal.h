@@ -10,6 +10,8 @@
 
 using slam::EventPair;
 
+struct slam_comm;
+
 namespace slam_detail {
 
 struct DevBuf {
@@ -127,6 +129,7 @@ struct slam_engine {
     int32_t* d_hobs = nullptr;
     int ekf_inplace_form = -1;   // slam_ekf_inplace_form_set: -1 by the feedback, 0 whole rows, 1 observed landmarks only
     int64_t ekf_inplace_launches[2] = { 0, 0 };
+    slam_comm* comm = nullptr; // the communicator made on this engine, if any: host-side waits poll it for failures
     int live_sessions = 0;     // slam_pf sessions alive on this engine (at most one: the stages keep per-population state here)
     bool pf_paged = false;     // slam_pf_paged_set: sessions made from now on keep their maps as copy-on-write pages
     int ekf_form = -1;         // slam_ekf_form_set: -1 choose by the feedback, 0 row per wavefront, 1 / 2 grouped by 4 / 2
@@ -175,7 +178,7 @@ struct slam_engine {
     // per-kernel HIP-event timing (slam_profile_*)
     int prof_mask = 0;
     std::vector<EventPair> prof_pool[SLAM_PROF_COUNT];   // grown on demand, reused after each read
-    size_t prof_used[SLAM_PROF_COUNT] = { 0, 0, 0 };
+    size_t prof_used[SLAM_PROF_COUNT] = {};
     EventPair prof_cur{};
 
     const EventPair* prof_next(int k)
@@ -191,6 +194,22 @@ struct slam_engine {
     }
 };
 
+
+// HIP events around whatever is enqueued on the engine's stream during the scope's lifetime (slam_profile_*)
+struct ProfScope {
+    slam_engine* e;
+    const EventPair* ev;
+    ProfScope(slam_engine* e_, int kernel) : e(e_), ev(e_->prof_next(kernel))
+    {
+        if (ev) (void)hipEventRecord(ev->start, e->stream);
+    }
+    ~ProfScope()
+    {
+        if (ev) (void)hipEventRecord(ev->stop, e->stream);
+    }
+    ProfScope(const ProfScope&) = delete;
+    ProfScope& operator=(const ProfScope&) = delete;
+};
 
 // helpers implemented in engine.hip
 int slam_engine_fail_hip(slam_engine* e, hipError_t err, const char* what);

@@ -225,6 +225,8 @@ hipError_t launch_best_particle(hipStream_t stream, const float* v, int n, const
 hipError_t launch_pose_sums(hipStream_t stream, const float* x, const float* y, const float* th, const int32_t* idx,
                             int n, float ref_th, unsigned long long* acc, unsigned int* ticket, long long* out4,
                             long long* h_out4, uint32_t* h_seq, uint32_t seq);
+// measurement support: rows of 5 x plane_stride floats copied with the update's access shape (slam_profile_copy_ceiling)
+hipError_t launch_copy_rows(hipStream_t stream, const float* in, float* out, int n, int plane_stride);
 hipError_t launch_gather_f32(hipStream_t stream, const float* src, const int32_t* idx, int n, float* dst);
 hipError_t launch_gather_map(hipStream_t stream, const float* in, float* out, int64_t in_row_stride,
                              int64_t out_row_stride, int in_plane_stride, int out_plane_stride, int nlandmarks,

@@ -1877,6 +1877,45 @@ hipError_t launch_pose_sums(hipStream_t stream, const float* x, const float* y, 
     return hipGetLastError();
 }
 
+// ---- measurement support (slam_profile_copy_ceiling): the access shape of ekf_update_kernel without its arithmetic
+__global__ __launch_bounds__(kEkfWaves * 64) void copy_rows_kernel(const float* __restrict__ in, float* __restrict__ out, int n,
+                                                                   int plane_stride, int xcd_chunk)
+{
+    const unsigned lane = threadIdx.x & 63u;
+    const int wave = threadIdx.x >> 6;
+    int bid = blockIdx.x;
+    if (xcd_chunk > 0) bid = (bid & 7) * xcd_chunk + (bid >> 3);
+    const int i = bid * kEkfWaves + wave;
+    if (i >= n) return;
+    const float* rin = in + (size_t)i * 5 * plane_stride;
+    float* rout = out + (size_t)i * 5 * plane_stride;
+    for (int lb = 0; lb < plane_stride; lb += 256) {   // two batches of 128 landmarks: every load before the first store
+        const int nb = plane_stride - lb >= 256 ? 2 : 1;
+        float m[2][2][5];
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int p = 0; p < 5; ++p)
+                    if (g < nb) m[g][t][p] = rin[p * plane_stride + lb + g * 128 + t * 64 + lane];
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int p = 0; p < 5; ++p)
+                    if (g < nb) __builtin_nontemporal_store(m[g][t][p], &rout[p * plane_stride + lb + g * 128 + t * 64 + lane]);
+    }
+}
+
+hipError_t launch_copy_rows(hipStream_t stream, const float* in, float* out, int n, int plane_stride)
+{
+    const int blocks = (n + kEkfWaves - 1) / kEkfWaves, chunk = (blocks + 7) / 8;
+    copy_rows_kernel<<<chunk * 8, kEkfWaves * 64, 0, stream>>>(in, out, n, plane_stride, chunk);
+    return hipGetLastError();
+}
+
 hipError_t launch_gather_f32(hipStream_t stream, const float* src, const int32_t* idx, int n, float* dst)
 {
     if (n <= 0) return hipSuccess;

@@ -86,7 +86,11 @@ int grow(slam_pf* pf, float** buf, size_t* have, size_t want)
 {
     if (want <= *have) return SLAM_OK;
     slam_engine* e = pf->e;
-    SLAM_HIP_TRY(e, hipStreamSynchronize(e->stream));   // an exchange still in flight may read the old buffer
+    if (pf->comm) {   // an exchange still in flight may read the old buffer
+        if (int rc = comm_wait_stream(pf->comm)) return rc;
+    } else {
+        SLAM_HIP_TRY(e, hipStreamSynchronize(e->stream));
+    }
     const size_t cap = want > 2 * *have ? want + want / 2 : 2 * *have;
     if (*buf) (void)hipFree(*buf);
     *buf = nullptr;
@@ -134,6 +138,7 @@ int migrate(slam_pf* pf)
     if (rtot && pf->paged) {
         // fresh pages for the received rows (a new free list first if the old one runs short), table rows n .. n + rtot - 1
         int32_t* pstate = pf->page_scratch + 2 * pf->nb + 1;
+        const ProfScope prof(e, SLAM_PROF_UNPACK);
         SLAM_HIP_TRY(e, launch_pool_reserve(e->stream, pstate, rtot * pf->nb));
         SLAM_HIP_TRY(e, launch_free_list(e->stream, pf->stamp, pf->npages, pf->stamp_now, pf->freelist, pstate,
                                          reinterpret_cast<int32_t*>(pf->d_hres) + 20));
@@ -171,6 +176,7 @@ int wait_result(slam_pf* pf, uint32_t seq)
 {
     slam_engine* e = pf->e;
     volatile uint32_t* h_seq = reinterpret_cast<volatile uint32_t*>(pf->h_res + 16);
+    if (pf->comm) return comm_wait_flag(pf->comm, h_seq, seq);
     for (long spin = 0; spin < 400000000L; ++spin)
         if (__atomic_load_n(h_seq, __ATOMIC_ACQUIRE) == seq) return SLAM_OK;
     SLAM_HIP_TRY(e, hipStreamSynchronize(e->stream));
@@ -418,9 +424,22 @@ int slam_pf_set_map_dev(slam_pf* pf, const float* d_rows, int64_t row_stride, in
 
 int slam_pf_is_paged(const slam_pf* pf) { return pf && pf->paged ? 1 : 0; }
 
+static int pf_step_impl(slam_pf* pf, int slot, const float dp[3], int use_observations, bool* collective_verdict);
+
 int slam_pf_step(slam_pf* pf, int slot, const float dp[3], int use_observations)
 {
     if (!pf || !dp) return SLAM_ERR_INVALID_ARG;
+    bool collective_verdict = false;
+    const int rc = pf_step_impl(pf, slot, dp, use_observations, &collective_verdict);
+    // A frame that fails on THIS rank alone leaves the other ranks inside (or on their way into) a collective: give up
+    // for good so that they get SLAM_ERR_COMM instead of waiting for ever.  A refusal every rank reaches together (the
+    // staging area might overflow: bit 1 of the plan) is not such a failure.
+    if (rc != SLAM_OK && pf->comm && !collective_verdict) (void)comm_abort(pf->comm);
+    return rc;
+}
+
+static int pf_step_impl(slam_pf* pf, int slot, const float dp[3], int use_observations, bool* collective_verdict)
+{
     slam_engine* e = pf->e;
     slam_comm* comm = pf->comm;
     if (pf->paged && __atomic_load_n(reinterpret_cast<int32_t*>(pf->h_res) + 20, __ATOMIC_ACQUIRE) != 0) {
@@ -459,7 +478,10 @@ int slam_pf_step(slam_pf* pf, int slot, const float dp[3], int use_observations)
     }
     if (comm) {
         // map rows of remote ancestors -> staging tail; issued behind the launch above, which does not need them
-        if ((rc = finish_exchange(pf)) != SLAM_OK) return rc;
+        if ((rc = finish_exchange(pf)) != SLAM_OK) {
+            *collective_verdict = rc == SLAM_ERR_CAPACITY;
+            return rc;
+        }
     }
     // 3. per-landmark EKF (+ fused gather); the log-likelihood stays inside the engine for step 4
     const bool ekf = L > 0 && use_observations;
@@ -472,10 +494,13 @@ int slam_pf_step(slam_pf* pf, int slot, const float dp[3], int use_observations)
             if (e->obs_nlandmarks != L) return SLAM_ERR_NOT_READY;
             SLAM_HIP_TRY(e, e->ll_buf.ensure(sizeof(float) * sn));
             int32_t *tpage = pf->page_scratch, *tindex = tpage + pf->nb, *count = tindex + pf->nb, *pstate = count + 1;
-            SLAM_HIP_TRY(e, launch_page_list(e->stream, e->d_obs_zx, e->d_obs_zy, L, pf->nb, tpage, tindex, count, n, pstate));
-            // a new free list when the old one runs short (decided on the device; the pages in use carry the last stamp)
-            SLAM_HIP_TRY(e, launch_free_list(e->stream, pf->stamp, pf->npages, pf->stamp_now, pf->freelist, pstate,
-                                             reinterpret_cast<int32_t*>(pf->d_hres) + 20));
+            {
+                const ProfScope prof(e, SLAM_PROF_PAGES);
+                SLAM_HIP_TRY(e, launch_page_list(e->stream, e->d_obs_zx, e->d_obs_zy, L, pf->nb, tpage, tindex, count, n, pstate));
+                // a new free list when the old one runs short (decided on the device; the pages in use carry the last stamp)
+                SLAM_HIP_TRY(e, launch_free_list(e->stream, pf->stamp, pf->npages, pf->stamp_now, pf->freelist, pstate,
+                                                 reinterpret_cast<int32_t*>(pf->d_hres) + 20));
+            }
             PagedEkfArgs a;
             a.pool = pf->pool;
             a.pt_in = pf->pt[pc];
@@ -505,6 +530,7 @@ int slam_pf_step(slam_pf* pf, int slot, const float dp[3], int use_observations)
             rc = slam_logweight_ekf_dev(e, pf->score, pf->cfg.score_gain, n, pf->logw, d_max);
         } else {
             if (anc) {   // the tables follow their particles
+                const ProfScope prof(e, SLAM_PROF_PAGES);
                 SLAM_HIP_TRY(e, launch_page_table_gather(e->stream, pf->pt[pc], pf->pt[1 - pc], pf->nb, anc, n, pf->stamp,
                                                          ++pf->stamp_now));
                 pf->pt_cur = 1 - pc;
@@ -621,7 +647,7 @@ int slam_pf_best(slam_pf* pf, float pose[3], float* logw, int32_t* index)
         if (int rc = comm_all_gather(pf->comm, pf->res_dev, pf->res_all, 5 * sizeof(float))) return rc;
         std::vector<float> all(5 * (size_t)pf->world);
         SLAM_HIP_TRY(e, hipMemcpyAsync(all.data(), pf->res_all, all.size() * 4, hipMemcpyDeviceToHost, e->stream));
-        SLAM_HIP_TRY(e, hipStreamSynchronize(e->stream));
+        if (int rc = comm_wait_stream(pf->comm)) return rc;
         int best = 0;
         for (int q = 1; q < pf->world; ++q)
             if (all[5 * q] > all[5 * best]) best = q;
@@ -665,7 +691,7 @@ int slam_pf_mean(slam_pf* pf, float ref_theta, float pose[3])
         if (int rc = comm_all_gather(pf->comm, pf->res_dev, pf->res_all, 4 * sizeof(long long))) return rc;
         std::vector<long long> all(4 * (size_t)pf->world);
         SLAM_HIP_TRY(e, hipMemcpyAsync(all.data(), pf->res_all, all.size() * 8, hipMemcpyDeviceToHost, e->stream));
-        SLAM_HIP_TRY(e, hipStreamSynchronize(e->stream));
+        if (int rc = comm_wait_stream(pf->comm)) return rc;
         for (int q = 0; q < pf->world; ++q)
             for (int k = 0; k < 4; ++k) sums[k] += all[4 * (size_t)q + k];
     }

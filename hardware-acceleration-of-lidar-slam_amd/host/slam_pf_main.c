@@ -195,7 +195,7 @@ static void *rank_main(void *arg)
     }
     me->rc = 0;
 fail:
-    if (me->rc && world > 1) exit(1);   /* the other ranks would wait for this one for ever: end the whole program */
+    if (me->rc && comm) slam_comm_abort(comm);   /* the other ranks must not wait for this one: their calls fail with SLAM_ERR_COMM */
     free(hits);
     fe_grid_free(&coarse); fe_grid_free(&fine);
     fe_points_free(&map); fe_points_free(&local);
@@ -259,7 +259,12 @@ int main(int argc, char **argv)
     if (run.world == 1) {
         rank_main(&ranks[0]);
     } else {
-        for (int r = 0; r < run.world; ++r) pthread_create(&th[r], NULL, rank_main, &ranks[r]);
+        for (int r = 0; r < run.world; ++r)
+            if (pthread_create(&th[r], NULL, rank_main, &ranks[r]) != 0) {
+                /* the ranks already running would wait for this one in their first collective: end the whole program */
+                fprintf(stderr, "pthread_create failed for rank %d\n", r);
+                exit(1);
+            }
         for (int r = 0; r < run.world; ++r) pthread_join(th[r], NULL);
     }
     int rc = 0;

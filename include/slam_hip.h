@@ -65,7 +65,8 @@ typedef struct {
 
 int slam_abi_version(void);
 const char *slam_status_string(int status);
-/* text of the most recent HIP error seen by this engine (empty string if none) */
+/* text of the most recent HIP error seen by this engine (empty string if none); e == NULL: why the calling thread's last
+ * slam_engine_create failed */
 const char *slam_last_error(const slam_engine *e);
 
 /* device: HIP device ordinal.  Fails with SLAM_ERR_NO_DEVICE when there is none. */
@@ -85,12 +86,32 @@ int slam_engine_sync(slam_engine *e);
  * synchronises the stream, returns the summed duration and the launch count since the last reset
  * and resets the counters.  (The reference's only timer is clock() around the whole run,
  * main.c:826-827, 971-973.) */
-typedef enum { SLAM_PROF_SCORE = 0, SLAM_PROF_EDT = 1, SLAM_PROF_EKF = 2, SLAM_PROF_COUNT = 3 } slam_prof_kernel;
+typedef enum {
+    SLAM_PROF_SCORE = 0,        /* score_poses_kernel (with or without the motion sample), lattice kernels */
+    SLAM_PROF_EDT = 1,          /* edt kernels */
+    SLAM_PROF_EKF = 2,          /* the landmark update of a frame, whichever kernel runs it (rows, grouped, list, pages) */
+    SLAM_PROF_WEIGHTS = 3,      /* log-weights + block maxima (+ the maximum's finalize launch on several GPUs) */
+    SLAM_PROF_SCAN = 4,         /* quantise + prefix sum (+ ESS sums) */
+    SLAM_PROF_ANCESTORS = 5,    /* offspring offsets / ancestor search (single GPU: one launch) */
+    SLAM_PROF_PLAN = 6,         /* several GPUs: global ancestor search, flag scans, exchange plan, local gather index */
+    SLAM_PROF_PACK = 7,         /* several GPUs: migrating rows into the send buffer */
+    SLAM_PROF_UNPACK = 8,       /* several GPUs: received rows into the staging tail */
+    SLAM_PROF_COLLECTIVES = 9,  /* every exchange between ranks (all-reduce, all-gathers, send/recv), as the stream sees them */
+    SLAM_PROF_PAGES = 10,       /* paged maps: touched-page list, free list, table gathers */
+    SLAM_PROF_COUNT = 11
+} slam_prof_kernel;
 int slam_profile_enable(slam_engine *e, int mask);
 int slam_profile_read(slam_engine *e, int kernel, double *total_ms, int64_t *launches);
 /* What an EMPTY start/stop bracket measures on this stream (mean of 64 back-to-back pairs, ms): the part of a
  * bracketed duration that is event bookkeeping rather than kernel time.  Synchronises. */
 int slam_profile_bracket_overhead(slam_engine *e, double *overhead_ms);
+/* What a PURE COPY with the landmark update's access shape reaches on this GPU: `rows` rows of five planes of
+ * `plane_stride` floats (a multiple of 128) are copied from d_src to d_dst `reps` times (one wavefront per row, 256-byte
+ * wave accesses, all loads of two batches before their stores, XCD-contiguous workgroup numbering, streaming stores —
+ * the addressing of the update without its arithmetic); *ms_per_copy is the average duration from HIP events.  Any
+ * kernel that reads 20 B and writes 20 B per (particle, landmark) is bounded by it: measurement support, not a stage. */
+int slam_profile_copy_ceiling(slam_engine *e, const float *d_src, float *d_dst, int64_t rows, int plane_stride, int reps,
+                              double *ms_per_copy);
 
 /* ------------------------------------------------------------------ EDT */
 
@@ -403,6 +424,12 @@ int slam_comm_create_rccl(slam_engine *e, int rank, int world, const uint8_t id[
 int slam_local_group_create(int world, slam_local_group **out);
 int slam_local_group_destroy(slam_local_group *g);
 int slam_comm_create_local(slam_engine *e, slam_local_group *g, int rank, slam_comm **out);
+/* Give up: after an error of its own a rank aborts its communicator so that the other ranks do not wait for it for
+ * ever (ncclCommAbort / the in-process group is marked broken); every later call on it — and, once they notice, on the
+ * peers' communicators — returns SLAM_ERR_COMM.  slam_pf_step does this itself when a frame of a sharded session fails
+ * on this rank alone.  Host-side waits of a sharded session poll for such failures (ncclCommGetAsyncError) and give
+ * up after SLAM_COMM_TIMEOUT_S seconds (environment, default 120). */
+int slam_comm_abort(slam_comm *c);
 int slam_comm_rank(const slam_comm *c);
 int slam_comm_world(const slam_comm *c);
 int slam_comm_destroy(slam_comm *c);

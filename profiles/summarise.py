@@ -31,7 +31,13 @@ def counter(mode, name):
     f = max(glob.glob(str(src / f"{tag}_pmc_{name}_{mode}" / "*" / "*counter_collection.csv")), key=os.path.getmtime)   # the newest run
     # both out-of-place kernels (ekf_update_kernel / ekf_update_group_kernel) count as "the EKF kernel"
     rows = [r for r in csv.DictReader(open(f)) if "ekf_update_" in r["Kernel_Name"] and r["Counter_Name"] == name]
+    global last_kernel
+    names = [r["Kernel_Name"].split("(")[0].replace("void slam::", "").replace("(anonymous namespace)::", "") for r in rows[4:10]]
+    last_kernel = max(set(names), key=names.count) if names else KERNEL   # the kernel the steady frames ran
     return [float(r["Counter_Value"]) * 1024 for r in rows]
+
+
+last_kernel = KERNEL
 
 
 for mode, out in (("pf", "bench_pf"), ("score", "bench_score")):
@@ -59,8 +65,9 @@ for mode, key, K in (("pf", f"pf:{n}:360:{L}:1024", L), ("pfobs32", f"pf:{n}:360
     rd = 2.0 * sum(fetch[steady]) / len(fetch[steady])
     wr = sum(write[steady]) / len(write[steady])
     alg = 40 * n * K
-    traffic[key] = {KERNEL: rd + wr, "read_bytes": rd, "write_bytes": wr, "algorithmic_bytes": alg,
-                    "fetch_size_calibration_factor": factor, "source": f"profiles/{tag}_pmc_ekf.md"}
+    traffic[key] = {"bytes_per_launch": rd + wr, "kernel": last_kernel.split("<")[0], "read_bytes": rd, "write_bytes": wr,
+                    "algorithmic_bytes": alg, "fetch_size_calibration_factor": factor, "source": f"profiles/{tag}_pmc_ekf.md",
+                    "measured": f"{tag}: builder-run rocprofv3 --pmc passes of bench.py --steps 8 --warmup 2"}
     md.append(f"`{key}`, steady frames: read = 2 x FETCH_SIZE = {rd / 1e6:.1f} MB, write = {wr / 1e6:.1f} MB, total "
               f"{(rd + wr) / 1e6:.1f} MB per launch vs {alg / 1e6:.1f} MB algorithmic (40 B x n x {K} observed).")
 md += ["", "The writes are the 20 B x n x 512 of the padded rows (every row is rewritten by the out-of-place update); the reads are "

@@ -59,7 +59,7 @@ md += ["## HBM traffic of `ekf_paged_kernel`, 500 landmarks (separate --pmc pass
 (here / f"{tag}_paged.md").write_text("\n".join(md) + "\n")
 tfile = here / "traffic.json"
 traffic = json.loads(tfile.read_text())
-traffic[f"pf:{n}:360:500:1024:paged:obs32"] = {"ekf_update_kernel": rd + wr, "read_bytes": rd, "write_bytes": wr,
+traffic[f"pf:{n}:360:500:1024:paged:obs32"] = {"bytes_per_launch": rd + wr, "read_bytes": rd, "write_bytes": wr,
                                                 "algorithmic_bytes": 40 * n * K, "kernel": "ekf_paged_kernel",
                                                 "source": f"profiles/{tag}_paged.md"}
 tfile.write_text(json.dumps(traffic, indent=1) + "\n")

@@ -1,4 +1,10 @@
-"""Particle-filter frame loop on the engine: host-side plumbing only.
+"""TEST INFRASTRUCTURE — a rehearsal harness, not the product path (the product's frame loop is the C session
+slam_pf_* in csrc/pf_session.hip, which issues its own exchange steps).  This module drives the STAGE entry points of
+the C ABI from Python with torch.distributed between them, so that the sharding / exchange index algebra can run on
+CPUs under gloo with the oracle's stages substituted (tests/test_pf_sharding_gloo.py) and against the C session on the GPU
+(tests/test_gpu_pf.py).
+
+Particle-filter frame loop on the engine: host-side plumbing only.
 
 One process per GPU.  This module owns the device buffers (torch tensors are used purely as HBM
 allocations on the current stream) and the exchange steps between GPUs (``torch.distributed``, i.e.

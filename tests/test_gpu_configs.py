@@ -167,7 +167,8 @@ def test_ekf_long_rows_small_n(eng, orc, L, Lp):
 
 
 # ------------------------------------------------------------------ the sharded C session (slam_pf_create_sharded)
-def _run_c_session_ranks(world, n_total, L, frames, transport="local", recv_capacity=0, ess=0.0, inplace_form=-1, paged=False):
+def _run_c_session_ranks(world, n_total, L, frames, transport="local", recv_capacity=0, ess=0.0, inplace_form=-1, paged=False,
+                         fail_rank=None, fail_frame=None):
     """`world` ranks of the C-level sharded session in THIS process, one host thread per rank, all on cuda:0
     (in-process transport), or a one-rank RCCL communicator.  Returns the concatenated population."""
     import threading
@@ -189,7 +190,6 @@ def _run_c_session_ranks(world, n_total, L, frames, transport="local", recv_capa
         try:
             eng = pkg.Engine(0)
             eng.ekf_inplace_form_set(inplace_form)   # frames that keep their population: whole rows / the compact observation list
-            eng.pf_paged_set(paged)                  # landmark maps as copy-on-write pages instead of one row per particle
             eng.grid_set_dev(0, d_edt, gm)
             eng.scan_upload(bx, by)
             comm = None
@@ -199,7 +199,7 @@ def _run_c_session_ranks(world, n_total, L, frames, transport="local", recv_capa
                 comm = pkg.Comm.rccl(eng, r, world, uid)
             ses = pkg.PfSession(eng, n, L, seed=77, sigma=(0.02, 0.02, 0.004), meas_var=0.02,
                                 score_gain=0.05 if L else 1.0, comm=comm, recv_capacity=recv_capacity,
-                                resample_ess_frac=ess)
+                                resample_ess_frac=ess, map_layout="pages" if paged else "rows")
             sl = slice(r * n, (r + 1) * n)
             ses.set_poses(x[sl], y[sl], th[sl])
             if L:
@@ -207,6 +207,9 @@ def _run_c_session_ranks(world, n_total, L, frames, transport="local", recv_capa
             rows, bests = [], []
             for f in range(frames):
                 use = L > 0 and f != 2                      # one frame without observations: the maps just follow
+                if r == fail_rank and f == fail_frame:
+                    comm.abort()                            # this rank gives up: the others must fail, not wait
+                    raise RuntimeError("rank gave up")
                 if use:
                     eng.obs_upload(*W.observations(lm, f), L)
                 ses.step(0, [0.01, -0.005, 0.002], use)
@@ -269,8 +272,8 @@ def test_c_sharded_session_ranks_on_one_card_equal_one_rank(orc, world, n_total,
 
 def test_c_sharded_session_over_rccl_one_rank(orc):
     """The engine-issued RCCL calls themselves, as far as one GPU allows: a one-rank communicator (ncclCommInitRank,
-    all-reduce MAX, three all-gathers, the grouped send/recv with empty splits on the communicator's own stream with
-    the event hand-overs) must reproduce the single-GPU session bit for bit.  RCCL with more than one rank needs more
+    all-reduce MAX, the all-gathers, the grouped send/recv with empty splits — all issued on the ENGINE's stream in
+    program order, csrc/comm.hip) must reproduce the single-GPU session bit for bit.  RCCL with more than one rank needs more
     than one GPU (it refuses two ranks on one device): unverified on this box."""
     one = _run_c_session_ranks(1, 8192, 6, 6, transport=None)[0]
     via = _run_c_session_ranks(1, 8192, 6, 6, transport="rccl")[0]
