@@ -124,6 +124,7 @@ SIGNATURES = {
     "slam_pf_rows_received": (_i, [_vp]),
     "slam_pf_device_view": (_i, [_vp, _vp]),
     "slam_pf_frames_resampled": (_i64, [_vp]),
+    "slam_pf_layout_changes": (_i64, [_vp]),
     "slam_pf_create": (_i, [_vp, _vp, C.POINTER(_vp)]),
     "slam_pf_destroy": (_i, [_vp]),
     "slam_pf_reset": (_i, [_vp, _fp]),
@@ -584,6 +585,9 @@ class PfSession:
 
     def frames_resampled(self) -> int:
         return int(self.e.lib.slam_pf_frames_resampled(self.h))
+
+    def layout_changes(self) -> int:
+        return int(self.e.lib.slam_pf_layout_changes(self.h))
 
     def device_view(self):
         """dict of DeviceArray views of the session's CURRENT buffers (``slam_pf_device_view``): pose [3][n], map and

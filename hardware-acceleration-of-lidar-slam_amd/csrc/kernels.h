@@ -124,8 +124,13 @@ struct PagedEkfArgs {
 // pool_state (pool_state_words() int32 on the device): the free list's bookkeeping — how long it is, how much of it has
 // been handed out, whether launch_free_list (to be called behind this launcher every frame) has to make a new one first
 int pool_state_words();
+// h_obs + votes (optional): the launch also takes SLAM_MAP_AUTO's sample — votes[2] (device): samples in a row with at most
+// a quarter / more than half of the landmarks observed; h_obs (mapped host memory): {observed, L, seq, votes[0], votes[1]}
 hipError_t launch_page_list(hipStream_t stream, const float* zx, const float* zy, int L, int nb, int32_t* tpage, int32_t* tindex,
-                            int32_t* count, int n, int32_t* pool_state);
+                            int32_t* count, int n, int32_t* pool_state, int32_t* h_obs = nullptr, uint32_t seq = 0,
+                            int32_t* votes = nullptr);
+// the same sample as a launch of its own (one small workgroup), for sessions on rows
+hipError_t launch_obs_count(hipStream_t stream, const float* zx, const float* zy, int L, int32_t* h_obs, uint32_t seq, int32_t* votes);
 hipError_t launch_ekf_paged(hipStream_t stream, const PagedEkfArgs& a, const EventPair* ev = nullptr);
 hipError_t launch_page_table_gather(hipStream_t stream, const int32_t* pt_in, int32_t* pt_out, int nb, const int32_t* anc, int n,
                                     uint32_t* stamp, uint32_t stamp_now);
@@ -136,8 +141,10 @@ hipError_t launch_free_list(hipStream_t stream, const uint32_t* stamp, int npage
                             int32_t* pool_state, int32_t* h_short = nullptr);
 // out[k] = anc[sel[k]] (anc == nullptr: sel[k])
 hipError_t launch_compose_index(hipStream_t stream, const int32_t* sel, const int32_t* anc, int count, int32_t* out);
+// rows -> pages page_base + j * nb + b behind identity tables; every other page of the pool goes on the free list
 hipError_t launch_pages_from_rows(hipStream_t stream, const float* rows, int64_t row_stride, int plane_stride, int nlandmarks,
-                                  int nb, int n, float* pool, int32_t* pt, int32_t* freelist, int npages, int32_t* pool_state);
+                                  int nb, int n, float* pool, int32_t* pt, int32_t* freelist, int npages, int32_t* pool_state,
+                                  int page_base = 0);
 hipError_t launch_rows_from_pages(hipStream_t stream, const float* pool, const int32_t* pt, int nb, const int32_t* anc, int n,
                                   float* rows, int64_t row_stride, int plane_stride, int nlandmarks);
 hipError_t launch_pages_reset(hipStream_t stream, float* pool, int32_t* pt, int64_t nentries, int32_t* freelist, int npages,

@@ -52,13 +52,45 @@ __device__ __forceinline__ void pool_reserve(int32_t* __restrict__ pool_state, i
 // The pages a frame touches: page b is touched when one of its landmarks has an observation (table form: NaN = none).
 // One workgroup, one landmark per thread and step: a page is kPage neighbouring lanes of a wavefront, "touched" a ballot.
 // tpage[0 .. T) ascending, tindex[b] = position of page b in tpage or -1, count[0] = T.
+// What SLAM_MAP_AUTO decides the layout from: votes[0] counts the samples in a row with at most a quarter of the landmarks
+// observed, votes[1] those in a row with more than half (device memory, kept by the kernels that take a sample); the
+// mirror in mapped host memory holds {observed, L, seq, votes[0], votes[1]}.
+__device__ __forceinline__ void publish_obs_count(int nobs, int L, int32_t* __restrict__ votes, int32_t* __restrict__ h_obs,
+                                                  uint32_t seq)
+{
+    int vp = votes[0], vr = votes[1];
+    if (4 * (int64_t)nobs <= L) {
+        vp = vp < 1000000 ? vp + 1 : vp;
+        vr = 0;
+    } else if (2 * (int64_t)nobs > L) {
+        vr = vr < 1000000 ? vr + 1 : vr;
+        vp = 0;
+    } else {
+        vp = vr = 0;
+    }
+    votes[0] = vp;
+    votes[1] = vr;
+    h_obs[0] = nobs;
+    h_obs[1] = L;
+    h_obs[3] = vp;
+    h_obs[4] = vr;
+    __threadfence_system();
+    __hip_atomic_store(reinterpret_cast<uint32_t*>(h_obs) + 2, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// h_obs (optional, mapped host memory; then votes != nullptr too): this launch also takes SLAM_MAP_AUTO's sample.
 __global__ __launch_bounds__(1024) void page_list_kernel(const float* __restrict__ zx, const float* __restrict__ zy, int L,
                                                          int nb, int32_t* __restrict__ tpage, int32_t* __restrict__ tindex,
-                                                         int32_t* __restrict__ count, int n, int32_t* __restrict__ pool_state)
+                                                         int32_t* __restrict__ count, int n, int32_t* __restrict__ pool_state,
+                                                         int32_t* __restrict__ h_obs, uint32_t seq, int32_t* __restrict__ votes)
 {
     __shared__ int s_wave[16];
     __shared__ int s_base;
-    if (threadIdx.x == 0) s_base = 0;
+    __shared__ int s_nobs;
+    if (threadIdx.x == 0) {
+        s_base = 0;
+        s_nobs = 0;
+    }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     constexpr int kPerWave = 64 / kPage;                       // pages per wavefront and step
@@ -71,6 +103,7 @@ __global__ __launch_bounds__(1024) void page_list_kernel(const float* __restrict
             ob = vx == vx && vy == vy;
         }
         const unsigned long long m = __ballot(ob);
+        if (h_obs && lane == 0 && m) atomicAdd(&s_nobs, __popcll(m));
         int touched_before = 0, touched_mine = 0, touched_all = 0;   // pages of this wavefront: below mine / mine / all
 #pragma unroll
         for (int g = 0; g < kPerWave; ++g) {
@@ -101,7 +134,27 @@ __global__ __launch_bounds__(1024) void page_list_kernel(const float* __restrict
         const int T = s_base;
         count[0] = T;
         pool_reserve(pool_state, (int64_t)n * T);   // this frame's n * T fresh pages
+        if (h_obs) publish_obs_count(s_nobs, L, votes, h_obs, seq);
     }
+}
+
+// The same sample for a session that is on rows
+__global__ __launch_bounds__(1024) void obs_count_kernel(const float* __restrict__ zx, const float* __restrict__ zy, int L,
+                                                         int32_t* __restrict__ h_obs, uint32_t seq, int32_t* __restrict__ votes)
+{
+    __shared__ int s_nobs;
+    if (threadIdx.x == 0) s_nobs = 0;
+    __syncthreads();
+    int c = 0;
+    for (int l = threadIdx.x; l < L; l += 1024) {
+        const float vx = zx[l], vy = zy[l];
+        c += (vx == vx && vy == vy) ? 1 : 0;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(&s_nobs, c);
+    __syncthreads();
+    if (threadIdx.x == 0) publish_obs_count(s_nobs, L, votes, h_obs, seq);
 }
 
 __global__ void pool_reserve_kernel(int32_t* __restrict__ pool_state, int64_t want) { pool_reserve(pool_state, want); }
@@ -326,10 +379,10 @@ __global__ __launch_bounds__(256) void free_list_kernel(const uint32_t* __restri
 }
 
 // ---- rows <-> pages (set / get of whole maps; not on the frame path)
-// rows [n][5][plane_stride] -> pages j * nb + b (the identity table)
+// rows [n][5][plane_stride] -> pages page_base + j * nb + b (the identity table, shifted)
 __global__ __launch_bounds__(256) void pages_from_rows_kernel(const float* __restrict__ rows, int64_t row_stride, int plane_stride,
                                                               int nlandmarks, int nb, int n, float* __restrict__ pool,
-                                                              int32_t* __restrict__ pt)
+                                                              int32_t* __restrict__ pt, int page_base)
 {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;   // one thread per (particle, page, slot)
     if (idx >= (int64_t)n * nb * kPage) return;
@@ -338,10 +391,10 @@ __global__ __launch_bounds__(256) void pages_from_rows_kernel(const float* __res
     const int b = (int)(pb % nb), i = (int)(pb / nb);
     const int l = b * kPage + slot;
     const float* r = rows + (int64_t)i * row_stride;
-    float* pg = pool + pb * kPageFloats + slot;
+    float* pg = pool + (pb + page_base) * kPageFloats + slot;
 #pragma unroll
     for (int p = 0; p < 5; ++p) pg[p * kPage] = l < nlandmarks ? r[(int64_t)p * plane_stride + l] : (p == 2 ? -1.0f : 0.0f);
-    if (slot == 0) pt[pb] = (int32_t)pb;
+    if (slot == 0) pt[pb] = (int32_t)pb + page_base;
 }
 
 // pages of particle anc[i] (or i) -> row i
@@ -383,13 +436,15 @@ __global__ __launch_bounds__(256) void pages_reset_kernel(float* __restrict__ po
     }
 }
 
-// free list = pages first .. first + count - 1, nothing handed out
-__global__ __launch_bounds__(256) void free_iota_kernel(int32_t* __restrict__ out, int first, int count,
+// free list = pages 0 .. count0 - 1, then first1 .. first1 + count1 - 1; nothing handed out
+__global__ __launch_bounds__(256) void free_iota_kernel(int32_t* __restrict__ out, int count0, int first1, int count1,
                                                         int32_t* __restrict__ pool_state)
 {
     const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx < count) out[idx] = first + idx;
+    if (idx < count0) out[idx] = idx;
+    else if (idx < count0 + count1) out[idx] = first1 + (idx - count0);
     if (idx == 0) {
+        const int count = count0 + count1;
         pool_state[kPoolFree] = count;
         pool_state[kPoolUsed] = 0;
         pool_state[kPoolRenew] = 0;
@@ -412,9 +467,15 @@ inline int blocks256(int64_t n) { return (int)((n + 255) / 256); }
 }  // namespace
 
 hipError_t launch_page_list(hipStream_t stream, const float* zx, const float* zy, int L, int nb, int32_t* tpage, int32_t* tindex,
-                            int32_t* count, int n, int32_t* pool_state)
+                            int32_t* count, int n, int32_t* pool_state, int32_t* h_obs, uint32_t seq, int32_t* votes)
 {
-    page_list_kernel<<<1, 1024, 0, stream>>>(zx, zy, L, nb, tpage, tindex, count, n, pool_state);
+    page_list_kernel<<<1, 1024, 0, stream>>>(zx, zy, L, nb, tpage, tindex, count, n, pool_state, votes ? h_obs : nullptr, seq, votes);
+    return hipGetLastError();
+}
+
+hipError_t launch_obs_count(hipStream_t stream, const float* zx, const float* zy, int L, int32_t* h_obs, uint32_t seq, int32_t* votes)
+{
+    obs_count_kernel<<<1, 1024, 0, stream>>>(zx, zy, L, h_obs, seq, votes);
     return hipGetLastError();
 }
 
@@ -469,12 +530,15 @@ hipError_t launch_migrate_unpack_paged(hipStream_t stream, const float* in, int 
 }
 
 hipError_t launch_pages_from_rows(hipStream_t stream, const float* rows, int64_t row_stride, int plane_stride, int nlandmarks,
-                                  int nb, int n, float* pool, int32_t* pt, int32_t* freelist, int npages, int32_t* pool_state)
+                                  int nb, int n, float* pool, int32_t* pt, int32_t* freelist, int npages, int32_t* pool_state,
+                                  int page_base)
 {
     pages_from_rows_kernel<<<blocks256((int64_t)n * nb * kPage), 256, 0, stream>>>(rows, row_stride, plane_stride, nlandmarks, nb, n,
-                                                                                  pool, pt);
-    const int used = n * nb;   // the identity table names pages 0 .. n * nb - 1: the rest is free
-    free_iota_kernel<<<blocks256(npages > used ? npages - used : 1), 256, 0, stream>>>(freelist, used, npages - used, pool_state);
+                                                                                  pool, pt, page_base);
+    const int used = n * nb;   // the tables name pages page_base .. page_base + n * nb - 1: the rest is free
+    const int after = page_base + used;
+    free_iota_kernel<<<blocks256(npages > used ? npages - used : 1), 256, 0, stream>>>(freelist, page_base, after, npages - after,
+                                                                                     pool_state);
     return hipGetLastError();
 }
 

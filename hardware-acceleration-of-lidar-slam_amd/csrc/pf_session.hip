@@ -63,6 +63,8 @@ struct slam_pf {
     // per particle instead of one row per particle (paged_kernels.hip); map[] stays unallocated
     bool paged = false;
     int nb = 0, npages = 0;         // pages per particle; pages in the pool (2 * cap * nb: never fewer than half are free)
+    float* store = nullptr;         // the one allocation behind map[0], map[1] and pool
+    int32_t* votes = nullptr;       // [2] SLAM_MAP_AUTO's sample counters on the device
     float* pool = nullptr;          // [npages][5][32]
     int32_t* pt[2] = { nullptr, nullptr };   // [n][nb] page tables, current and next
     int pt_cur = 0;
@@ -72,6 +74,13 @@ struct slam_pf {
     int32_t* page_scratch = nullptr;   // tpage[nb] | tindex[nb] | count | the free list's bookkeeping (pool_state_words())
     bool gated = false;             // cfg.resample_ess_frac in (0, 1): a frame resamples only when its ESS is low
     int64_t frames_resampled = 0;   // (as far as the host has looked: one frame behind)
+    // SLAM_MAP_AUTO: the session watches how many landmarks the frames observe ({observed, L, seq} in words 24..26 of h_res,
+    // left there by page_list_kernel / obs_count_kernel) and moves between rows and pages while it runs
+    int layout_cfg = SLAM_MAP_AUTO;
+    uint32_t obs_seq_issued = 0, obs_seq_seen = 0;
+    int votes_pages = 0, votes_rows = 0;
+    bool auto_stuck = false;        // a conversion ran out of memory: stay where we are
+    int64_t conversions = 0;
     bool counted = false;           // this session holds the engine's one session slot
     bool last_ekf = false;          // the last frame ran the landmark update (its log-likelihoods are in the engine)
     int32_t* sel = nullptr;         // grow-only scratch of slam_pf_get_map_rows_host: chosen particles | their source rows
@@ -198,6 +207,126 @@ int gathered_copy_out(slam_pf* pf, const float* d_src, const int32_t* idx, float
                                                                                                       : SLAM_ERR_HIP;
 }
 
+// ---- the landmark maps live in ONE allocation `store` of 2 x cap x 5 x Lp floats, seen either as two row buffers
+// (map[0] = the first half, map[1] = the second) or as a pool of 2 x cap x nb pages (the same bytes: a page is 5 x 32 floats,
+// a row nb of them).  The page tables, free list and stamps exist only for sessions that may be on pages.
+bool alloc_store(slam_pf* pf)
+{
+    const size_t half = 5 * (size_t)pf->Lp * (size_t)pf->cap;   // floats
+    if (dev_alloc((void**)&pf->store, 2 * half * 4) != hipSuccess) {
+        (void)hipGetLastError();
+        pf->store = nullptr;
+        return false;
+    }
+    pf->map[0] = pf->store;
+    pf->map[1] = pf->store + half;
+    pf->pool = pf->store;
+    return true;
+}
+
+void free_page_tables(slam_pf* pf)
+{
+    for (void** p : { (void**)&pf->pt[0], (void**)&pf->pt[1], (void**)&pf->freelist, (void**)&pf->stamp, (void**)&pf->page_scratch,
+                      (void**)&pf->votes }) {
+        if (*p) (void)hipFree(*p);
+        *p = nullptr;
+    }
+}
+
+bool alloc_page_tables(slam_pf* pf)
+{
+    const size_t P = (size_t)pf->npages, words = 2 * (size_t)pf->nb + 1 + (size_t)pool_state_words();
+    const bool ok = dev_alloc((void**)&pf->freelist, P * 4) == hipSuccess && dev_alloc((void**)&pf->stamp, P * 4) == hipSuccess &&
+                    hipMemset(pf->stamp, 0, P * 4) == hipSuccess && dev_alloc((void**)&pf->page_scratch, words * 4) == hipSuccess &&
+                    hipMemset(pf->page_scratch, 0, words * 4) == hipSuccess &&
+                    dev_alloc((void**)&pf->pt[0], (size_t)pf->cap * pf->nb * 4) == hipSuccess &&
+                    dev_alloc((void**)&pf->pt[1], (size_t)pf->cap * pf->nb * 4) == hipSuccess &&
+                    dev_alloc((void**)&pf->votes, 2 * 4) == hipSuccess && hipMemset(pf->votes, 0, 2 * 4) == hipSuccess;
+    if (!ok) {
+        (void)hipGetLastError();
+        free_page_tables(pf);
+    }
+    return ok;
+}
+
+// rows -> pages while the session runs: ONE kernel, stream-ordered, no allocation.  The current rows sit in one half of the
+// store (before the pending gather); they are written as pages into the OTHER half — page (other half's first page) + r * nb
+// + b behind identity tables, so the pending gather index means the same thing afterwards — and the half they came from
+// becomes free pages.
+int convert_to_pages(slam_pf* pf)
+{
+    slam_engine* e = pf->e;
+    const int mc = pf->map_cur;
+    const int page_base = (1 - mc) * pf->cap * pf->nb;
+    pf->pt_cur = 0;
+    SLAM_HIP_TRY(e, launch_pages_from_rows(e->stream, pf->map[mc], 5 * (int64_t)pf->Lp, pf->Lp, pf->L, pf->nb, pf->n, pf->pool,
+                                           pf->pt[0], pf->freelist, pf->npages, pf->page_scratch + 2 * pf->nb + 1, page_base));
+    pf->paged = true;
+    pf->conversions++;
+    return SLAM_OK;
+}
+
+// pages -> rows: the pages lie anywhere in the store, a row buffer is one contiguous half of it, so the rows are put
+// together in a scratch buffer first (row r = the pages table row r names, again before the pending gather) and copied
+// into the first half.  While it runs this takes half as much memory again; when that is not to be had the session stays
+// on pages.
+int convert_to_rows(slam_pf* pf)
+{
+    slam_engine* e = pf->e;
+    const size_t half = 5 * (size_t)pf->Lp * (size_t)pf->cap, used = 5 * (size_t)pf->Lp * (size_t)pf->n;
+    float* tmp = nullptr;
+    if (hipMalloc((void**)&tmp, used * 4) != hipSuccess) {
+        (void)hipGetLastError();
+        pf->auto_stuck = true;
+        return SLAM_OK;
+    }
+    int rc = SLAM_OK;
+    auto ok = [&](hipError_t err, const char* what) {
+        if (err != hipSuccess && rc == SLAM_OK) rc = slam_engine_fail_hip(e, err, what);
+        return err == hipSuccess;
+    };
+    (void)half;
+    ok(launch_rows_from_pages(e->stream, pf->pool, pf->pt[pf->pt_cur], pf->nb, nullptr, pf->n, tmp, 5 * (int64_t)pf->Lp, pf->Lp, pf->L),
+       "rows_from_pages") &&
+        ok(hipMemcpyAsync(pf->map[0], tmp, used * 4, hipMemcpyDeviceToDevice, e->stream), "hipMemcpyAsync") &&
+        ok(hipStreamSynchronize(e->stream), "hipStreamSynchronize");
+    (void)hipFree(tmp);
+    if (rc != SLAM_OK) return rc;
+    pf->map_cur = 0;
+    pf->paged = false;
+    pf->conversions++;
+    return SLAM_OK;
+}
+
+// SLAM_MAP_AUTO, at the start of a frame: look at the counts that have arrived since the last look (no waiting) and move
+// when the last three agree.  Pages pay when a frame observes at most a quarter of the landmarks (a resampling frame on
+// rows rewrites every row in full); rows pay when it observes more than half (every page is touched anyway and the row
+// kernels are faster at that).  Results do not depend on the layout, so the ranks of a sharded session may decide apart.
+int auto_layout(slam_pf* pf)
+{
+    if (pf->layout_cfg != SLAM_MAP_AUTO || pf->L == 0 || pf->auto_stuck) return SLAM_OK;
+    const int32_t* h = reinterpret_cast<const int32_t*>(pf->h_res) + 24;   // {observed, L, seq, votes_pages, votes_rows}
+    const volatile uint32_t* h_seq = reinterpret_cast<const volatile uint32_t*>(h) + 2;
+    // The first frames of a session WAIT for the sample of the frame before (it is taken early in that frame: the wait is
+    // about one motion + score launch), so that a session settles on its layout within its first four frames however far
+    // the host runs ahead of the device; later looks never wait.
+    if (pf->frame <= 3 && pf->obs_seq_issued != pf->obs_seq_seen) {
+        if (pf->comm) {
+            if (int rc = comm_wait_flag(pf->comm, h_seq, pf->obs_seq_issued)) return rc;
+        } else {
+            for (long spin = 0; spin < 400000000L && __atomic_load_n(h_seq, __ATOMIC_ACQUIRE) != pf->obs_seq_issued; ++spin) {}
+        }
+    }
+    const uint32_t seq = __atomic_load_n(h_seq, __ATOMIC_ACQUIRE);
+    if (seq == pf->obs_seq_seen) return SLAM_OK;
+    pf->obs_seq_seen = seq;
+    pf->votes_pages = h[3];   // samples in a row (counted on the device, so none is missed however far the host runs ahead)
+    pf->votes_rows = h[4];
+    if (!pf->paged && pf->votes_pages >= 3) return convert_to_pages(pf);
+    if (pf->paged && pf->votes_rows >= 3) return convert_to_rows(pf);
+    return SLAM_OK;
+}
+
 int create_common(slam_engine* e, const slam_pf_config* cfg, slam_comm* comm, int recv_capacity, slam_pf** out)
 {
     if (!e || !cfg || !out || cfg->n_particles <= 0 || cfg->n_landmarks < 0 || !(cfg->meas_var > 0.0f) ||
@@ -229,29 +358,36 @@ int create_common(slam_engine* e, const slam_pf_config* cfg, slam_comm* comm, in
         delete pf;
         return SLAM_ERR_CAPACITY;
     }
-    const size_t n = (size_t)pf->n, L = (size_t)pf->L, Lp = (size_t)pf->Lp, cap = (size_t)pf->cap, G = (size_t)pf->world;
+    const size_t n = (size_t)pf->n, L = (size_t)pf->L, cap = (size_t)pf->cap, G = (size_t)pf->world;
     bool ok = true;
-    pf->paged = pf->L > 0 && (cfg->map_layout == SLAM_MAP_PAGES || (cfg->map_layout == SLAM_MAP_AUTO && e->pf_paged));
-    if (pf->paged) {
-        pf->nb = pf->Lp / kPageLandmarks;
+    // slam_pf_paged_set(e, 1) turns an AUTO request into PAGES (sessions made while it is set stay on pages)
+    pf->layout_cfg = cfg->map_layout == SLAM_MAP_AUTO && e->pf_paged ? (int)SLAM_MAP_PAGES : cfg->map_layout;
+    pf->paged = pf->L > 0 && pf->layout_cfg == SLAM_MAP_PAGES;
+    pf->nb = pf->Lp / kPageLandmarks;
+    {
         const int64_t np = 2 * (int64_t)pf->cap * pf->nb;   // table rows (with the staging tail) never name more than half
-        if (np > 0x7fffffff - 8192) {   // page numbers are int32, and free_list_kernel's last tile may look 8191 past the end
-            delete pf;
-            return SLAM_ERR_CAPACITY;
+        // page numbers are int32, and free_list_kernel's last tile may look 8191 past the end
+        if (np > 0x7fffffff - 8192) {
+            if (pf->paged) {
+                delete pf;
+                return SLAM_ERR_CAPACITY;
+            }
+            pf->auto_stuck = true;   // too many pages for this population: AUTO stays on rows
         }
-        pf->npages = (int)np;
-        const size_t P = (size_t)pf->npages;
-        ok = dev_alloc((void**)&pf->pool, P * 5 * kPageLandmarks * 4) == hipSuccess &&
-             dev_alloc((void**)&pf->freelist, P * 4) == hipSuccess && dev_alloc((void**)&pf->stamp, P * 4) == hipSuccess &&
-             hipMemset(pf->stamp, 0, P * 4) == hipSuccess &&
-             dev_alloc((void**)&pf->page_scratch, (2 * (size_t)pf->nb + 1 + (size_t)pool_state_words()) * 4) == hipSuccess &&
-             hipMemset(pf->page_scratch, 0, (2 * (size_t)pf->nb + 1 + (size_t)pool_state_words()) * 4) == hipSuccess;
+        pf->npages = np > 0x7fffffff - 8192 ? 0 : (int)np;
+        if (pf->nb < 2) pf->auto_stuck = true;   // one page per particle: nothing to gain from pages
+    }
+    if (L) ok = alloc_store(pf);
+    if (L && ok && (pf->paged || (pf->layout_cfg == SLAM_MAP_AUTO && !pf->auto_stuck))) {
+        ok = alloc_page_tables(pf);
+        if (!ok && !pf->paged) {   // AUTO can live without them: it stays on rows
+            pf->auto_stuck = true;
+            ok = true;
+        }
     }
     for (int b = 0; b < 2; ++b) {
         ok = ok && dev_alloc((void**)&pf->pose[b], 3 * n * 4) == hipSuccess;
         ok = ok && dev_alloc((void**)&pf->anc[b], n * 4) == hipSuccess;
-        if (L && !pf->paged) ok = ok && dev_alloc((void**)&pf->map[b], 5 * Lp * cap * 4) == hipSuccess;
-        if (pf->paged) ok = ok && dev_alloc((void**)&pf->pt[b], cap * (size_t)pf->nb * 4) == hipSuccess;
         if (comm) ok = ok && dev_alloc((void**)&pf->pose_idx[b], n * 4) == hipSuccess;
     }
     ok = ok && dev_alloc((void**)&pf->score, n * 4) == hipSuccess && dev_alloc((void**)&pf->logw, n * 4) == hipSuccess &&
@@ -323,16 +459,15 @@ int slam_pf_destroy(slam_pf* pf)
     for (int b = 0; b < 2; ++b) {
         (void)hipFree(pf->pose[b]);
         (void)hipFree(pf->anc[b]);
-        (void)hipFree(pf->map[b]);
         (void)hipFree(pf->pose_idx[b]);
     }
+    if (pf->store) (void)hipFree(pf->store);
+    free_page_tables(pf);
     for (void* p : { (void*)pf->score, (void*)pf->logw, (void*)pf->count, (void*)pf->first, (void*)pf->pose_all, (void*)pf->pose_stage, (void*)pf->first_all,
                      (void*)pf->d_max, (void*)pf->d_sum, (void*)pf->totals, (void*)pf->d_plan, (void*)pf->sbuf,
                      (void*)pf->rbuf, (void*)pf->res_dev, (void*)pf->sums_acc, pf->res_all })
         (void)hipFree(p);
-    for (void* p : { (void*)pf->pool, (void*)pf->pt[0], (void*)pf->pt[1], (void*)pf->freelist, (void*)pf->stamp,
-                     (void*)pf->page_scratch, (void*)pf->sel })
-        (void)hipFree(p);
+    (void)hipFree(pf->sel);
     if (pf->h_res) (void)hipHostFree(pf->h_res);
     delete pf;
     return SLAM_OK;
@@ -446,8 +581,15 @@ static int pf_step_impl(slam_pf* pf, int slot, const float dp[3], int use_observ
         snprintf(e->err, sizeof e->err, "paged maps: a free list was shorter than the pages reserved from it (pool invariant broken)");
         return SLAM_ERR_CAPACITY;
     }
+    if (int rc0 = auto_layout(pf)) return rc0;   // may move the maps between rows and pages (never changes a result)
     const int n = pf->n, L = pf->L, cur = pf->cur, nxt = 1 - cur;
     const size_t sn = (size_t)n;
+    // SLAM_MAP_AUTO samples the number of observed landmarks: every frame at the start and while the counts speak against
+    // the current layout, every 8th frame otherwise
+    const bool sample_obs = pf->layout_cfg == SLAM_MAP_AUTO && !pf->auto_stuck && L > 0 && use_observations &&
+                            e->obs_nlandmarks == L &&
+                            (pf->frame < 8 || (pf->frame & 7u) == 0 || (pf->paged ? pf->votes_rows : pf->votes_pages) > 0);
+    int32_t* d_hobs = reinterpret_cast<int32_t*>(pf->d_hres) + 24;
     const float* src = pf->pose[cur];
     float* dst = pf->pose[nxt];
     const int32_t* anc = pf->has_anc ? pf->anc[cur] : nullptr;
@@ -496,7 +638,9 @@ static int pf_step_impl(slam_pf* pf, int slot, const float dp[3], int use_observ
             int32_t *tpage = pf->page_scratch, *tindex = tpage + pf->nb, *count = tindex + pf->nb, *pstate = count + 1;
             {
                 const ProfScope prof(e, SLAM_PROF_PAGES);
-                SLAM_HIP_TRY(e, launch_page_list(e->stream, e->d_obs_zx, e->d_obs_zy, L, pf->nb, tpage, tindex, count, n, pstate));
+                SLAM_HIP_TRY(e, launch_page_list(e->stream, e->d_obs_zx, e->d_obs_zy, L, pf->nb, tpage, tindex, count, n, pstate,
+                                                 sample_obs ? d_hobs : nullptr, sample_obs ? ++pf->obs_seq_issued : 0,
+                                                 sample_obs ? pf->votes : nullptr));
                 // a new free list when the old one runs short (decided on the device; the pages in use carry the last stamp)
                 SLAM_HIP_TRY(e, launch_free_list(e->stream, pf->stamp, pf->npages, pf->stamp_now, pf->freelist, pstate,
                                                  reinterpret_cast<int32_t*>(pf->d_hres) + 20));
@@ -538,11 +682,13 @@ static int pf_step_impl(slam_pf* pf, int slot, const float dp[3], int use_observ
             rc = slam_logweight_dev(e, pf->score, nullptr, pf->cfg.score_gain, n, pf->logw, d_max);
         }
     } else if (ekf && in_place) {
+        if (sample_obs) SLAM_HIP_TRY(e, launch_obs_count(e->stream, e->d_obs_zx, e->d_obs_zy, L, d_hobs, ++pf->obs_seq_issued, pf->votes));
         rc = slam_ekf_update_dev(e, pf->map[mc], pf->map[mc], 5 * (int64_t)pf->Lp, pf->Lp, L, dst, dst + sn, dst + 2 * sn, nullptr, n,
                                  pf->cfg.meas_var, nullptr);
         if (rc != SLAM_OK) return rc;
         rc = slam_logweight_ekf_dev(e, pf->score, pf->cfg.score_gain, n, pf->logw, d_max);
     } else if (ekf) {
+        if (sample_obs) SLAM_HIP_TRY(e, launch_obs_count(e->stream, e->d_obs_zx, e->d_obs_zy, L, d_hobs, ++pf->obs_seq_issued, pf->votes));
         rc = slam_ekf_update_dev(e, pf->map[mc], pf->map[mn], 5 * (int64_t)pf->Lp, pf->Lp, L, dst, dst + sn, dst + 2 * sn, anc, n,
                                  pf->cfg.meas_var, nullptr);
         if (rc != SLAM_OK) return rc;
@@ -592,6 +738,8 @@ static int pf_step_impl(slam_pf* pf, int slot, const float dp[3], int use_observ
 int slam_pf_rows_received(const slam_pf* pf) { return pf ? pf->rows_received : 0; }
 
 int64_t slam_pf_frames_resampled(const slam_pf* pf) { return pf ? pf->frames_resampled : 0; }
+
+int64_t slam_pf_layout_changes(const slam_pf* pf) { return pf ? pf->conversions : 0; }
 
 int slam_pf_device_view(slam_pf* pf, slam_pf_view* out)
 {

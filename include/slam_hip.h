@@ -397,6 +397,13 @@ typedef struct {
  * entries and rewrites only the pages that hold an observed landmark: the fastest form when a frame observes few of
  * many).  Both give the same bits.  SLAM_MAP_AUTO lets the session choose and change its mind while it runs. */
 typedef enum { SLAM_MAP_AUTO = 0, SLAM_MAP_ROWS = 1, SLAM_MAP_PAGES = 2 } slam_map_layout;
+/* SLAM_MAP_AUTO starts on rows and watches how many landmarks the frames observe (a count the update kernels leave in
+ * mapped host memory: every frame at the start and while they speak against the current layout, every 8th frame otherwise;
+ * read without waiting, except in a session's first four frames, which wait for the count of the frame before so that the
+ * layout is settled by then): three counts in a row of at most
+ * a quarter of the landmarks move the maps to pages, three in a row of more than half move them back.  A move costs one
+ * pass over the maps and, while it runs, half as much memory again as the steady state (one row buffer beside the pool);
+ * when that is not to be had the session stays where it is.  Sessions with at most 32 landmarks stay on rows. */
 
 int slam_pf_create(slam_engine *e, const slam_pf_config *cfg, slam_pf **out);
 
@@ -483,6 +490,8 @@ int slam_pf_rows_received(const slam_pf *pf);
 /* With cfg.resample_ess_frac in (0, 1): how many of the frames the host has looked at so far did resample (the
  * verdict of a frame is read at the start of the next one).  Without a gate: 0 (every frame resamples). */
 int64_t slam_pf_frames_resampled(const slam_pf *pf);
+/* how often a SLAM_MAP_AUTO session has moved its maps between rows and pages so far */
+int64_t slam_pf_layout_changes(const slam_pf *pf);
 /* The session's CURRENT device buffers, for hosts that fill or inspect the population on the device instead of
  * through the *_host copies (a 52 GB map does not want to pass through host memory): pose = [x | y | theta] of
  * n_particles floats each; map = one row per particle, row_stride floats apart, five planes of plane_stride floats

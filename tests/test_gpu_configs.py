@@ -168,7 +168,7 @@ def test_ekf_long_rows_small_n(eng, orc, L, Lp):
 
 # ------------------------------------------------------------------ the sharded C session (slam_pf_create_sharded)
 def _run_c_session_ranks(world, n_total, L, frames, transport="local", recv_capacity=0, ess=0.0, inplace_form=-1, paged=False,
-                         fail_rank=None, fail_frame=None):
+                         fail_rank=None, fail_frame=None, layout=None, sparse_obs=False):
     """`world` ranks of the C-level sharded session in THIS process, one host thread per rank, all on cuda:0
     (in-process transport), or a one-rank RCCL communicator.  Returns the concatenated population."""
     import threading
@@ -199,7 +199,7 @@ def _run_c_session_ranks(world, n_total, L, frames, transport="local", recv_capa
                 comm = pkg.Comm.rccl(eng, r, world, uid)
             ses = pkg.PfSession(eng, n, L, seed=77, sigma=(0.02, 0.02, 0.004), meas_var=0.02,
                                 score_gain=0.05 if L else 1.0, comm=comm, recv_capacity=recv_capacity,
-                                resample_ess_frac=ess, map_layout="pages" if paged else "rows")
+                                resample_ess_frac=ess, map_layout=layout or ("pages" if paged else "rows"))
             sl = slice(r * n, (r + 1) * n)
             ses.set_poses(x[sl], y[sl], th[sl])
             if L:
@@ -210,14 +210,18 @@ def _run_c_session_ranks(world, n_total, L, frames, transport="local", recv_capa
                 if r == fail_rank and f == fail_frame:
                     comm.abort()                            # this rank gives up: the others must fail, not wait
                     raise RuntimeError("rank gave up")
-                if use:
+                if use and sparse_obs:                      # 12 neighbouring landmarks: under a quarter of the map
+                    ids = ((np.arange(12) + 17 * f) % L).astype(np.int32)
+                    z = lm[ids] + 0.01 * np.float32(f)
+                    eng.obs_upload(ids, z[:, 0].copy(), z[:, 1].copy(), L)
+                elif use:
                     eng.obs_upload(*W.observations(lm, f), L)
                 ses.step(0, [0.01, -0.005, 0.002], use)
                 rows.append(ses.rows_received())
                 if f % 3 == 1:
                     bests.append(ses.best())                 # collective; must not disturb the pending exchange
             res = {"pose": ses.poses(), "best": ses.best(), "rows": rows, "bests": bests, "resampled": ses.frames_resampled(),
-                   "mean": ses.mean(0.07)}
+                   "mean": ses.mean(0.07), "paged_end": ses.is_paged()}
             if L:
                 res["map"] = ses.maps()
             out[r] = res

@@ -21,10 +21,10 @@ def _run(paged, n, L, frames, ess, obs_of, start):
     lm = lm[:L]
     x, y, th, mp = W.init_state(n, L, lm)
     eng = pkg.Engine(0)
-    eng.pf_paged_set(paged)
     eng.grid_set_dev(0, torch.from_numpy(edt).to(DEV), pkg.grid_meta(meta.rows, meta.cols, meta.ld, meta.pixel, meta.min_x, meta.min_y))
     eng.scan_upload(bx, by)
-    ses = pkg.PfSession(eng, n, L, seed=77, sigma=(0.02, 0.02, 0.004), meas_var=0.02, score_gain=0.05, resample_ess_frac=ess)
+    ses = pkg.PfSession(eng, n, L, seed=77, sigma=(0.02, 0.02, 0.004), meas_var=0.02, score_gain=0.05, resample_ess_frac=ess,
+                        map_layout="pages" if paged else "rows")
     assert ses.is_paged() == bool(paged)
     if start == "empty":
         ses.reset([0.0, 0.0, 0.0])
