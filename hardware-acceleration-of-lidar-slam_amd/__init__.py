@@ -96,6 +96,8 @@ SIGNATURES = {
     "slam_gather_f32_dev": (_i, [_vp, _vp, _vp, _i, _vp]),
     "slam_gather_map_dev": (_i, [_vp, _vp, _vp, _i64, _i64, _i, _i, _i, _vp, _i]),
     "slam_mapper_create": (_i, [_vp, _i, _f, _f, C.POINTER(_vp)]),
+    "slam_mapper_create_ex": (_i, [_vp, _i, _f, _f, _vp, C.POINTER(_vp)]),
+    "slam_mapper_params_default": (None, [_vp]),
     "slam_mapper_destroy": (_i, [_vp]),
     "slam_mapper_first_frame": (_i, [_vp, _vp]),
     "slam_mapper_next_frame": (_i, [_vp, _vp, _fp]),
@@ -453,6 +455,24 @@ class Engine:
         self._ck(self.lib.slam_gather_map_dev(self.h, _ptr(d_in), _ptr(d_out), in_row_stride, out_row_stride,
                                               in_plane_stride, out_plane_stride, nlandmarks, _ptr(d_idx), n),
                  "gather_map_dev")
+
+
+class MapperParams(C.Structure):
+    """``slam_mapper_params``: the reference's run-time parameters (main.c:832-839, :50, :846, :224, :943)."""
+
+    _fields_ = [("fast_res", C.c_float * 3), ("fast_res2", C.c_float * 3), ("border", C.c_float), ("pixel", C.c_float),
+                ("pixel2", C.c_float), ("key_dt", C.c_float), ("key_dr", C.c_float), ("range_min", C.c_float),
+                ("usable_range", C.c_float), ("edt_cap", C.c_float), ("new_point_threshold", C.c_float)]
+
+    @classmethod
+    def default(cls):
+        p = cls()
+        load_library().slam_mapper_params_default(C.byref(p))
+        return p
+
+    def as_list(self):
+        return list(self.fast_res) + list(self.fast_res2) + [self.border, self.pixel, self.pixel2, self.key_dt, self.key_dr,
+                                                             self.range_min, self.usable_range, self.edt_cap, self.new_point_threshold]
 
 
 class PfConfig(C.Structure):

@@ -754,6 +754,34 @@ int slam_ekf_update_dev(slam_engine* e, const float* d_map_in, float* d_map_out,
     return SLAM_OK;
 }
 
+}  // extern "C"
+
+int slam_engine_obs_list(slam_engine* e, int nlandmarks, slam::ObsListView* out)
+{
+    if (nlandmarks > kObsListMaxLandmarks || e->obs_nlandmarks != nlandmarks) return SLAM_ERR_INVALID_ARG;
+    const size_t L = (size_t)nlandmarks;
+    if (!e->obs_table_owned) e->obs_list_valid = false;   // the caller's arrays may have been rewritten since the last launch
+    if (e->obs_list.cap < 4 * (4 * L + 2)) {
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        HIP_TRY(e->obs_list.ensure(4 * (4 * L + 2)));
+        e->obs_list_valid = false;
+    }
+    int32_t* li = e->obs_list.as<int32_t>();
+    if (!e->obs_list_valid) {
+        HIP_TRY(launch_build_obs_list(e->stream, e->d_obs_zx, e->d_obs_zy, nlandmarks, li, (float*)(li + L), (float*)(li + 2 * L),
+                                      li + 3 * L, li + 4 * L, e->d_hobs));
+        e->obs_list_valid = true;
+    }
+    out->id = li;
+    out->zx = (const float*)(li + L);
+    out->zy = (const float*)(li + 2 * L);
+    out->round = li + 3 * L;
+    out->count = li + 4 * L;
+    return SLAM_OK;
+}
+
+extern "C" {
+
 int slam_ekf_form_set(slam_engine* e, int form)
 {
     ENTER(e);

@@ -61,7 +61,7 @@ hipError_t launch_crop(hipStream_t s, const float* tx, const float* ty, const in
 hipError_t launch_rasterise(hipStream_t s, const float* lx, const float* ly, const int32_t* lsize, float pixel, int ld,
                             int32_t* grid, slam_grid_meta* meta);
 hipError_t launch_map_append(hipStream_t s, const float* hits, int nhits, const float* tx, const float* ty, float* mx,
-                             float* my, int32_t* msize, int map_cap);
+                             float* my, int32_t* msize, int map_cap, float threshold);
 
 // ---- edt_kernels.hip (row A6; reference: main.c:223-269, main_accelerated.c:215-283)
 enum { EDT_MAX_RADIUS = 32 };
@@ -103,6 +103,13 @@ hipError_t launch_ekf_sparse(hipStream_t stream, const EkfArgs& a, const int32_t
                              const int32_t* round, const int32_t* count, const EventPair* ev = nullptr);
 // ---- paged_kernels.hip: landmark maps as copy-on-write pages of kPageLandmarks landmarks (5 planes x 32 floats = 640 B)
 constexpr int kPageLandmarks = 32;
+// the compact observation list launch_build_obs_list makes: ids ascending, measurements, accumulator rounds, {nobs, highest round}
+struct ObsListView {
+    const int32_t* id = nullptr;
+    const float *zx = nullptr, *zy = nullptr;
+    const int32_t* round = nullptr;
+    const int32_t* count = nullptr;
+};
 struct PagedEkfArgs {
     float* pool;             // [npages][5][32]
     const int32_t* pt_in;    // [rows][nb] page tables of the ancestors
@@ -116,6 +123,9 @@ struct PagedEkfArgs {
     float* loglik;
     float* loglik_user;
     const int32_t *tpage, *tindex, *count;   // launch_page_list of the same table
+    const int32_t* tmask;                    // ... bit s of tmask[t]: landmark s of touched page t is observed
+    const int32_t* tbase;                    // ... tbase[t]: observations in the touched pages before t (tbase[T]: all)
+    ObsListView ol;                          // the same observations as a list (the list form of the update)
     const int32_t* freelist;                 // particle i takes entries pool_state[base] + [i * T, (i + 1) * T)
     const int32_t* pool_state;               // written by launch_page_list of this frame
     uint32_t* stamp;                         // [npages]: every page a new table names gets stamp_now
@@ -127,11 +137,15 @@ int pool_state_words();
 // h_obs + votes (optional): the launch also takes SLAM_MAP_AUTO's sample — votes[2] (device): samples in a row with at most
 // a quarter / more than half of the landmarks observed; h_obs (mapped host memory): {observed, L, seq, votes[0], votes[1]}
 hipError_t launch_page_list(hipStream_t stream, const float* zx, const float* zy, int L, int nb, int32_t* tpage, int32_t* tindex,
-                            int32_t* count, int n, int32_t* pool_state, int32_t* h_obs = nullptr, uint32_t seq = 0,
-                            int32_t* votes = nullptr);
+                            int32_t* tmask, int32_t* tbase, int32_t* count, int n, int32_t* pool_state, int32_t* h_obs = nullptr,
+                            uint32_t seq = 0, int32_t* votes = nullptr, int32_t* h_touched = nullptr);
 // the same sample as a launch of its own (one small workgroup), for sessions on rows
 hipError_t launch_obs_count(hipStream_t stream, const float* zx, const float* zy, int L, int32_t* h_obs, uint32_t seq, int32_t* votes);
-hipError_t launch_ekf_paged(hipStream_t stream, const PagedEkfArgs& a, const EventPair* ev = nullptr);
+// form 0: every lane of a touched page runs the update arithmetic, one page after the other; form 1 (needs a.ol): the
+// touched pages go through an LDS image, several at a time with all their loads in flight together, and the arithmetic
+// runs once per observation, one lane each — the same bits.  touched_hint: pages to stage per pass (<= 0: a default)
+hipError_t launch_ekf_paged(hipStream_t stream, const PagedEkfArgs& a, const EventPair* ev = nullptr, int form = 1,
+                            int touched_hint = 0);
 hipError_t launch_page_table_gather(hipStream_t stream, const int32_t* pt_in, int32_t* pt_out, int nb, const int32_t* anc, int n,
                                     uint32_t* stamp, uint32_t stamp_now);
 // free list = pages whose stamp differs from `live`, the stamp of the last update (in no particular order); does

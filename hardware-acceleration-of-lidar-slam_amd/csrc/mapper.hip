@@ -22,6 +22,7 @@ enum { kMapCap = 20000, kLocalCap = 25000, kCoarseLd = 200, kFineLd = 400 };   /
 struct slam_mapper {
     slam_engine* e = nullptr;
     int nbeams = 0;
+    slam_mapper_params par{};   // the reference's run-time parameters (main.c:832-839, :50, :846, :224, :943)
     // device state
     DevBuf buf;   // one allocation, carved below
     float *d_cos = nullptr, *d_sin = nullptr, *d_range = nullptr, *d_bx = nullptr, *d_by = nullptr, *d_tx = nullptr,
@@ -48,8 +49,8 @@ int upload_ranges(slam_mapper* m, const float* ranges)
     memcpy(m->h_range, ranges, sizeof(float) * (size_t)m->nbeams);
     MP_TRY(hipMemcpyAsync(m->d_range, m->h_range, sizeof(float) * (size_t)m->nbeams, hipMemcpyHostToDevice, st));
     // main.c:863 readAScan(24): range_min 0.023 (main.c:50), usable range 24
-    MP_TRY(launch_clean_scan(st, m->d_range, m->d_cos, m->d_sin, m->nbeams, 0.023f, 24.0f, m->d_bx, m->d_by,
-                             m->d_counts + 0));
+    MP_TRY(launch_clean_scan(st, m->d_range, m->d_cos, m->d_sin, m->nbeams, m->par.range_min, m->par.usable_range, m->d_bx,
+                             m->d_by, m->d_counts + 0));
     return SLAM_OK;
 }
 
@@ -65,9 +66,9 @@ int rebuild_grids(slam_mapper* m)
 {
     hipStream_t st = m->e->stream;
     // main.c:870-871: ExtractLocalMap(borderSize = 1), OccupationalGrid(0.2, 0.1)
-    MP_TRY(launch_crop(st, m->d_tx, m->d_ty, m->d_counts + 0, 1.0f, m->d_mx, m->d_my, m->d_counts + 1, kLocalCap,
+    MP_TRY(launch_crop(st, m->d_tx, m->d_ty, m->d_counts + 0, m->par.border, m->d_mx, m->d_my, m->d_counts + 1, kLocalCap,
                        m->d_lx, m->d_ly, m->d_counts + 2));
-    const float pix[2] = { 0.2f, 0.1f };
+    const float pix[2] = { m->par.pixel, m->par.pixel2 };
     const int ld[2] = { kCoarseLd, kFineLd };
     for (int k = 0; k < 2; ++k)
         MP_TRY(launch_rasterise(st, m->d_lx, m->d_ly, m->d_counts + 2, pix[k], ld[k], m->d_occ[k], m->d_meta + k));
@@ -77,7 +78,7 @@ int rebuild_grids(slam_mapper* m)
     for (int k = 0; k < 2; ++k) {
         if (h_meta[k].rows < 1 || h_meta[k].cols < 1 || h_meta[k].rows > ld[k] || h_meta[k].cols > ld[k])
             return SLAM_ERR_CAPACITY;   // the reference would overrun its 200^2 / 400^2 grids here
-        MP_TRY(launch_edt(st, m->d_occ[k], ld[k], h_meta[k].rows, h_meta[k].cols, 10.0f /* main.c:224 */, m->d_edt[k]));
+        MP_TRY(launch_edt(st, m->d_occ[k], ld[k], h_meta[k].rows, h_meta[k].cols, m->par.edt_cap /* main.c:224 */, m->d_edt[k]));
         int rc = slam_grid_set_dev(m->e, k, m->d_edt[k], &h_meta[k]);
         if (rc != SLAM_OK) return rc;
     }
@@ -88,16 +89,42 @@ int rebuild_grids(slam_mapper* m)
 
 extern "C" {
 
+void slam_mapper_params_default(slam_mapper_params* p)
+{
+    if (!p) return;
+    const slam_mapper_params d = { { 0.05f, 0.05f, 0.008727f },    // main.c:832
+                                   { 0.025f, 0.025f, 0.004363f },  // main.c:833
+                                   1.0f, 0.2f, 0.1f,               // main.c:834-836
+                                   0.3f, 0.0872665f,               // main.c:838-839
+                                   0.023f, 24.0f,                  // main.c:50, :846
+                                   10.0f, 1.5f };                  // main.c:224, :943
+    *p = d;
+}
+
 int slam_mapper_create(slam_engine* e, int nbeams, float angle_min, float angle_inc, slam_mapper** out)
+{
+    return slam_mapper_create_ex(e, nbeams, angle_min, angle_inc, nullptr, out);
+}
+
+int slam_mapper_create_ex(slam_engine* e, int nbeams, float angle_min, float angle_inc, const slam_mapper_params* params,
+                          slam_mapper** out)
 {
     if (!e || !out || nbeams <= 0) return SLAM_ERR_INVALID_ARG;
     if (nbeams > SLAM_MAX_BEAMS) return SLAM_ERR_CAPACITY;
+    slam_mapper_params par;
+    slam_mapper_params_default(&par);
+    if (params) par = *params;
+    if (!(par.pixel > 0.0f) || !(par.pixel2 > 0.0f) || !(par.border >= 0.0f) || !(par.edt_cap >= 0.0f) || !(par.key_dt >= 0.0f) ||
+        !(par.key_dr >= 0.0f) || !(par.usable_range >= par.range_min))
+        return SLAM_ERR_INVALID_ARG;
+    if (ceilf(par.edt_cap) > (float)EDT_MAX_RADIUS) return SLAM_ERR_CAPACITY;
     *out = nullptr;
     if (int rc = slam_engine_sync(e)) return rc;
     slam_mapper* m = new (std::nothrow) slam_mapper();
     if (!m) return SLAM_ERR_HIP;
     m->e = e;
     m->nbeams = nbeams;
+    m->par = par;
     m->map_cap = kMapCap + nbeams;
     const size_t nb = (size_t)nbeams;
     const size_t floats = 8 * nb + 2 * (size_t)m->map_cap + 2 * (size_t)kLocalCap + (size_t)kCoarseLd * kCoarseLd +
@@ -172,7 +199,7 @@ int slam_mapper_first_frame(slam_mapper* m, const float* ranges)
     int32_t nscan = 0;
     MP_TRY(hipMemcpyAsync(&nscan, m->d_counts + 0, 4, hipMemcpyDeviceToHost, st));
     MP_TRY(hipStreamSynchronize(st));
-    MP_TRY(launch_map_append(st, m->d_hits, nscan, m->d_tx, m->d_ty, m->d_mx, m->d_my, m->d_counts + 1, m->map_cap));
+    MP_TRY(launch_map_append(st, m->d_hits, nscan, m->d_tx, m->d_ty, m->d_mx, m->d_my, m->d_counts + 1, m->map_cap, 1.5f));
     MP_TRY(hipMemsetAsync(m->d_hits, 0, 4 * (size_t)m->nbeams, st));
     m->mini_updated = 1;
     m->frame = 1;
@@ -184,8 +211,8 @@ int slam_mapper_next_frame(slam_mapper* m, const float* ranges, float pose_out[3
 {
     if (!m || !ranges || !pose_out || m->frame < 1) return SLAM_ERR_INVALID_ARG;
     SLAM_HIP_TRY(m->e, hipSetDevice(m->e->device));
-    const float coarse[3] = { 0.05f, 0.05f, 0.008727f };   // main.c:832
-    const float fine[3] = { 0.025f, 0.025f, 0.004363f };   // main.c:833
+    const float* coarse = m->par.fast_res;   // main.c:832
+    const float* fine = m->par.fast_res2;    // main.c:833
     if (int rc = upload_ranges(m, ranges)) return rc;
     int in_world = 0;
     if (m->mini_updated) {   // main.c:865-872 — world points from the OLD pose
@@ -206,13 +233,13 @@ int slam_mapper_next_frame(slam_mapper* m, const float* ranges, float pose_out[3
     memcpy(m->prev, m->pose, sizeof m->prev);
     memcpy(m->pose, m2, sizeof m->pose);
     // main.c:928-961
-    if (fabsf(m->pose[0] - m->map_pose[0]) > 0.3f || fabsf(m->pose[1] - m->map_pose[1]) > 0.3f ||
-        fabsf(m->pose[2] - m->map_pose[2]) > 0.0872665f) {
+    if (fabsf(m->pose[0] - m->map_pose[0]) > m->par.key_dt || fabsf(m->pose[1] - m->map_pose[1]) > m->par.key_dt ||
+        fabsf(m->pose[2] - m->map_pose[2]) > m->par.key_dr) {
         m->mini_updated = 1;
         if (!in_world)
             if (int rc2 = to_world(m, m->pose)) return rc2;
         MP_TRY(launch_map_append(m->e->stream, m->d_hits, m->nhits, m->d_tx, m->d_ty, m->d_mx, m->d_my,
-                                 m->d_counts + 1, m->map_cap));
+                                 m->d_counts + 1, m->map_cap, m->par.new_point_threshold));
         memcpy(m->map_pose, m->pose, sizeof m->map_pose);
     } else {
         m->mini_updated = 0;

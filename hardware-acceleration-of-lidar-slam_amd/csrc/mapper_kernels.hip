@@ -174,14 +174,14 @@ __global__ __launch_bounds__(kMapBlock) void rasterise_kernel(const float* __res
 __global__ __launch_bounds__(kMapBlock) void map_append_kernel(const float* __restrict__ hits, int nhits,
                                                                const float* __restrict__ tx, const float* __restrict__ ty,
                                                                float* __restrict__ mx, float* __restrict__ my,
-                                                               int32_t* __restrict__ msize, int map_cap)
+                                                               int32_t* __restrict__ msize, int map_cap, float threshold)
 {
     __shared__ int s_wave[kMapBlock / 64];
     const int m0 = *msize;
     int base = 0;
     for (int j0 = 0; j0 < nhits; j0 += kMapBlock) {
         const int j = j0 + threadIdx.x;
-        const bool keep = j < nhits && hits[j] > 1.5f;
+        const bool keep = j < nhits && hits[j] > threshold;   // main.c:943 (1.5)
         const int slot = block_compact_slot(keep, base, s_wave);
         if (slot >= 0 && m0 + slot < map_cap) { mx[m0 + slot] = tx[j]; my[m0 + slot] = ty[j]; }
     }
@@ -217,9 +217,9 @@ hipError_t launch_rasterise(hipStream_t s, const float* lx, const float* ly, con
     return hipGetLastError();
 }
 hipError_t launch_map_append(hipStream_t s, const float* hits, int nhits, const float* tx, const float* ty, float* mx,
-                             float* my, int32_t* msize, int map_cap)
+                             float* my, int32_t* msize, int map_cap, float threshold)
 {
-    map_append_kernel<<<1, kMapBlock, 0, s>>>(hits, nhits, tx, ty, mx, my, msize, map_cap);
+    map_append_kernel<<<1, kMapBlock, 0, s>>>(hits, nhits, tx, ty, mx, my, msize, map_cap, threshold);
     return hipGetLastError();
 }
 

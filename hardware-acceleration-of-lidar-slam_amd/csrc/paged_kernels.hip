@@ -17,8 +17,10 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "det_math.h"
+#include "ekf_math.h"
 #include "kernels.h"
 
 namespace slam {
@@ -79,17 +81,21 @@ __device__ __forceinline__ void publish_obs_count(int nobs, int L, int32_t* __re
 }
 
 // h_obs (optional, mapped host memory; then votes != nullptr too): this launch also takes SLAM_MAP_AUTO's sample.
+// Besides tpage / tindex / count: tmask[t] = which landmarks of touched page t are observed (bit s = landmark s of the
+// page), tbase[t] = how many observations lie in the touched pages before t (tbase[T] = all of them) — the observation
+// list of build_obs_list_kernel is sorted by landmark, so the observations of page t are its entries tbase[t] .. tbase[t+1].
 __global__ __launch_bounds__(1024) void page_list_kernel(const float* __restrict__ zx, const float* __restrict__ zy, int L,
                                                          int nb, int32_t* __restrict__ tpage, int32_t* __restrict__ tindex,
+                                                         int32_t* __restrict__ tmask, int32_t* __restrict__ tbase,
                                                          int32_t* __restrict__ count, int n, int32_t* __restrict__ pool_state,
-                                                         int32_t* __restrict__ h_obs, uint32_t seq, int32_t* __restrict__ votes)
+                                                         int32_t* __restrict__ h_obs, uint32_t seq, int32_t* __restrict__ votes,
+                                                         int32_t* __restrict__ h_touched)
 {
-    __shared__ int s_wave[16];
-    __shared__ int s_base;
-    __shared__ int s_nobs;
+    __shared__ int s_wave[16], s_wobs[16];
+    __shared__ int s_base, s_obase;
     if (threadIdx.x == 0) {
         s_base = 0;
-        s_nobs = 0;
+        s_obase = 0;
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -103,7 +109,6 @@ __global__ __launch_bounds__(1024) void page_list_kernel(const float* __restrict
             ob = vx == vx && vy == vy;
         }
         const unsigned long long m = __ballot(ob);
-        if (h_obs && lane == 0 && m) atomicAdd(&s_nobs, __popcll(m));
         int touched_before = 0, touched_mine = 0, touched_all = 0;   // pages of this wavefront: below mine / mine / all
 #pragma unroll
         for (int g = 0; g < kPerWave; ++g) {
@@ -112,29 +117,46 @@ __global__ __launch_bounds__(1024) void page_list_kernel(const float* __restrict
             if (g < lane / kPage) touched_before += tg;
             if (g == lane / kPage) touched_mine = tg;
         }
-        if (lane == 0) s_wave[wave] = touched_all;
+        if (lane == 0) {
+            s_wave[wave] = touched_all;
+            s_wobs[wave] = __popcll(m);
+        }
         __syncthreads();
-        int off = s_base;
-        for (int w = 0; w < wave; ++w) off += s_wave[w];
+        int off = s_base, ooff = s_obase;
+        for (int w = 0; w < wave; ++w) {
+            off += s_wave[w];
+            ooff += s_wobs[w];
+        }
         const int b = l0 / kPage + kPerWave * wave + lane / kPage;
         if (lane % kPage == 0 && b < nb) {
             const int t = off + touched_before;
             tindex[b] = touched_mine ? t : -1;
-            if (touched_mine) tpage[t] = b;
+            if (touched_mine) {
+                const int g = lane / kPage;
+                tpage[t] = b;
+                tmask[t] = (int32_t)(uint32_t)(m >> (g * kPage) & kMask);
+                tbase[t] = ooff + __popcll(m & ((1ull << (g * kPage)) - 1ull));   // observations in the pages before this one
+            }
         }
         __syncthreads();
         if (threadIdx.x == 0) {
-            int tot = 0;
-            for (int w = 0; w < 16; ++w) tot += s_wave[w];
+            int tot = 0, otot = 0;
+            for (int w = 0; w < 16; ++w) {
+                tot += s_wave[w];
+                otot += s_wobs[w];
+            }
             s_base += tot;
+            s_obase += otot;
         }
         __syncthreads();
     }
     if (threadIdx.x == 0) {
         const int T = s_base;
         count[0] = T;
+        tbase[T] = s_obase;
+        if (h_touched) *h_touched = T;   // a hint for the host: how many pages the update's launches should stage at a time
         pool_reserve(pool_state, (int64_t)n * T);   // this frame's n * T fresh pages
-        if (h_obs) publish_obs_count(s_nobs, L, votes, h_obs, seq);
+        if (h_obs) publish_obs_count(s_obase, L, votes, h_obs, seq);
     }
 }
 
@@ -235,29 +257,8 @@ __global__ __launch_bounds__(kWaves * 64) void ekf_paged_kernel(PagedEkfArgs a)
             const bool in = l < a.nlandmarks;
             const float zx = in ? a.obs_zx[l] : __builtin_nanf(""), zy = in ? a.obs_zy[l] : __builtin_nanf("");
             const bool ob = zx == zx && zy == zy;
-            // the arithmetic of ekf_batches (pf_kernels.hip), one landmark per lane
-            const float dx = mx - px, dy = my - py;
-            const float vx = zx - (c * dx - s * dy);
-            const float vy = zy - (s * dx + c * dy);
-            const float a00 = c * pxx - s * pxy, a01 = c * pxy - s * pyy;
-            const float a10 = s * pxx + c * pxy, a11 = s * pxy + c * pyy;
-            const float s00 = (a00 * c - a01 * s) + q;
-            const float s01 = a00 * s + a01 * c;
-            const float s11 = (a10 * s + a11 * c) + q;
-            const float det = s00 * s11 - s01 * s01;
-            const float idet = 1.0f / det;
-            const float i00 = s11 * idet, i01 = -s01 * idet, i11 = s00 * idet;
-            const float k00 = a00 * i00 + a10 * i01, k01 = a00 * i01 + a10 * i11;
-            const float k10 = a01 * i00 + a11 * i01, k11 = a01 * i01 + a11 * i11;
-            const float o0 = mx + (k00 * vx + k01 * vy);
-            const float o1 = my + (k10 * vx + k11 * vy);
-            const float o2 = pxx - (k00 * a00 + k01 * a10);
-            const float o3 = pxy - (k00 * a01 + k01 * a11);
-            const float o4 = pyy - (k10 * a01 + k11 * a11);
-            const float maha = vx * (i00 * vx + i01 * vy) + vy * (i01 * vx + i11 * vy);
-            const float ll = ((0.0f - 0.5f * maha) - 0.5f * det_logf(det)) - 1.8378770664f;
-            const float f0 = px + (c * zx + s * zy);   // first sighting: the observed point, P = R, no likelihood
-            const float f1 = py + (c * zy - s * zx);
+            const EkfResult<float> u = ekf_update_one<float>(mx, my, pxx, pxy, pyy, zx, zy, s, c, px, py, q);   // one landmark per lane
+            const float o0 = u.o0, o1 = u.o1, o2 = u.o2, o3 = u.o3, o4 = u.o4, ll = u.ll, f0 = u.f0, f1 = u.f1;
             const bool first = pxx < 0.0f;
             float r0 = first ? f0 : o0, r1 = first ? f1 : o1, r2 = first ? q : o2, r3 = first ? 0.0f : o3, r4 = first ? q : o4;
             const float term = first ? 0.0f : ll;
@@ -299,6 +300,129 @@ __global__ __launch_bounds__(kWaves * 64) void ekf_paged_kernel(PagedEkfArgs a)
     }
 }
 
+// ---- the list form of the paged update, touched pages staged in LDS (same bits): (a) the table row; then, PG touched pages
+// at a time:
+// (b) the pages are loaded — every load of the chunk in flight together — into an LDS image, (c) the observations of these
+// pages (entries tbase[c0] .. tbase[c0 + PG] of the sorted list) are updated IN the image, one lane each: five ds reads,
+// the arithmetic, five ds writes, and (d) the image is stored to the fresh pages — whole 128-byte lines, every landmark
+// written once.  Against the page-wide form: the arithmetic runs once per observation instead of once per lane of every
+// touched page, a particle's pages are not fetched one dependent round trip after the other, and nothing is gathered from or
+// scattered to global memory.
+template <int PG>
+__global__ __launch_bounds__(kWaves * 64) void ekf_paged_lds_kernel(PagedEkfArgs a)
+{
+    constexpr int kGroups = 64 / kPage;
+    __shared__ float s_img[kWaves][PG][5][64];       // [page of the chunk][plane][lane]: lane = particle of the wavefront x slot
+    __shared__ float s_acc[kWaves][kGroups][128];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int half = lane / kPage, slot = lane % kPage;
+    const int first_of_wave = ((int)blockIdx.x * kWaves + wave) * kGroups;
+    const int i_raw = first_of_wave + half;
+    if (first_of_wave >= a.n) return;
+    const bool alive = i_raw < a.n;
+    const int i = alive ? i_raw : a.n - 1;
+    const int src = a.anc ? a.anc[i] : i;
+    const int T = __builtin_amdgcn_readfirstlane(a.count[0]);
+    const int max_round = __builtin_amdgcn_readfirstlane(a.ol.count[1]);
+    const int32_t* __restrict__ row_in = a.pt_in + (int64_t)src * a.nb;
+    int32_t* __restrict__ row_out = a.pt_out + (int64_t)i * a.nb;
+    const int fbase = __builtin_amdgcn_readfirstlane(a.pool_state[kPoolBase]);
+    const int32_t* __restrict__ fresh = a.freelist + fbase + (int64_t)i * T;
+    const float* __restrict__ pool_in = a.pool;   // pages named by the ancestors' tables: read only
+    float* __restrict__ pool_out = a.pool;        // fresh pages: written only (never one of the above)
+    float(*img)[5][64] = s_img[wave];
+
+    if (alive)
+        for (int b = slot; b < a.nb; b += kPage) {
+            const int t = a.tindex[b];
+            const int32_t page = t < 0 ? row_in[b] : fresh[t];
+            row_out[b] = page;
+            a.stamp[page] = a.stamp_now;
+        }
+    float st, ct;
+    det_sincosf(a.th[i], st, ct);
+    const float s = st, c = ct, px = a.x[i], py = a.y[i], q = a.meas_var;
+    float* acc = s_acc[wave][half];
+#pragma unroll
+    for (int k = 0; k < 128 / kPage; ++k) acc[slot + kPage * k] = 0.0f;
+
+    for (int c0 = 0; c0 < T; c0 += PG) {
+        const int tc = T - c0 < PG ? T - c0 : PG;   // wave-uniform
+        // what the pages of this chunk need, looked up by the lanes side by side (lane j of a particle: page c0 + j), then every
+        // load of the chunk goes out back to back: nothing here waits for one page before it asks for the next
+        const int tl = c0 + slot < T ? c0 + slot : T - 1;
+        const int my_old = row_in[a.tpage[tl]], my_new = fresh[tl];
+        // (b) pages c0 .. c0 + tc - 1 of the ancestor -> image (chunk slots beyond tc re-read the last page: harmless)
+        float v[PG][5];
+        int64_t oout[PG];
+#pragma unroll
+        for (int j = 0; j < PG; ++j) {
+            const int from = half * kPage + (j < kPage ? j : kPage - 1);
+            const int64_t oin = (int64_t)__shfl(my_old, from, 64) * kPageFloats + slot;
+            oout[j] = (int64_t)__shfl(my_new, from, 64) * kPageFloats + slot;
+#pragma unroll
+            for (int p = 0; p < 5; ++p) v[j][p] = pool_in[oin + p * kPage];
+        }
+#pragma unroll
+        for (int j = 0; j < PG; ++j)
+#pragma unroll
+            for (int p = 0; p < 5; ++p) img[j][p][lane] = v[j][p];
+        __builtin_amdgcn_wave_barrier();
+        // (c) the observations that fall into these pages, one lane each
+        const int k_lo = __builtin_amdgcn_readfirstlane(a.tbase[c0]), k_hi = __builtin_amdgcn_readfirstlane(a.tbase[c0 + tc]);
+        for (int k0 = k_lo; k0 < k_hi; k0 += kPage) {
+            const int k = k0 + slot;
+            const bool on = k < k_hi;
+            const int kk = on ? k : k_lo;
+            const int l = a.ol.id[kk], rnd = a.ol.round[kk];
+            const float zx = a.ol.zx[kk], zy = a.ol.zy[kk];
+            const int j = a.tindex[l / kPage] - c0, at = half * kPage + l % kPage;
+            const float mx = img[j][0][at], my = img[j][1][at], pxx = img[j][2][at], pxy = img[j][3][at], pyy = img[j][4][at];
+            const EkfResult<float> u = ekf_update_one<float>(mx, my, pxx, pxy, pyy, zx, zy, s, c, px, py, q);
+            const bool first = pxx < 0.0f;
+            const float term = first ? 0.0f : u.ll;
+            if (on) {
+                img[j][0][at] = first ? u.f0 : u.o0;
+                img[j][1][at] = first ? u.f1 : u.o1;
+                img[j][2][at] = first ? q : u.o2;
+                img[j][3][at] = first ? 0.0f : u.o3;
+                img[j][4][at] = first ? q : u.o4;
+            }
+            // accumulator = landmark mod 128, in order of the landmark: round by round (the observations of one accumulator have
+            // distinct rounds; the LDS operations of a wavefront execute in order)
+            const int ka = l & 127;
+            for (int r = 0; r <= max_round; ++r)
+                if (on && rnd == r) acc[ka] = acc[ka] + term;
+        }
+        __builtin_amdgcn_wave_barrier();
+        // (d) image -> fresh pages, whole lines
+#pragma unroll
+        for (int j = 0; j < PG; ++j)
+            if (j < tc && alive) {
+#pragma unroll
+                for (int p = 0; p < 5; ++p) pool_out[oout[j] + p * kPage] = img[j][p][lane];
+            }
+        __builtin_amdgcn_wave_barrier();
+    }
+    float u2[64 / kPage];
+#pragma unroll
+    for (int m = 0; m < 64 / kPage; ++m) u2[m] = acc[slot + kPage * m] + acc[slot + kPage * m + 64];
+#pragma unroll
+    for (int sft = 1; sft < kPage; sft <<= 1)
+#pragma unroll
+        for (int m = 0; m < 64 / kPage; ++m) u2[m] = u2[m] + __shfl_xor(u2[m], sft, 64);
+#pragma unroll
+    for (int w = 1; w < 64 / kPage; w <<= 1)
+#pragma unroll
+        for (int m = 0; m < 64 / kPage; m += 2 * w) u2[m] = u2[m] + u2[m + w];
+    const float total = u2[0];
+    if (slot == 0 && alive) {
+        a.loglik[i] = total;
+        if (a.loglik_user) a.loglik_user[i] = total;
+    }
+}
+
 // A frame without observations: the tables follow their particles, nothing else moves.  Every page the new tables name
 // gets the new stamp, like in an update: "in use" always means "named by the latest generation of tables".
 __global__ __launch_bounds__(256) void page_table_gather_kernel(const int32_t* __restrict__ pt_in, int32_t* __restrict__ pt_out,
@@ -325,6 +449,8 @@ constexpr int kFreeTile = 8192;
 // pool, so a new list always holds what a frame takes — if that invariant were ever broken the update would hand out pages
 // that are still in use, so the shortfall is reported (pool_state[kPoolShort] and, when given, a word in mapped host memory
 // that slam_pf_step turns into SLAM_ERR_CAPACITY) instead of passing silently.
+// A wavefront reads 64 consecutive stamps per step (one coalesced 256-byte access; one thread walking 32 consecutive stamps
+// took 0.6 ms for a 20-million-page pool) and a ballot gives the free ones in order.
 __global__ __launch_bounds__(256) void free_list_kernel(const uint32_t* __restrict__ stamp, int npages, uint32_t live,
                                                         int32_t* __restrict__ freelist, int32_t* __restrict__ pool_state,
                                                         int32_t* __restrict__ h_short)
@@ -332,26 +458,19 @@ __global__ __launch_bounds__(256) void free_list_kernel(const uint32_t* __restri
     __shared__ int s_w[4];
     __shared__ int s_base;
     if (pool_state[kPoolRenew] == 0) return;
-    const int base = blockIdx.x * kFreeTile;
+    constexpr int kSteps = kFreeTile / 256;   // 64-page steps per wavefront
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    constexpr int kPer = kFreeTile / 256;   // consecutive pages per thread (strided, coalesced reads measured slower: 25 vs 20 us)
-    const int p0 = base + (int)threadIdx.x * kPer;
-    uint32_t freebits = 0;
+    const int w0 = blockIdx.x * kFreeTile + wave * (kFreeTile / 4);   // this wavefront's pages: w0 .. w0 + 2047
+    unsigned long long mask[kSteps];
     int c = 0;
 #pragma unroll
-    for (int k = 0; k < kPer; ++k) {
-        const int p = p0 + k;
-        const bool fr = p < npages && stamp[p] != live;
-        freebits |= fr ? 1u << k : 0u;
-        c += fr ? 1 : 0;
+    for (int k = 0; k < kSteps; ++k) {
+        const int p = w0 + 64 * k + lane;
+        const bool fr = p < npages && stamp[p < npages ? p : npages - 1] != live;
+        mask[k] = __ballot(fr);
+        c += __popcll(mask[k]);   // wave-uniform
     }
-    int incl = c;   // inclusive scan of the counts over the wavefront, then over the four wavefronts
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int v = __shfl_up(incl, o, 64);
-        if (lane >= o) incl += v;
-    }
-    if (lane == 63) s_w[wave] = incl;
+    if (lane == 0) s_w[wave] = c;
     __syncthreads();
     int woff = 0, tot = 0;
     for (int w = 0; w < 4; ++w) {
@@ -360,10 +479,13 @@ __global__ __launch_bounds__(256) void free_list_kernel(const uint32_t* __restri
     }
     if (threadIdx.x == 0) s_base = tot ? atomicAdd(&pool_state[kPoolFree], tot) : 0;
     __syncthreads();
-    int out = s_base + woff + incl - c;
+    int out = s_base + woff;
 #pragma unroll
-    for (int k = 0; k < kPer; ++k)
-        if (freebits >> k & 1u) freelist[out++] = p0 + k;
+    for (int k = 0; k < kSteps; ++k) {
+        const unsigned long long m = mask[k];
+        if (m >> lane & 1ull) freelist[out + __popcll(m & ((1ull << lane) - 1ull))] = w0 + 64 * k + lane;
+        out += __popcll(m);
+    }
     if (threadIdx.x == 0) {
         __threadfence();
         if (atomicAdd(&pool_state[kPoolTicket], 1) == (int)gridDim.x - 1) {   // every workgroup's share is in
@@ -467,9 +589,11 @@ inline int blocks256(int64_t n) { return (int)((n + 255) / 256); }
 }  // namespace
 
 hipError_t launch_page_list(hipStream_t stream, const float* zx, const float* zy, int L, int nb, int32_t* tpage, int32_t* tindex,
-                            int32_t* count, int n, int32_t* pool_state, int32_t* h_obs, uint32_t seq, int32_t* votes)
+                            int32_t* tmask, int32_t* tbase, int32_t* count, int n, int32_t* pool_state, int32_t* h_obs, uint32_t seq,
+                            int32_t* votes, int32_t* h_touched)
 {
-    page_list_kernel<<<1, 1024, 0, stream>>>(zx, zy, L, nb, tpage, tindex, count, n, pool_state, votes ? h_obs : nullptr, seq, votes);
+    page_list_kernel<<<1, 1024, 0, stream>>>(zx, zy, L, nb, tpage, tindex, tmask, tbase, count, n, pool_state,
+                                             votes ? h_obs : nullptr, seq, votes, h_touched);
     return hipGetLastError();
 }
 
@@ -479,12 +603,24 @@ hipError_t launch_obs_count(hipStream_t stream, const float* zx, const float* zy
     return hipGetLastError();
 }
 
-hipError_t launch_ekf_paged(hipStream_t stream, const PagedEkfArgs& a, const EventPair* ev)
+hipError_t launch_ekf_paged(hipStream_t stream, const PagedEkfArgs& a, const EventPair* ev, int form, int touched_hint)
 {
     if (a.n <= 0) return hipSuccess;
     if (ev) (void)hipEventRecord(ev->start, stream);
     constexpr int per_block = kWaves * (64 / kPage);
-    ekf_paged_kernel<<<(a.n + per_block - 1) / per_block, kWaves * 64, 0, stream>>>(a);
+    const int grid = (a.n + per_block - 1) / per_block;
+    static const int pg_env = getenv("SLAM_PAGED_PG") ? atoi(getenv("SLAM_PAGED_PG")) : 0;
+    // pages staged per pass: what the last frame touched (a frame's touched pages then go through in one pass without idle
+    // slots); any value gives the same results
+    const int pg = pg_env > 0 ? pg_env : (touched_hint > 0 ? touched_hint : 6);
+    if (form == 0 || !a.ol.id) ekf_paged_kernel<<<grid, kWaves * 64, 0, stream>>>(a);
+    else if (pg <= 1) ekf_paged_lds_kernel<1><<<grid, kWaves * 64, 0, stream>>>(a);
+    else if (pg == 2) ekf_paged_lds_kernel<2><<<grid, kWaves * 64, 0, stream>>>(a);
+    else if (pg == 3) ekf_paged_lds_kernel<3><<<grid, kWaves * 64, 0, stream>>>(a);
+    else if (pg == 4) ekf_paged_lds_kernel<4><<<grid, kWaves * 64, 0, stream>>>(a);
+    else if (pg == 5) ekf_paged_lds_kernel<5><<<grid, kWaves * 64, 0, stream>>>(a);
+    else if (pg == 6) ekf_paged_lds_kernel<6><<<grid, kWaves * 64, 0, stream>>>(a);
+    else ekf_paged_lds_kernel<8><<<grid, kWaves * 64, 0, stream>>>(a);
     if (ev) (void)hipEventRecord(ev->stop, stream);
     return hipGetLastError();
 }

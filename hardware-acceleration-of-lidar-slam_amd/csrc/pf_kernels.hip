@@ -15,6 +15,7 @@
 #include <stdlib.h>
 
 #include "det_math.h"
+#include "ekf_math.h"
 #include "kernels.h"
 
 namespace slam {
@@ -51,44 +52,6 @@ __global__ __launch_bounds__(kBlock) void motion_sample_kernel(const float* __re
 // are neighbouring particles, so the 10 KB source row is fetched from HBM once and re-read from L2 by the other
 // offspring — the sweep's HBM traffic is the 20 B/(particle, landmark) it writes plus the distinct rows it reads,
 // not 40 B.  Row base addresses are wave-uniform (SGPR).
-typedef float v2f __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ v2f bc2(float a) { return (v2f){a, a}; }
-
-// det_logf on two values: the integer steps per component, the polynomial packed (same operation order)
-__device__ __forceinline__ v2f det_logf2(v2f x)
-{
-    float m_[2], ef_[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        float xv = x[t];
-        if (!(xv >= 1.17549435e-38f)) xv = 1.17549435e-38f;
-        const uint32_t u = __float_as_uint(xv);
-        int e = (int)(u >> 23) - 126;
-        const float m = __uint_as_float((u & 0x007fffffu) | 0x3f000000u);
-        const bool lo = m < 0.70710678f;
-        e = lo ? e - 1 : e;
-        m_[t] = lo ? m + m : m;
-        ef_[t] = (float)e;
-    }
-    const v2f f = (v2f){m_[0], m_[1]} - bc2(1.0f), ef = (v2f){ef_[0], ef_[1]};
-    const v2f z = f * f;
-    v2f y = bc2(7.0376836292e-2f) * f;
-    y = y + bc2(-1.1514610310e-1f); y = y * f;
-    y = y + bc2(1.1676998740e-1f);  y = y * f;
-    y = y + bc2(-1.2420140846e-1f); y = y * f;
-    y = y + bc2(1.4249322787e-1f);  y = y * f;
-    y = y + bc2(-1.6668057665e-1f); y = y * f;
-    y = y + bc2(2.0000714765e-1f);  y = y * f;
-    y = y + bc2(-2.4999993993e-1f); y = y * f;
-    y = y + bc2(3.3333331174e-1f);  y = y * f;
-    y = y * z;
-    y = y + ef * bc2(-2.12194440e-4f);
-    y = y - bc2(0.5f) * z;
-    v2f r = f + y;
-    r = r + ef * bc2(0.693359375f);
-    return r;
-}
-
 __device__ __forceinline__ float wave_xor_tree_sum(float v)   // t[j] = t[j] + t[j ^ s], s = 1 .. 32: all lanes equal
 {
 #pragma unroll
@@ -182,29 +145,10 @@ __device__ __forceinline__ void ekf_batches(const EkfLane& w, unsigned lb, unsig
                 }
             continue;
         }
-        const v2f s = w.s, c = w.c, px = w.px, py = w.py, q = w.q;
-        const v2f dx = mx - px, dy = my - py;
-        const v2f vx = zx[g] - (c * dx - s * dy);
-        const v2f vy = zy[g] - (s * dx + c * dy);
-        const v2f a00 = c * pxx - s * pxy, a01 = c * pxy - s * pyy;
-        const v2f a10 = s * pxx + c * pxy, a11 = s * pxy + c * pyy;
-        const v2f s00 = (a00 * c - a01 * s) + q;
-        const v2f s01 = a00 * s + a01 * c;
-        const v2f s11 = (a10 * s + a11 * c) + q;
-        const v2f det = s00 * s11 - s01 * s01;
-        const v2f idet = (v2f){1.0f / det[0], 1.0f / det[1]};
-        const v2f i00 = s11 * idet, i01 = -s01 * idet, i11 = s00 * idet;
-        const v2f k00 = a00 * i00 + a10 * i01, k01 = a00 * i01 + a10 * i11;
-        const v2f k10 = a01 * i00 + a11 * i01, k11 = a01 * i01 + a11 * i11;
-        v2f o0 = mx + (k00 * vx + k01 * vy);
-        v2f o1 = my + (k10 * vx + k11 * vy);
-        v2f o2 = pxx - (k00 * a00 + k01 * a10);
-        v2f o3 = pxy - (k00 * a01 + k01 * a11);
-        v2f o4 = pyy - (k10 * a01 + k11 * a11);
-        const v2f maha = vx * (i00 * vx + i01 * vy) + vy * (i01 * vx + i11 * vy);
-        v2f ll = ((bc2(0.0f) - bc2(0.5f) * maha) - bc2(0.5f) * det_logf2(det)) - bc2(1.8378770664f);
-        const v2f f0 = px + (c * zx[g] + s * zy[g]);   // first sighting: the observed point, P = R, no likelihood
-        const v2f f1 = py + (c * zy[g] - s * zx[g]);
+        const v2f q = w.q;
+        const EkfResult<v2f> u = ekf_update_one<v2f>(mx, my, pxx, pxy, pyy, zx[g], zy[g], w.s, w.c, w.px, w.py, q);
+        const v2f o0 = u.o0, o1 = u.o1, o2 = u.o2, o3 = u.o3, o4 = u.o4, f0 = u.f0, f1 = u.f1;
+        v2f ll = u.ll;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const bool ob = obs[g][t];
@@ -314,29 +258,10 @@ __device__ __forceinline__ void ekf_apply(const EkfBatch<NB>& b, const EkfPose& 
                 for (int p = 0; p < 5; ++p) row_store(w.rout, b.off[g][t], p * pl, b.m[g][p][t]);
             continue;
         }
-        const v2f s = w.s, c = w.c, px = w.px, py = w.py, q = q2;
-        const v2f dx = mx - px, dy = my - py;
-        const v2f vx = b.zx[g] - (c * dx - s * dy);
-        const v2f vy = b.zy[g] - (s * dx + c * dy);
-        const v2f a00 = c * pxx - s * pxy, a01 = c * pxy - s * pyy;
-        const v2f a10 = s * pxx + c * pxy, a11 = s * pxy + c * pyy;
-        const v2f s00 = (a00 * c - a01 * s) + q;
-        const v2f s01 = a00 * s + a01 * c;
-        const v2f s11 = (a10 * s + a11 * c) + q;
-        const v2f det = s00 * s11 - s01 * s01;
-        const v2f idet = (v2f){1.0f / det[0], 1.0f / det[1]};
-        const v2f i00 = s11 * idet, i01 = -s01 * idet, i11 = s00 * idet;
-        const v2f k00 = a00 * i00 + a10 * i01, k01 = a00 * i01 + a10 * i11;
-        const v2f k10 = a01 * i00 + a11 * i01, k11 = a01 * i01 + a11 * i11;
-        v2f o0 = mx + (k00 * vx + k01 * vy);
-        v2f o1 = my + (k10 * vx + k11 * vy);
-        v2f o2 = pxx - (k00 * a00 + k01 * a10);
-        v2f o3 = pxy - (k00 * a01 + k01 * a11);
-        v2f o4 = pyy - (k10 * a01 + k11 * a11);
-        const v2f maha = vx * (i00 * vx + i01 * vy) + vy * (i01 * vx + i11 * vy);
-        v2f ll = ((bc2(0.0f) - bc2(0.5f) * maha) - bc2(0.5f) * det_logf2(det)) - bc2(1.8378770664f);
-        const v2f f0 = px + (c * b.zx[g] + s * b.zy[g]);   // first sighting: the observed point, P = R, no likelihood
-        const v2f f1 = py + (c * b.zy[g] - s * b.zx[g]);
+        const v2f q = q2;
+        const EkfResult<v2f> u = ekf_update_one<v2f>(mx, my, pxx, pxy, pyy, b.zx[g], b.zy[g], w.s, w.c, w.px, w.py, q);
+        const v2f o0 = u.o0, o1 = u.o1, o2 = u.o2, o3 = u.o3, o4 = u.o4, f0 = u.f0, f1 = u.f1;
+        v2f ll = u.ll;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const bool ob = b.obs[g][t];
@@ -583,28 +508,8 @@ __global__ __launch_bounds__(kEkfWaves * 64) void ekf_sparse_kernel(EkfArgs a, O
 #pragma unroll
             for (int p = 0; p < 5; ++p) m[p][t] = ob[t] ? row_load(row, off[t], p * pl) : 1.0f;   // 1: harmless operands for idle lanes
         const v2f mx = m[0], my = m[1], pxx = m[2], pxy = m[3], pyy = m[4];
-        const v2f dx = mx - px, dy = my - py;
-        const v2f vx = zx - (c * dx - s * dy);
-        const v2f vy = zy - (s * dx + c * dy);
-        const v2f a00 = c * pxx - s * pxy, a01 = c * pxy - s * pyy;
-        const v2f a10 = s * pxx + c * pxy, a11 = s * pxy + c * pyy;
-        const v2f s00 = (a00 * c - a01 * s) + q;
-        const v2f s01 = a00 * s + a01 * c;
-        const v2f s11 = (a10 * s + a11 * c) + q;
-        const v2f det = s00 * s11 - s01 * s01;
-        const v2f idet = (v2f){1.0f / det[0], 1.0f / det[1]};
-        const v2f i00 = s11 * idet, i01 = -s01 * idet, i11 = s00 * idet;
-        const v2f k00 = a00 * i00 + a10 * i01, k01 = a00 * i01 + a10 * i11;
-        const v2f k10 = a01 * i00 + a11 * i01, k11 = a01 * i01 + a11 * i11;
-        const v2f o0 = mx + (k00 * vx + k01 * vy);
-        const v2f o1 = my + (k10 * vx + k11 * vy);
-        const v2f o2 = pxx - (k00 * a00 + k01 * a10);
-        const v2f o3 = pxy - (k00 * a01 + k01 * a11);
-        const v2f o4 = pyy - (k10 * a01 + k11 * a11);
-        const v2f maha = vx * (i00 * vx + i01 * vy) + vy * (i01 * vx + i11 * vy);
-        const v2f ll = ((bc2(0.0f) - bc2(0.5f) * maha) - bc2(0.5f) * det_logf2(det)) - bc2(1.8378770664f);
-        const v2f f0 = px + (c * zx + s * zy);   // first sighting: the observed point, P = R, no likelihood
-        const v2f f1 = py + (c * zy - s * zx);
+        const EkfResult<v2f> u = ekf_update_one<v2f>(mx, my, pxx, pxy, pyy, zx, zy, s, c, px, py, q);
+        const v2f o0 = u.o0, o1 = u.o1, o2 = u.o2, o3 = u.o3, o4 = u.o4, f0 = u.f0, f1 = u.f1, ll = u.ll;
         float term[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {

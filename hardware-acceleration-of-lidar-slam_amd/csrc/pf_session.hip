@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <new>
@@ -71,7 +72,7 @@ struct slam_pf {
     int32_t* freelist = nullptr;    // [npages] ascending free pages as of the last update
     uint32_t* stamp = nullptr;      // [npages] frame stamp of the last table that named the page
     uint32_t stamp_now = 0;
-    int32_t* page_scratch = nullptr;   // tpage[nb] | tindex[nb] | count | the free list's bookkeeping (pool_state_words())
+    int32_t* page_scratch = nullptr;   // the free list's bookkeeping (pool_state_words()) | count | tpage[nb] | tindex[nb] | tmask[nb] | tbase[nb + 1]
     bool gated = false;             // cfg.resample_ess_frac in (0, 1): a frame resamples only when its ESS is low
     int64_t frames_resampled = 0;   // (as far as the host has looked: one frame behind)
     // SLAM_MAP_AUTO: the session watches how many landmarks the frames observe ({observed, L, seq} in words 24..26 of h_res,
@@ -146,7 +147,7 @@ int migrate(slam_pf* pf)
     if (int rc = comm_all_to_all_f32(pf->comm, pf->sbuf, sfl, pf->rbuf, rfl)) return rc;
     if (rtot && pf->paged) {
         // fresh pages for the received rows (a new free list first if the old one runs short), table rows n .. n + rtot - 1
-        int32_t* pstate = pf->page_scratch + 2 * pf->nb + 1;
+        int32_t* pstate = pf->page_scratch;
         const ProfScope prof(e, SLAM_PROF_UNPACK);
         SLAM_HIP_TRY(e, launch_pool_reserve(e->stream, pstate, rtot * pf->nb));
         SLAM_HIP_TRY(e, launch_free_list(e->stream, pf->stamp, pf->npages, pf->stamp_now, pf->freelist, pstate,
@@ -235,7 +236,7 @@ void free_page_tables(slam_pf* pf)
 
 bool alloc_page_tables(slam_pf* pf)
 {
-    const size_t P = (size_t)pf->npages, words = 2 * (size_t)pf->nb + 1 + (size_t)pool_state_words();
+    const size_t P = (size_t)pf->npages, words = 4 * (size_t)pf->nb + 2 + (size_t)pool_state_words();
     const bool ok = dev_alloc((void**)&pf->freelist, P * 4) == hipSuccess && dev_alloc((void**)&pf->stamp, P * 4) == hipSuccess &&
                     hipMemset(pf->stamp, 0, P * 4) == hipSuccess && dev_alloc((void**)&pf->page_scratch, words * 4) == hipSuccess &&
                     hipMemset(pf->page_scratch, 0, words * 4) == hipSuccess &&
@@ -260,7 +261,7 @@ int convert_to_pages(slam_pf* pf)
     const int page_base = (1 - mc) * pf->cap * pf->nb;
     pf->pt_cur = 0;
     SLAM_HIP_TRY(e, launch_pages_from_rows(e->stream, pf->map[mc], 5 * (int64_t)pf->Lp, pf->Lp, pf->L, pf->nb, pf->n, pf->pool,
-                                           pf->pt[0], pf->freelist, pf->npages, pf->page_scratch + 2 * pf->nb + 1, page_base));
+                                           pf->pt[0], pf->freelist, pf->npages, pf->page_scratch, page_base));
     pf->paged = true;
     pf->conversions++;
     return SLAM_OK;
@@ -485,7 +486,7 @@ int slam_pf_reset(slam_pf* pf, const float pose[3])
     if (hipMemcpy(pf->pose[pf->cur], h.data(), 3 * n * 4, hipMemcpyHostToDevice) != hipSuccess) return SLAM_ERR_HIP;
     if (pf->paged) {   // every particle names ONE shared page of landmarks not seen yet
         SLAM_HIP_TRY(pf->e, launch_pages_reset(pf->e->stream, pf->pool, pf->pt[pf->pt_cur], (int64_t)pf->n * pf->nb, pf->freelist,
-                                               pf->npages, pf->page_scratch + 2 * pf->nb + 1));
+                                               pf->npages, pf->page_scratch));
         if (int rc = slam_engine_sync(pf->e)) return rc;
     } else if (pf->L) {   // P_xx = -1: "not seen yet"
         const size_t Lp = (size_t)pf->Lp;
@@ -547,7 +548,7 @@ int slam_pf_set_map_dev(slam_pf* pf, const float* d_rows, int64_t row_stride, in
     SLAM_HIP_TRY(e, hipSetDevice(e->device));
     if (pf->paged) {
         SLAM_HIP_TRY(e, launch_pages_from_rows(e->stream, d_rows, row_stride, plane_stride, pf->L, pf->nb, pf->n, pf->pool,
-                                               pf->pt[pf->pt_cur], pf->freelist, pf->npages, pf->page_scratch + 2 * pf->nb + 1));
+                                               pf->pt[pf->pt_cur], pf->freelist, pf->npages, pf->page_scratch));
         return SLAM_OK;
     }
     for (int pl = 0; pl < 5; ++pl)   // plane by plane: one 2-D copy each whatever the caller's row stride is
@@ -635,17 +636,27 @@ static int pf_step_impl(slam_pf* pf, int slot, const float dp[3], int use_observ
             // touched pages of this frame's observation table, the update into fresh pages, the next frame's free list
             if (e->obs_nlandmarks != L) return SLAM_ERR_NOT_READY;
             SLAM_HIP_TRY(e, e->ll_buf.ensure(sizeof(float) * sn));
-            int32_t *tpage = pf->page_scratch, *tindex = tpage + pf->nb, *count = tindex + pf->nb, *pstate = count + 1;
+            int32_t *pstate = pf->page_scratch, *count = pstate + pool_state_words(), *tpage = count + 1, *tindex = tpage + pf->nb,
+                    *tmask = tindex + pf->nb, *tbase = tmask + pf->nb;
             {
                 const ProfScope prof(e, SLAM_PROF_PAGES);
-                SLAM_HIP_TRY(e, launch_page_list(e->stream, e->d_obs_zx, e->d_obs_zy, L, pf->nb, tpage, tindex, count, n, pstate,
+                SLAM_HIP_TRY(e, launch_page_list(e->stream, e->d_obs_zx, e->d_obs_zy, L, pf->nb, tpage, tindex, tmask, tbase, count, n, pstate,
                                                  sample_obs ? d_hobs : nullptr, sample_obs ? ++pf->obs_seq_issued : 0,
-                                                 sample_obs ? pf->votes : nullptr));
+                                                 sample_obs ? pf->votes : nullptr, reinterpret_cast<int32_t*>(pf->d_hres) + 30));
                 // a new free list when the old one runs short (decided on the device; the pages in use carry the last stamp)
                 SLAM_HIP_TRY(e, launch_free_list(e->stream, pf->stamp, pf->npages, pf->stamp_now, pf->freelist, pstate,
                                                  reinterpret_cast<int32_t*>(pf->d_hres) + 20));
             }
             PagedEkfArgs a;
+            // the list form (one lane per observation) whenever a list can be made; SLAM_PAGED_FORM=0 keeps the page-wide form
+            static const int env_form = getenv("SLAM_PAGED_FORM") ? atoi(getenv("SLAM_PAGED_FORM")) : 1;
+            const int form = env_form != 0 && L <= kObsListMaxLandmarks ? 1 : 0;
+            if (form != 0) {
+                const ProfScope prof(e, SLAM_PROF_PAGES);
+                if (int rl = slam_engine_obs_list(e, L, &a.ol)) return rl;
+            }
+            a.tmask = tmask;
+            a.tbase = tbase;
             a.pool = pf->pool;
             a.pt_in = pf->pt[pc];
             a.pt_out = pf->pt[1 - pc];
@@ -668,7 +679,9 @@ static int pf_step_impl(slam_pf* pf, int slot, const float dp[3], int use_observ
             a.pool_state = pstate;
             a.stamp = pf->stamp;
             a.stamp_now = ++pf->stamp_now;
-            SLAM_HIP_TRY(e, launch_ekf_paged(e->stream, a, e->prof_next(SLAM_PROF_EKF)));
+            // pages staged per pass = what the last frames touched (a hint in mapped memory, read without waiting)
+            SLAM_HIP_TRY(e, launch_ekf_paged(e->stream, a, e->prof_next(SLAM_PROF_EKF), form,
+                                             __atomic_load_n(reinterpret_cast<int32_t*>(pf->h_res) + 30, __ATOMIC_RELAXED)));
             e->ll_n = n;
             pf->pt_cur = 1 - pc;
             rc = slam_logweight_ekf_dev(e, pf->score, pf->cfg.score_gain, n, pf->logw, d_max);
@@ -764,7 +777,7 @@ int slam_pf_paged_device_view(slam_pf* pf, slam_pf_paged_view* out)
     out->pool = pf->pool;
     out->table = pf->pt[pf->pt_cur];
     out->freelist = pf->freelist;
-    out->state = pf->page_scratch + 2 * pf->nb + 1;
+    out->state = pf->page_scratch;
     out->stamp = pf->stamp;
     out->stamp_now = pf->stamp_now;
     out->page_landmarks = kPageLandmarks;

@@ -67,7 +67,7 @@ int fe_bin_write_frame(FILE *f, const fe_scan *s)
     return fwrite(s->range, sizeof(float), (size_t)s->nbeams, f) == (size_t)s->nbeams ? 0 : -1;
 }
 
-void fe_clean(fe_scan *s, float range_min, int usable_range)
+void fe_clean(fe_scan *s, float range_min, float usable_range)
 {
     /* main.c:77-94: both comparisons false keeps the beam (so NaN survives) */
     const float hi = (float)usable_range;

@@ -61,7 +61,7 @@ int fe_bin_open(FILE *f, int *nbeams);                 /* 0 if `f` starts with a
 int fe_read_frame_bin(FILE *f, fe_scan *s);            /* values read (nbeams on a complete frame) */
 int fe_bin_write_header(FILE *f, int nbeams);
 int fe_bin_write_frame(FILE *f, const fe_scan *s);
-void fe_clean(fe_scan *s, float range_min, int usable_range);
+void fe_clean(fe_scan *s, float range_min, float usable_range);
 void fe_to_world(fe_scan *s, const float pose[3]);
 
 int fe_points_init(fe_points *p, int capacity);

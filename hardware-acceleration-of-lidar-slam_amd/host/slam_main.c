@@ -9,7 +9,9 @@
  *     FastMatch / FastMatch2        -> slam_fastmatch_host     (replaces main.c:381-809)
  * The grids and the scan stay resident on the GPU between the calls of one frame.
  *
- * usage: slam_main [--mapper] dataset frames beams map_out.csv [angle_min angle_inc]
+ * usage: slam_main [--mapper] dataset frames beams map_out.csv [angle_min angle_inc] [--params P x 15]
+ *        --params: the 15 floats of slam_mapper_params in declaration order (fast_res[3] fast_res2[3] border pixel pixel2
+ *        key_dt key_dr range_min usable_range edt_cap new_point_threshold); default: the reference's (main.c:832-839 ...)
  *        slam_main --to-binary dataset.csv frames beams dataset.bin      (no GPU needed)
  * --mapper runs the whole per-frame pipeline through slam_mapper_* (scan clean-up, local map, rasters and map
  * update on the device too) instead of the host front end below; same results.
@@ -62,8 +64,18 @@ int main(int argc, char **argv)
         --argc;
         ++argv;
     }
+    slam_mapper_params par;
+    slam_mapper_params_default(&par);
+    for (int a = 1; a < argc; ++a)
+        if (strcmp(argv[a], "--params") == 0) {
+            if (argc - a - 1 < 15) { fprintf(stderr, "--params needs 15 values\n"); return 2; }
+            float *f = (float *)&par;   /* 15 floats in declaration order */
+            for (int k = 0; k < 15; ++k) f[k] = (float)atof(argv[a + 1 + k]);
+            argc = a;
+            break;
+        }
     if (argc < 5) {
-        fprintf(stderr, "usage: %s [--mapper] dataset frames beams map_out.csv [angle_min angle_inc]\n", argv[0]);
+        fprintf(stderr, "usage: %s [--mapper] dataset frames beams map_out.csv [angle_min angle_inc] [--params P x 15]\n", argv[0]);
         return 2;
     }
     FILE *in = fopen(argv[1], "rb");
@@ -79,12 +91,11 @@ int main(int argc, char **argv)
     const float angle_min = argc > 6 ? (float)atof(argv[5]) : -2.351831f;   /* main.c:47 */
     const float angle_inc = argc > 6 ? (float)atof(argv[6]) : 0.004363f;    /* main.c:49 */
 
-    /* constants of main.c:830-839 */
-    const float coarse_step[3] = { 0.05f, 0.05f, 0.008727f };
-    const float fine_step[3] = { 0.025f, 0.025f, 0.004363f };
-    const float border = 1, pixel_coarse = 0.2f, pixel_fine = 0.1f;
-    const float key_dt = 0.3f, key_dr = 0.0872665f;
-    const float edt_cap = 10;   /* main.c:224 */
+    /* the reference's run-time parameters (main.c:830-839, :224, :943): slam_mapper_params, defaults = the reference's */
+    const float *coarse_step = par.fast_res, *fine_step = par.fast_res2;
+    const float border = par.border, pixel_coarse = par.pixel, pixel_fine = par.pixel2;
+    const float key_dt = par.key_dt, key_dr = par.key_dr;
+    const float edt_cap = par.edt_cap;
 
     slam_engine *eng = NULL;
     {
@@ -98,7 +109,7 @@ int main(int argc, char **argv)
         fe_scan rd;
         slam_mapper *mp = NULL;
         if (fe_scan_init(&rd, beams, angle_min, angle_inc)) return 1;
-        CHECK(slam_mapper_create(eng, beams, angle_min, angle_inc, &mp));
+        CHECK(slam_mapper_create_ex(eng, beams, angle_min, angle_inc, &par, &mp));
         const double t0 = now_s();
         if (binary) fe_read_frame_bin(in, &rd); else fe_read_frame(in, &rd);
         CHECK(slam_mapper_first_frame(mp, rd.range));
@@ -143,7 +154,7 @@ int main(int argc, char **argv)
     /* main.c:844-858: frame 0 at the origin seeds the map */
     float pose[3] = { 0, 0, 0 }, prev[3] = { 0, 0, 0 };
     if (binary) fe_read_frame_bin(in, &scan); else fe_read_frame(in, &scan);
-    fe_clean(&scan, 0.023f, 24);
+    fe_clean(&scan, par.range_min, par.usable_range);
     fe_to_world(&scan, pose);
     memcpy(map.x, scan.wx, sizeof(float) * (size_t)scan.nscan);
     memcpy(map.y, scan.wy, sizeof(float) * (size_t)scan.nscan);
@@ -154,7 +165,7 @@ int main(int argc, char **argv)
     for (int k = 1; k < frames; ++k) {
         printf("scan %d\n", k + 1);
         if (binary) fe_read_frame_bin(in, &scan); else fe_read_frame(in, &scan);
-        fe_clean(&scan, 0.023f, 24);
+        fe_clean(&scan, par.range_min, par.usable_range);
         CHECK(slam_scan_upload_host(eng, scan.bx, scan.by, scan.nscan));
         int in_world = 0;
         if (mini_updated) {   /* main.c:865-872 (world points from the OLD pose) */
@@ -191,7 +202,7 @@ int main(int argc, char **argv)
             if (!in_world) fe_to_world(&scan, pose);
             int added = 0;
             for (int j = 0; j < nhits; ++j)   /* hits of the LAST candidate, count of the BEST (Q2) */
-                if (hits[j] > 1.5 && map.size + added < map.capacity) {
+                if (hits[j] > par.new_point_threshold && map.size + added < map.capacity) {
                     map.x[map.size + added] = scan.wx[j];
                     map.y[map.size + added] = scan.wy[j];
                     ++added;

@@ -544,7 +544,24 @@ int slam_pf_paged_device_view(slam_pf *pf, slam_pf_paged_view *out);
  * pose sequence and the final map are bit-identical to the reference program's.  Uses grid slots 0 and 1 of
  * the engine.  `ranges` = one raw scan frame of `nbeams` floats (what main.c:22-30 parses from the CSV). */
 typedef struct slam_mapper slam_mapper;
+/* The run-time parameters the reference keeps as locals of main() and as literals: one plain struct,
+ * slam_mapper_params_default fills in the reference's values. */
+typedef struct {
+    float fast_res[3];          /* fastResolution  {0.05, 0.05, 0.008727}    main.c:832: lattice step of FastMatch (x = y, theta) */
+    float fast_res2[3];         /* fastResolution2 {0.025, 0.025, 0.004363}  main.c:833: ... of FastMatch2 */
+    float border;               /* borderSize 1          main.c:834: margin of the local-map crop around the scan, metres */
+    float pixel, pixel2;        /* pixelSize 0.2, pixelSize2 0.1   main.c:835-836: coarse / fine grid resolution, metres */
+    float key_dt, key_dr;       /* miniUpdateDT 0.3 m, miniUpdateDR 0.0872665 rad   main.c:838-839: key-frame test, per axis */
+    float range_min;            /* lidar.range_min 0.023 main.c:50 */
+    float usable_range;         /* readAScan(24)         main.c:846, :863 (the reference compares with an int) */
+    float edt_cap;              /* 10 cells              main.c:224 (<= 32) */
+    float new_point_threshold;  /* 1.5 cells             main.c:943: a beam farther than this from the map is a new map point */
+} slam_mapper_params;
+void slam_mapper_params_default(slam_mapper_params *p);
+/* slam_mapper_create = slam_mapper_create_ex with the defaults (params == NULL means the same) */
 int slam_mapper_create(slam_engine *e, int nbeams, float angle_min, float angle_inc, slam_mapper **out);
+int slam_mapper_create_ex(slam_engine *e, int nbeams, float angle_min, float angle_inc, const slam_mapper_params *params,
+                          slam_mapper **out);
 int slam_mapper_destroy(slam_mapper *m);
 int slam_mapper_first_frame(slam_mapper *m, const float *ranges);                    /* main.c:844-858 */
 int slam_mapper_next_frame(slam_mapper *m, const float *ranges, float pose_out[3]);  /* main.c:859-969 */

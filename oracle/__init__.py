@@ -59,7 +59,7 @@ def lib() -> C.CDLL:
     L = C.CDLL(str(so))
     P = C.POINTER
     L.orc_beam_angles.argtypes = [C.c_float, C.c_float, C.c_int, _f32p]
-    L.orc_clean_scan.argtypes = [_f32p, _f32p, C.c_int, C.c_float, C.c_int, _f32p, _f32p]
+    L.orc_clean_scan.argtypes = [_f32p, _f32p, C.c_int, C.c_float, C.c_float, _f32p, _f32p]
     L.orc_clean_scan.restype = C.c_int
     L.orc_transform.argtypes = [_f32p, _f32p, C.c_int, _f32p, _f32p, _f32p]
     L.orc_local_map.argtypes = [_f32p, _f32p, C.c_int, _f32p, _f32p, C.c_int, C.c_float, _f32p, _f32p]

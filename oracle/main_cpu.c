@@ -6,17 +6,29 @@
  * TEST INFRASTRUCTURE: used to pin the oracle against the reference's own stdout/map output
  * byte for byte, and as the `cpu_baseline` of bench.py.  Not part of the product.
  *
- * usage: main_cpu dataset.csv frames beams edt_variant map_out.csv [angle_min angle_inc]
+ * usage: main_cpu dataset.csv frames beams edt_variant map_out.csv [angle_min angle_inc] [--params P x 15]
  *        edt_variant: 0 = gather (main.c), 1 = scatter (main_accelerated.c), 2 = window
+ *        --params: the 15 floats of orc_slam_params in declaration order (default: the reference's, main.c:832-839 ...)
  */
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include <time.h>
 
 #include "slam_oracle.h"
 
 int main(int argc, char **argv)
 {
+    orc_slam_params par;
+    orc_slam_params_default(&par);
+    for (int a = 1; a < argc; ++a)
+        if (strcmp(argv[a], "--params") == 0) {
+            if (argc - a - 1 < 15) { fprintf(stderr, "--params needs 15 values\n"); return 2; }
+            float *f = (float *)&par;
+            for (int k = 0; k < 15; ++k) f[k] = (float)atof(argv[a + 1 + k]);
+            argc = a;
+            break;
+        }
     if (argc < 6) {
         fprintf(stderr, "usage: %s dataset.csv frames beams edt_variant map_out.csv [angle_min angle_inc]\n", argv[0]);
         return 2;
@@ -31,6 +43,7 @@ int main(int argc, char **argv)
     float *ranges = (float *)calloc((size_t)beams, sizeof(float));
     orc_slam *s = orc_slam_create(beams, amin, ainc);
     orc_slam_set_edt_variant(s, atoi(argv[4]));
+    orc_slam_set_params(s, &par);
 
     struct timespec t0, t1;
     clock_gettime(CLOCK_MONOTONIC, &t0);

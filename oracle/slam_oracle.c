@@ -43,14 +43,14 @@ void orc_beam_angles(float angle_min, float angle_inc, int nbeams, float *angles
 }
 
 int orc_clean_scan(const float *ranges, const float *angles, int nbeams, float range_min,
-                   int usable_range, float *x, float *y)
+                   float usable_range, float *x, float *y)
 {
     /* main.c:73-94 — gate is (r < range_min) | (r > (int)usable); NaN passes both tests and
      * is kept (Appendix A.2) */
     int n = 0;
     for (int k = 0; k < nbeams; ++k) {
         const float r = ranges[k];
-        if ((r < range_min) | (r > (float)usable_range)) continue;
+        if ((r < range_min) | (r > usable_range)) continue;   /* the reference's int 24 converts exactly */
         const float a = angles[k];
         x[n] = r * cosf(a);
         y[n] = r * sinf(a);
@@ -318,6 +318,7 @@ struct orc_slam {
     float pose[3], prev[3];
     int mini_updated, frame;   /* frame = the reference's scan_iter */
     int edt_variant;
+    orc_slam_params par;   /* main.c:832-839, :50, :846, :224, :943 */
     double edt_s, match_s;
     long edt_calls, match_calls;
     long partial_frames;   /* frames whose best candidate had beams out of bounds (the Q2 quirk matters there) */
@@ -351,9 +352,23 @@ orc_slam *orc_slam_create(int nbeams, float angle_min, float angle_inc)
     }
     s->hits = (float *)calloc(HITS_CAP > nbeams ? HITS_CAP : nbeams, sizeof(float));
     s->edt_variant = 1;
+    orc_slam_params_default(&s->par);
     orc_beam_angles(angle_min, angle_inc, nbeams, s->angles);   /* main.c:845 */
     return s;
 }
+
+void orc_slam_params_default(orc_slam_params *p)
+{
+    const orc_slam_params d = { { 0.05f, 0.05f, 0.008727f },    /* main.c:832 */
+                                { 0.025f, 0.025f, 0.004363f },  /* main.c:833 */
+                                1.0f, 0.2f, 0.1f,               /* main.c:834-836 */
+                                0.3f, 0.0872665f,               /* main.c:838-839 */
+                                0.023f, 24.0f,                  /* main.c:50, :846 */
+                                10.0f, 1.5f };                  /* main.c:224, :943 */
+    *p = d;
+}
+
+void orc_slam_set_params(orc_slam *s, const orc_slam_params *p) { s->par = *p; }
 
 void orc_slam_destroy(orc_slam *s)
 {
@@ -381,7 +396,7 @@ void orc_slam_first_frame(orc_slam *s, const float *ranges)
 {
     /* main.c:844-858 — scan 0 at pose (0,0,0) seeds the map; the loop starts "mini-updated" */
     const float origin[3] = { 0, 0, 0 };
-    s->scan_n = orc_clean_scan(ranges, s->angles, s->nbeams, 0.023f, 24, s->sx, s->sy);
+    s->scan_n = orc_clean_scan(ranges, s->angles, s->nbeams, s->par.range_min, s->par.usable_range, s->sx, s->sy);
     orc_transform(s->sx, s->sy, s->scan_n, origin, s->stx, s->sty);
     memcpy(s->map_x, s->stx, sizeof(float) * (size_t)s->scan_n);   /* main.c:136-145 */
     memcpy(s->map_y, s->sty, sizeof(float) * (size_t)s->scan_n);
@@ -396,16 +411,16 @@ void orc_slam_first_frame(orc_slam *s, const float *ranges)
 static void build_grids(orc_slam *s)
 {
     /* main.c:870-871 -> :155-198 and :271-363 (both resolutions, then both EDTs) */
-    s->loc_n = orc_local_map(s->map_x, s->map_y, s->map_n, s->stx, s->sty, s->scan_n, 1.0f, s->loc_x, s->loc_y);
-    const float pix[2] = { 0.2f, 0.1f };   /* main.c:835-836 */
+    s->loc_n = orc_local_map(s->map_x, s->map_y, s->map_n, s->stx, s->sty, s->scan_n, s->par.border, s->loc_x, s->loc_y);
+    const float pix[2] = { s->par.pixel, s->par.pixel2 };   /* main.c:835-836 */
     for (int k = 0; k < 2; ++k)
         orc_rasterise(s->loc_x, s->loc_y, s->loc_n, pix[k], s->meta[k].ld, s->meta[k].ld, s->occ[k], &s->meta[k]);
     for (int k = 0; k < 2; ++k) {
         const double t0 = now_s();
         const orc_grid_meta *m = &s->meta[k];
-        if (s->edt_variant == 0) orc_edt_gather(s->occ[k], s->edt[k], m->ld, m->rows, m->cols, 10.0f);
-        else if (s->edt_variant == 1) orc_edt_scatter(s->occ[k], s->edt[k], m->ld, m->rows, m->cols, 10.0f);
-        else orc_edt_window(s->occ[k], s->edt[k], m->ld, m->rows, m->cols, 10.0f);
+        if (s->edt_variant == 0) orc_edt_gather(s->occ[k], s->edt[k], m->ld, m->rows, m->cols, s->par.edt_cap);
+        else if (s->edt_variant == 1) orc_edt_scatter(s->occ[k], s->edt[k], m->ld, m->rows, m->cols, s->par.edt_cap);
+        else orc_edt_window(s->occ[k], s->edt[k], m->ld, m->rows, m->cols, s->par.edt_cap);
         s->edt_s += now_s() - t0;
         s->edt_calls++;
     }
@@ -421,10 +436,10 @@ static void match(orc_slam *s, int which, const float pose[3], const float res[3
 
 void orc_slam_next_frame(orc_slam *s, const float *ranges, float pose_out[3])
 {
-    const float coarse[3] = { 0.05f, 0.05f, 0.008727f };    /* main.c:832 */
-    const float fine[3] = { 0.025f, 0.025f, 0.004363f };    /* main.c:833 */
+    const float *coarse = s->par.fast_res;    /* main.c:832 */
+    const float *fine = s->par.fast_res2;     /* main.c:833 */
 
-    s->scan_n = orc_clean_scan(ranges, s->angles, s->nbeams, 0.023f, 24, s->sx, s->sy);   /* :863 */
+    s->scan_n = orc_clean_scan(ranges, s->angles, s->nbeams, s->par.range_min, s->par.usable_range, s->sx, s->sy);   /* :863 */
     int transformed = 0;
     if (s->mini_updated) {   /* main.c:865-872 — note: transformed with the OLD pose (Q3) */
         orc_transform(s->sx, s->sy, s->scan_n, s->pose, s->stx, s->sty);
@@ -448,14 +463,14 @@ void orc_slam_next_frame(orc_slam *s, const float *ranges, float pose_out[3])
     const float dx = fabsf(s->pose[0] - s->map_pose[0]);
     const float dy = fabsf(s->pose[1] - s->map_pose[1]);
     const float dth = fabsf(s->pose[2] - s->map_pose[2]);
-    if (dx > 0.3f || dy > 0.3f || dth > 0.0872665f) {
+    if (dx > s->par.key_dt || dy > s->par.key_dt || dth > s->par.key_dr) {
         s->mini_updated = 1;
         if (!transformed) orc_transform(s->sx, s->sy, s->scan_n, s->pose, s->stx, s->sty);
         /* main.c:941-953 — hits of the LAST candidate, count of the BEST one, and the world
          * points indexed by in-bounds ordinal rather than beam number (Q2) */
         int added = 0;
         for (int j = 0; j < s->hits_n; ++j)
-            if (s->hits[j] > 1.5 && s->map_n + added < MAP_CAP + 4096) {
+            if (s->hits[j] > s->par.new_point_threshold && s->map_n + added < MAP_CAP + 4096) {
                 s->map_x[s->map_n + added] = s->stx[j];
                 s->map_y[s->map_n + added] = s->sty[j];
                 ++added;

@@ -39,7 +39,7 @@ void orc_beam_angles(float angle_min, float angle_inc, int nbeams, float *angles
 /* Range gate + polar->cartesian + order-preserving compaction (main.c:71-95).
  * Keeps beam k unless r < range_min or r > usable_range (int).  Returns the survivor count. */
 int orc_clean_scan(const float *ranges, const float *angles, int nbeams, float range_min,
-                   int usable_range, float *x, float *y);
+                   float usable_range, float *x, float *y);
 
 /* Sensor frame -> world frame with the reference's transposed rotation (main.c:97-118). */
 void orc_transform(const float *x, const float *y, int n, const float pose[3], float *tx, float *ty);
@@ -98,10 +98,20 @@ void orc_fastmatch(const orc_grid_meta *g, const float *edt, const float *bx, co
 
 typedef struct orc_slam orc_slam;   /* whole-pipeline state (the reference's globals) */
 
+/* the reference's run-time parameters as one struct (same fields, same order as slam_mapper_params in include/slam_hip.h) */
+typedef struct {
+    float fast_res[3], fast_res2[3];   /* main.c:832-833 */
+    float border, pixel, pixel2;       /* main.c:834-836 */
+    float key_dt, key_dr;              /* main.c:838-839 */
+    float range_min, usable_range;     /* main.c:50, :846 */
+    float edt_cap, new_point_threshold;   /* main.c:224, :943 */
+} orc_slam_params;
+void orc_slam_params_default(orc_slam_params *p);
 orc_slam *orc_slam_create(int nbeams, float angle_min, float angle_inc);
 void orc_slam_destroy(orc_slam *s);
 /* edt_variant: 0 gather (main.c), 1 scatter (main_accelerated.c), 2 window */
 void orc_slam_set_edt_variant(orc_slam *s, int edt_variant);
+void orc_slam_set_params(orc_slam *s, const orc_slam_params *p);
 /* first frame: builds the initial map at pose (0,0,0) (main.c:844-852) */
 void orc_slam_first_frame(orc_slam *s, const float *ranges);
 /* every later frame (main.c:859-969); writes the matched pose */

@@ -451,3 +451,49 @@ def test_particle_filter_host_program_tracks_the_reference_trajectory(orc, tmp_p
           f"vs ground truth: PF {pf_truth:.4f} m, reference {ref_truth:.4f} m")
     assert err_xy.max() < 0.10 and err_th.max() < 0.012
     assert pf_truth <= ref_truth
+
+
+# ------------------------------------------------------------------ slam_mapper_params (one struct of parameters)
+NON_DEFAULT = [0.04, 0.04, 0.007, 0.02, 0.02, 0.0035, 0.8, 0.1, 0.05, 0.2, 0.06, 0.05, 20.0, 8.0, 1.2]
+
+
+@pytest.mark.parametrize("mapper", [False, True])
+def test_non_default_parameters_equal_the_cpu_restatement(orc, tmp_path, mapper):
+    """A parameter set that differs from the reference's in every field (lattice steps, border, both pixel sizes, key-frame
+    thresholds, range gate, EDT cap, new-point threshold): the C host program — host front end and device-resident mapper —
+    prints the pose log and writes the map of the CPU restatement run with the same parameters, byte for byte, and that
+    log differs from the default one (the parameters really take effect)."""
+    info = json.loads((GOLDEN / "datasets.json").read_text())["parity"]
+    csv = tmp_path / "parity.csv"
+    orc.run_tool("gen_dataset", csv, *info["gen_args"])
+    frames = 500
+    par = [str(v) for v in NON_DEFAULT]
+    ref = orc.run_tool("main_cpu", csv, frames, NB, 1, tmp_path / "map_cpu.csv", "--params", *par, capture_output=True, text=True)
+    want = [ln for ln in ref.stdout.splitlines() if ln.startswith("pose =")]
+    exe = PKG_DIR / "lib" / "slam_main"
+    cmd = [str(exe)] + (["--mapper"] if mapper else []) + [str(csv), str(frames), str(NB), str(tmp_path / "map.csv"), "--params", *par]
+    r = subprocess.run(cmd, check=True, capture_output=True, text=True)
+    got = [ln for ln in r.stdout.splitlines() if ln.startswith("pose =")]
+    assert got == want and len(got) == frames - 1
+    assert (tmp_path / "map.csv").read_bytes() == (tmp_path / "map_cpu.csv").read_bytes()
+    assert "\n".join(got) + "\n" != "".join((GOLDEN / "parity_pose.txt").read_text().splitlines(keepends=True)[:frames - 1])
+
+
+def test_mapper_params_struct_defaults_and_validation():
+    """slam_mapper_params_default holds the reference's values (main.c:832-839, :50, :846, :224, :943); bad values are refused."""
+    pkg = load_package()
+    p = pkg.MapperParams.default()
+    want = [0.05, 0.05, 0.008727, 0.025, 0.025, 0.004363, 1.0, 0.2, 0.1, 0.3, 0.0872665, 0.023, 24.0, 10.0, 1.5]
+    assert np.array_equal(np.array(p.as_list(), np.float32), np.array(want, np.float32))
+    eng = pkg.Engine(0)
+    import ctypes as C
+    h = C.c_void_p()
+    bad = pkg.MapperParams.default()
+    bad.pixel = 0.0
+    assert eng.lib.slam_mapper_create_ex(eng.h, 360, -3.14, 0.0175, C.byref(bad), C.byref(h)) == -2
+    bad = pkg.MapperParams.default()
+    bad.edt_cap = 40.0
+    assert eng.lib.slam_mapper_create_ex(eng.h, 360, -3.14, 0.0175, C.byref(bad), C.byref(h)) == -5
+    assert eng.lib.slam_mapper_create_ex(eng.h, 360, -3.14, 0.0175, None, C.byref(h)) == 0
+    eng.lib.slam_mapper_destroy(h)
+    eng.close()

@@ -193,3 +193,22 @@ def test_a8_whole_program_pose_log_and_map(orc, tmp_path, name, frames, variant)
     assert (tmp_path / "map.csv").read_bytes() == (GOLDEN / f"{name}_map.csv").read_bytes()
     if name == "hall":
         assert int(r.stderr.rsplit("partial-inbounds frames", 1)[1]) > 300   # the fixture really exercises Q2
+
+
+def test_main_cpu_parameters_default_equals_golden_and_non_default_differs(orc, tmp_path):
+    """main_cpu --params with the reference's values reproduces the golden pose log of the compiled reference; a different
+    parameter set gives a different log (the parameters are live)."""
+    import json
+
+    info = json.loads((GOLDEN / "datasets.json").read_text())["parity"]
+    csv = tmp_path / "parity.csv"
+    orc.run_tool("gen_dataset", csv, *info["gen_args"])
+    frames = 300
+    default = ["0.05", "0.05", "0.008727", "0.025", "0.025", "0.004363", "1", "0.2", "0.1", "0.3", "0.0872665", "0.023", "24", "10", "1.5"]
+    golden = (GOLDEN / "parity_pose.txt").read_text().splitlines()[:frames - 1]
+    r = orc.run_tool("main_cpu", csv, frames, 1079, 0, tmp_path / "m.csv", "--params", *default, capture_output=True, text=True)
+    assert [ln for ln in r.stdout.splitlines() if ln.startswith("pose =")] == golden
+    other = list(default)
+    other[7], other[8], other[9] = "0.1", "0.05", "0.2"      # pixel sizes and the key-frame distance
+    r2 = orc.run_tool("main_cpu", csv, frames, 1079, 0, tmp_path / "m2.csv", "--params", *other, capture_output=True, text=True)
+    assert [ln for ln in r2.stdout.splitlines() if ln.startswith("pose =")] != golden
