@@ -141,7 +141,7 @@ int slam_engine_create(int device, slam_engine** out)
         hipHostGetDevicePointer((void**)&e->d_hplan, e->h_plan, 0) != hipSuccess ||
         hipHostMalloc((void**)&e->h_gate, sizeof(int32_t) * 2, hipHostMallocMapped) != hipSuccess ||
         hipHostGetDevicePointer((void**)&e->d_hgate, e->h_gate, 0) != hipSuccess ||
-        e->gate_buf.ensure(2 * sizeof(int32_t)) != hipSuccess ||
+        e->gate_buf.ensure(kGateBufWords * sizeof(int32_t)) != hipSuccess ||   // flag | ticket | accumulators: see kernels.h
         hipHostMalloc((void**)&e->h_heads, sizeof(int32_t) * 2, hipHostMallocMapped) != hipSuccess ||
         hipHostGetDevicePointer((void**)&e->d_hheads, e->h_heads, 0) != hipSuccess ||
         hipHostMalloc((void**)&e->h_obs, sizeof(int32_t) * 2, hipHostMallocMapped) != hipSuccess ||
@@ -167,7 +167,7 @@ int slam_engine_create(int device, slam_engine** out)
     if (getenv("SLAM_EKF_INPLACE")) e->ekf_inplace_form = atoi(getenv("SLAM_EKF_INPLACE"));
     if (getenv("SLAM_PF_PAGED")) e->pf_paged = atoi(getenv("SLAM_PF_PAGED")) != 0;
     {
-        const int32_t one[16] = { 1 };   // "the previous frame resampled": nothing is carried into the first frame; the rest 0
+        const int32_t one[kGateBufWords] = { 1 };   // "the previous frame resampled": nothing is carried into the first frame; the rest 0
         if (hipMemcpy(e->gate_buf.p, one, sizeof one, hipMemcpyHostToDevice) != hipSuccess) {
             (void)hipGetLastError();
             slam_engine_destroy(e);
@@ -754,34 +754,6 @@ int slam_ekf_update_dev(slam_engine* e, const float* d_map_in, float* d_map_out,
     return SLAM_OK;
 }
 
-}  // extern "C"
-
-int slam_engine_obs_list(slam_engine* e, int nlandmarks, slam::ObsListView* out)
-{
-    if (nlandmarks > kObsListMaxLandmarks || e->obs_nlandmarks != nlandmarks) return SLAM_ERR_INVALID_ARG;
-    const size_t L = (size_t)nlandmarks;
-    if (!e->obs_table_owned) e->obs_list_valid = false;   // the caller's arrays may have been rewritten since the last launch
-    if (e->obs_list.cap < 4 * (4 * L + 2)) {
-        HIP_TRY(hipStreamSynchronize(e->stream));
-        HIP_TRY(e->obs_list.ensure(4 * (4 * L + 2)));
-        e->obs_list_valid = false;
-    }
-    int32_t* li = e->obs_list.as<int32_t>();
-    if (!e->obs_list_valid) {
-        HIP_TRY(launch_build_obs_list(e->stream, e->d_obs_zx, e->d_obs_zy, nlandmarks, li, (float*)(li + L), (float*)(li + 2 * L),
-                                      li + 3 * L, li + 4 * L, e->d_hobs));
-        e->obs_list_valid = true;
-    }
-    out->id = li;
-    out->zx = (const float*)(li + L);
-    out->zy = (const float*)(li + 2 * L);
-    out->round = li + 3 * L;
-    out->count = li + 4 * L;
-    return SLAM_OK;
-}
-
-extern "C" {
-
 int slam_ekf_form_set(slam_engine* e, int form)
 {
     ENTER(e);
@@ -872,7 +844,7 @@ int slam_quantise_scan_dev(slam_engine* e, const float* d_logw, const float* d_m
     }
     const ProfScope prof(e, SLAM_PROF_SCAN);
     HIP_TRY(launch_quantise_scan(e->stream, d_logw, d_max, e->bmax_buf.as<float>(), e->bmax_count, n, cdf, tiles, d_sum,
-                                 carry, tiles + ntiles, tiles + 2 * ntiles, e->gate_buf.as<unsigned int>() + 2));
+                                 carry, tiles + ntiles, tiles + 2 * ntiles, e->gate_buf.as<unsigned int>() + kGateTicketWord));
     e->scan_n = n;
     e->carry_n = carry ? n : -1;
     return SLAM_OK;

@@ -220,9 +220,6 @@ int slam_engine_fastmatch(slam_engine* e, int slot, const float* d_bx, const flo
                           const int32_t* d_nbeams, const float pose[3], const float res[3], float out_pose[3],
                           float* best_hits, int32_t* best_hits_size, float* best_score, float* d_hits_persist);
 
-// the compact list of the current observation table (built now unless the list on file is still valid)
-int slam_engine_obs_list(slam_engine* e, int nlandmarks, slam::ObsListView* out);
-
 // slam_migrate_pack_dev for a session with paged maps (d_pt: page tables of nb entries, d_map: the page pool)
 extern "C" int slam_migrate_pack_paged(slam_engine* e, int n_local, int rank, int world, const int32_t* plan, const float* d_pose,
                             int64_t pose_ld, const float* d_map, int64_t row_stride, int plane_stride, int nlandmarks,

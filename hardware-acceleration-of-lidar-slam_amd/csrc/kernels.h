@@ -110,6 +110,11 @@ struct ObsListView {
     const int32_t* round = nullptr;
     const int32_t* count = nullptr;
 };
+struct ObsListOut {   // where launch_page_list leaves the same list (id == nullptr: none wanted)
+    int32_t* id = nullptr;
+    float *zx = nullptr, *zy = nullptr;
+    int32_t *round = nullptr, *count = nullptr;
+};
 struct PagedEkfArgs {
     float* pool;             // [npages][5][32]
     const int32_t* pt_in;    // [rows][nb] page tables of the ancestors
@@ -138,7 +143,8 @@ int pool_state_words();
 // a quarter / more than half of the landmarks observed; h_obs (mapped host memory): {observed, L, seq, votes[0], votes[1]}
 hipError_t launch_page_list(hipStream_t stream, const float* zx, const float* zy, int L, int nb, int32_t* tpage, int32_t* tindex,
                             int32_t* tmask, int32_t* tbase, int32_t* count, int n, int32_t* pool_state, int32_t* h_obs = nullptr,
-                            uint32_t seq = 0, int32_t* votes = nullptr, int32_t* h_touched = nullptr);
+                            uint32_t seq = 0, int32_t* votes = nullptr, int32_t* h_touched = nullptr,
+                            const ObsListOut& ol = ObsListOut());
 // the same sample as a launch of its own (one small workgroup), for sessions on rows
 hipError_t launch_obs_count(hipStream_t stream, const float* zx, const float* zy, int L, int32_t* h_obs, uint32_t seq, int32_t* votes);
 // form 0: every lane of a touched page runs the update arithmetic, one page after the other; form 1 (needs a.ol): the
@@ -188,6 +194,9 @@ struct HeadsOut {
     unsigned int* counter = nullptr;
     int32_t* h_out = nullptr;
 };
+// The gate's small device buffer, int32 words: [0] "the last resample stage did resample" (the flag logweight_kernel reads),
+// [1] pad, [2] the ticket of quantise_scan_kernel's shard sums, [3] pad, [4..9] its three 64-bit accumulators (8-byte aligned)
+enum { kGateFlagWord = 0, kGateTicketWord = 2, kGateBufWords = 16 };
 struct GateOut {
     int32_t* d_flag = nullptr;
     int32_t* h_flag = nullptr;

@@ -89,13 +89,17 @@ __global__ __launch_bounds__(1024) void page_list_kernel(const float* __restrict
                                                          int32_t* __restrict__ tmask, int32_t* __restrict__ tbase,
                                                          int32_t* __restrict__ count, int n, int32_t* __restrict__ pool_state,
                                                          int32_t* __restrict__ h_obs, uint32_t seq, int32_t* __restrict__ votes,
-                                                         int32_t* __restrict__ h_touched)
+                                                         int32_t* __restrict__ h_touched, ObsListOut ol)
 {
+    // ol.id != nullptr (L <= kObsListMaxLandmarks): the same pass also makes the compact observation list of
+    // build_obs_list_kernel (pf_kernels.hip) — ids ascending, measurements, accumulator rounds, {count, highest round}
+    __shared__ unsigned s_bits[kObsListMaxLandmarks / 32];
     __shared__ int s_wave[16], s_wobs[16];
-    __shared__ int s_base, s_obase;
+    __shared__ int s_base, s_obase, s_max_round;
     if (threadIdx.x == 0) {
         s_base = 0;
         s_obase = 0;
+        s_max_round = 0;
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -108,7 +112,16 @@ __global__ __launch_bounds__(1024) void page_list_kernel(const float* __restrict
             const float vx = zx[l], vy = zy[l];
             ob = vx == vx && vy == vy;
         }
+        float vx = 0.0f, vy = 0.0f;
+        if (ob) {
+            vx = zx[l];
+            vy = zy[l];
+        }
         const unsigned long long m = __ballot(ob);
+        if (ol.id) {
+            if (lane == 0) s_bits[(l0 >> 5) + 2 * wave] = (unsigned)m;
+            if (lane == 32) s_bits[(l0 >> 5) + 2 * wave + 1] = (unsigned)(m >> 32);
+        }
         int touched_before = 0, touched_mine = 0, touched_all = 0;   // pages of this wavefront: below mine / mine / all
 #pragma unroll
         for (int g = 0; g < kPerWave; ++g) {
@@ -138,6 +151,17 @@ __global__ __launch_bounds__(1024) void page_list_kernel(const float* __restrict
                 tbase[t] = ooff + __popcll(m & ((1ull << (g * kPage)) - 1ull));   // observations in the pages before this one
             }
         }
+        if (ol.id && ob) {
+            const int k = ooff + __popcll(m & ((1ull << lane) - 1ull));
+            ol.id[k] = l;
+            ol.zx[k] = vx;
+            ol.zy[k] = vy;
+            // round: earlier observed landmarks with the same l mod 128 = the same bit of every fourth word below
+            int r = 0;
+            for (int b2 = l - 128; b2 >= 0; b2 -= 128) r += (int)((s_bits[b2 >> 5] >> (b2 & 31)) & 1u);
+            ol.round[k] = r;
+            if (r > 0) atomicMax(&s_max_round, r);
+        }
         __syncthreads();
         if (threadIdx.x == 0) {
             int tot = 0, otot = 0;
@@ -154,6 +178,10 @@ __global__ __launch_bounds__(1024) void page_list_kernel(const float* __restrict
         const int T = s_base;
         count[0] = T;
         tbase[T] = s_obase;
+        if (ol.id) {
+            ol.count[0] = s_obase;
+            ol.count[1] = s_max_round;
+        }
         if (h_touched) *h_touched = T;   // a hint for the host: how many pages the update's launches should stage at a time
         pool_reserve(pool_state, (int64_t)n * T);   // this frame's n * T fresh pages
         if (h_obs) publish_obs_count(s_obase, L, votes, h_obs, seq);
@@ -590,10 +618,12 @@ inline int blocks256(int64_t n) { return (int)((n + 255) / 256); }
 
 hipError_t launch_page_list(hipStream_t stream, const float* zx, const float* zy, int L, int nb, int32_t* tpage, int32_t* tindex,
                             int32_t* tmask, int32_t* tbase, int32_t* count, int n, int32_t* pool_state, int32_t* h_obs, uint32_t seq,
-                            int32_t* votes, int32_t* h_touched)
+                            int32_t* votes, int32_t* h_touched, const ObsListOut& ol)
 {
+    ObsListOut o = ol;
+    if (L > kObsListMaxLandmarks) o.id = nullptr;
     page_list_kernel<<<1, 1024, 0, stream>>>(zx, zy, L, nb, tpage, tindex, tmask, tbase, count, n, pool_state,
-                                             votes ? h_obs : nullptr, seq, votes, h_touched);
+                                             votes ? h_obs : nullptr, seq, votes, h_touched, o);
     return hipGetLastError();
 }
 
@@ -611,9 +641,11 @@ hipError_t launch_ekf_paged(hipStream_t stream, const PagedEkfArgs& a, const Eve
     const int grid = (a.n + per_block - 1) / per_block;
     static const int pg_env = getenv("SLAM_PAGED_PG") ? atoi(getenv("SLAM_PAGED_PG")) : 0;
     // pages staged per pass: what the last frame touched (a frame's touched pages then go through in one pass without idle
-    // slots); any value gives the same results
+    // slots); any value gives the same results.  Frames that touch more than six pages per particle run the page-wide form:
+    // with that many pages the LDS image costs more wavefronts in flight than the list form saves (measured, 64k x 500 with
+    // 128 observed / 64k x 5000 with 512: 120 / 460 us page-wide against 123 / 474 us at best).
     const int pg = pg_env > 0 ? pg_env : (touched_hint > 0 ? touched_hint : 6);
-    if (form == 0 || !a.ol.id) ekf_paged_kernel<<<grid, kWaves * 64, 0, stream>>>(a);
+    if (form == 0 || !a.ol.id || (pg_env <= 0 && touched_hint > 6)) ekf_paged_kernel<<<grid, kWaves * 64, 0, stream>>>(a);
     else if (pg <= 1) ekf_paged_lds_kernel<1><<<grid, kWaves * 64, 0, stream>>>(a);
     else if (pg == 2) ekf_paged_lds_kernel<2><<<grid, kWaves * 64, 0, stream>>>(a);
     else if (pg == 3) ekf_paged_lds_kernel<3><<<grid, kWaves * 64, 0, stream>>>(a);

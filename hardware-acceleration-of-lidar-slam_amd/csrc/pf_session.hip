@@ -72,7 +72,8 @@ struct slam_pf {
     int32_t* freelist = nullptr;    // [npages] ascending free pages as of the last update
     uint32_t* stamp = nullptr;      // [npages] frame stamp of the last table that named the page
     uint32_t stamp_now = 0;
-    int32_t* page_scratch = nullptr;   // the free list's bookkeeping (pool_state_words()) | count | tpage[nb] | tindex[nb] | tmask[nb] | tbase[nb + 1]
+    int32_t* page_scratch = nullptr;   // the free list's bookkeeping (pool_state_words()) | count | tpage[nb] | tindex[nb] | tmask[nb] | tbase[nb + 1] |
+                                       // the frame's observation list id[Lp] | zx[Lp] | zy[Lp] | round[Lp] | {count, highest round}
     bool gated = false;             // cfg.resample_ess_frac in (0, 1): a frame resamples only when its ESS is low
     int64_t frames_resampled = 0;   // (as far as the host has looked: one frame behind)
     // SLAM_MAP_AUTO: the session watches how many landmarks the frames observe ({observed, L, seq} in words 24..26 of h_res,
@@ -236,7 +237,7 @@ void free_page_tables(slam_pf* pf)
 
 bool alloc_page_tables(slam_pf* pf)
 {
-    const size_t P = (size_t)pf->npages, words = 4 * (size_t)pf->nb + 2 + (size_t)pool_state_words();
+    const size_t P = (size_t)pf->npages, words = 4 * (size_t)pf->nb + 2 + (size_t)pool_state_words() + 4 * (size_t)pf->Lp + 2;
     const bool ok = dev_alloc((void**)&pf->freelist, P * 4) == hipSuccess && dev_alloc((void**)&pf->stamp, P * 4) == hipSuccess &&
                     hipMemset(pf->stamp, 0, P * 4) == hipSuccess && dev_alloc((void**)&pf->page_scratch, words * 4) == hipSuccess &&
                     hipMemset(pf->page_scratch, 0, words * 4) == hipSuccess &&
@@ -637,24 +638,33 @@ static int pf_step_impl(slam_pf* pf, int slot, const float dp[3], int use_observ
             if (e->obs_nlandmarks != L) return SLAM_ERR_NOT_READY;
             SLAM_HIP_TRY(e, e->ll_buf.ensure(sizeof(float) * sn));
             int32_t *pstate = pf->page_scratch, *count = pstate + pool_state_words(), *tpage = count + 1, *tindex = tpage + pf->nb,
-                    *tmask = tindex + pf->nb, *tbase = tmask + pf->nb;
+                    *tmask = tindex + pf->nb, *tbase = tmask + pf->nb, *lst = tbase + pf->nb + 1;
+            // the list form (one lane per observation) whenever a list can be made; SLAM_PAGED_FORM=0 keeps the page-wide form
+            static const int env_form = getenv("SLAM_PAGED_FORM") ? atoi(getenv("SLAM_PAGED_FORM")) : 1;
+            const int form = env_form != 0 && L <= kObsListMaxLandmarks ? 1 : 0;
+            ObsListOut lo;
+            if (form) {
+                lo.id = lst;
+                lo.zx = reinterpret_cast<float*>(lst + pf->Lp);
+                lo.zy = reinterpret_cast<float*>(lst + 2 * pf->Lp);
+                lo.round = lst + 3 * pf->Lp;
+                lo.count = lst + 4 * pf->Lp;
+            }
             {
                 const ProfScope prof(e, SLAM_PROF_PAGES);
                 SLAM_HIP_TRY(e, launch_page_list(e->stream, e->d_obs_zx, e->d_obs_zy, L, pf->nb, tpage, tindex, tmask, tbase, count, n, pstate,
                                                  sample_obs ? d_hobs : nullptr, sample_obs ? ++pf->obs_seq_issued : 0,
-                                                 sample_obs ? pf->votes : nullptr, reinterpret_cast<int32_t*>(pf->d_hres) + 30));
+                                                 sample_obs ? pf->votes : nullptr, reinterpret_cast<int32_t*>(pf->d_hres) + 30, lo));
                 // a new free list when the old one runs short (decided on the device; the pages in use carry the last stamp)
                 SLAM_HIP_TRY(e, launch_free_list(e->stream, pf->stamp, pf->npages, pf->stamp_now, pf->freelist, pstate,
                                                  reinterpret_cast<int32_t*>(pf->d_hres) + 20));
             }
             PagedEkfArgs a;
-            // the list form (one lane per observation) whenever a list can be made; SLAM_PAGED_FORM=0 keeps the page-wide form
-            static const int env_form = getenv("SLAM_PAGED_FORM") ? atoi(getenv("SLAM_PAGED_FORM")) : 1;
-            const int form = env_form != 0 && L <= kObsListMaxLandmarks ? 1 : 0;
-            if (form != 0) {
-                const ProfScope prof(e, SLAM_PROF_PAGES);
-                if (int rl = slam_engine_obs_list(e, L, &a.ol)) return rl;
-            }
+            a.ol.id = lo.id;
+            a.ol.zx = lo.zx;
+            a.ol.zy = lo.zy;
+            a.ol.round = lo.round;
+            a.ol.count = lo.count;
             a.tmask = tmask;
             a.tbase = tbase;
             a.pool = pf->pool;

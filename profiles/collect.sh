@@ -10,7 +10,7 @@ OUT=$ROOT/gpurun_out
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-B="python3 $ROOT/bench.py --no-cpu-baseline"
+B="python3 $ROOT/bench.py --no-cpu-baseline --no-extra-legs"
 step() { echo "[collect] $*"; }
 
 step "kernel trace, default workload (configs[1])"
@@ -20,10 +20,19 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${TAG}_trace_score
 for C in FETCH_SIZE WRITE_SIZE; do
   step "pmc $C: pf default, pf --observed 32, ekf sweep (calibration)"
   rocprofv3 --pmc $C --output-format csv -d "$OUT/${TAG}_pmc_${C}_pf" -- $B --mode pf --steps 8 --warmup 2 --events none > /dev/null 2> "$OUT/${TAG}_pmc_${C}_pf.err"
-  rocprofv3 --pmc $C --output-format csv -d "$OUT/${TAG}_pmc_${C}_pfobs32" -- $B --mode pf --observed 32 --steps 8 --warmup 2 --events none > /dev/null 2> "$OUT/${TAG}_pmc_${C}_pfobs32.err"
+  rocprofv3 --pmc $C --output-format csv -d "$OUT/${TAG}_pmc_${C}_pfobs32" -- $B --mode pf --observed 32 --map-layout rows --steps 8 --warmup 2 --events none > /dev/null 2> "$OUT/${TAG}_pmc_${C}_pfobs32.err"
   rocprofv3 --pmc $C --output-format csv -d "$OUT/${TAG}_pmc_${C}_ekf" -- $B --mode ekf --steps 8 --warmup 2 --events none > /dev/null 2> "$OUT/${TAG}_pmc_${C}_ekf.err"
 done
-step "copy ceiling of the EKF access shape (pure copy, no arithmetic)"
+step "copy ceilings: the EKF's row access shape, and scattered pages (pure copies, no arithmetic)"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -o /tmp/copy_ceiling "$ROOT/profiles/copy_ceiling.hip"
 { /tmp/copy_ceiling 65536 512; /tmp/copy_ceiling 1048576 1024; } > "$OUT/${TAG}_copy_ceiling.txt" 2>&1
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -o /tmp/page_copy_ceiling "$ROOT/profiles/page_copy_ceiling.hip"
+{ /tmp/page_copy_ceiling 65536; /tmp/page_copy_ceiling 1048576 67108864; } > "$OUT/${TAG}_page_copy_ceiling.txt" 2>&1
+step "hardware counters of the in-filter EKF kernel (one pass per group)"
+k=0
+for G in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_INSTS_VALU SQ_INSTS_VMEM_WR" "SQ_INSTS_VMEM_RD SQ_INSTS_SALU" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM" \
+         "SQ_WAIT_INST_ANY SQ_WAIT_ANY" "VALUBusy" "MemUnitStalled" "WriteUnitStalled" "GRBM_GUI_ACTIVE"; do
+  k=$((k + 1))
+  timeout -k 5 150 rocprofv3 --pmc $G --output-format csv -d "$OUT/${TAG}_ekfpmc_$k" -- $B --mode pf --steps 8 --warmup 2 --events none --no-sweep > /dev/null 2> "$OUT/${TAG}_ekfpmc_$k.err" || echo "[collect] ekf pmc pass $k ($G) FAILED"
+done
 step done

@@ -9,10 +9,10 @@ OUT=$ROOT/gpurun_out
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-B="python3 $ROOT/bench.py --no-cpu-baseline --no-sweep --observed 32"
+B="python3 $ROOT/bench.py --no-cpu-baseline --no-extra-legs --no-sweep --observed 32"
 for L in 500 5000; do
   for P in rows paged; do
-    F=""; [ $P = paged ] && F="--paged"
+    F="--map-layout rows"; [ $P = paged ] && F="--paged"
     echo "[collect_paged] trace L=$L $P"
     timeout -k 5 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${TAG}_pagedtrace_${L}_$P" -- $B --landmarks $L --steps 60 --warmup 10 --events none $F > "$OUT/${TAG}_pagedtrace_${L}_$P.json" 2> "$OUT/${TAG}_pagedtrace_${L}_$P.err"
   done

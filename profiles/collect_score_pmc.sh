@@ -9,7 +9,7 @@ OUT=$ROOT/gpurun_out
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-B="python3 $ROOT/bench.py --no-cpu-baseline --mode score --particles 1048576 --grid 2048 --steps 6 --warmup 2 --events none $SCORE_PMC_EXTRA"
+B="python3 $ROOT/bench.py --no-cpu-baseline --no-extra-legs --mode score --particles 1048576 --grid 2048 --steps 6 --warmup 2 --events none $SCORE_PMC_EXTRA"
 k=0
 for G in "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" \
          "TA_BUSY_avr TA_TA_BUSY_sum" "TA_FLAT_READ_WAVEFRONTS_sum" "TA_TOTAL_WAVEFRONTS_sum" \
