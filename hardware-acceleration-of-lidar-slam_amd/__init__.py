@@ -21,7 +21,10 @@ from pathlib import Path
 import numpy as np
 
 PKG_DIR = Path(__file__).resolve().parent
-LIB_PATH = PKG_DIR / "lib" / "libslam_hip.so"
+import os as _os
+
+# SLAM_HIP_LIB: another build of the same library (kernel-tuning measurements); the product is lib/libslam_hip.so
+LIB_PATH = Path(_os.environ["SLAM_HIP_LIB"]) if _os.environ.get("SLAM_HIP_LIB") else PKG_DIR / "lib" / "libslam_hip.so"
 HEADER_PATH = PKG_DIR.parent / "include" / "slam_hip.h"
 
 SLAM_OK = 0

@@ -290,8 +290,15 @@ __device__ __forceinline__ float lane_value(float v, int k)   // lane k's value,
     return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), k));
 }
 
+// EKF_GROUP_WPE: waves per SIMD the register allocation is held to.  Left alone the kernel takes 82 VGPRs = 5 waves; held
+// to 6 (80 VGPRs, two dwords of scratch) it measured 149 -> 147 us at 64k x 500 and 4.13 -> 3.96 ms at 1M x 1000 in the
+// filter; held to 8 (64 VGPRs, 100 bytes of scratch) 295 us / 7.5 ms.
+#ifndef EKF_GROUP_WPE
+#define EKF_GROUP_WPE 6
+#endif
+#define EKF_GROUP_ATTR __attribute__((amdgpu_waves_per_eu(EKF_GROUP_WPE, EKF_GROUP_WPE)))
 template <int NB, int G>
-__global__ __launch_bounds__(kEkfWaves * 64) void ekf_update_group_kernel(EkfArgs a)
+__global__ __launch_bounds__(kEkfWaves * 64) EKF_GROUP_ATTR void ekf_update_group_kernel(EkfArgs a)
 {
     __shared__ float s_acc[kEkfWaves][G][128];   // per particle of the group: the 128 accumulators of the specification
     const unsigned lane = threadIdx.x & 63u;
