@@ -65,8 +65,17 @@ template <class T> struct EkfResult {
     T o0, o1, o2, o3, o4, ll, f0, f1;
 };
 
-// prior (mx, my, pxx, pxy, pyy), observation (zx, zy) in the sensor frame, pose (px, py, heading sine s / cosine c), q = R
-template <class T>
+// what a first sighting puts into the map: the observed point in the world frame
+template <class T> __device__ __forceinline__ void ekf_first_sighting(T zx, T zy, T s, T c, T px, T py, T& f0, T& f1)
+{
+    f0 = px + (c * zx + s * zy);
+    f1 = py + (c * zy - s * zx);
+}
+
+// prior (mx, my, pxx, pxy, pyy), observation (zx, zy) in the sensor frame, pose (px, py, heading sine s / cosine c), q = R.
+// WITH_FIRST = false leaves f0 / f1 unset: the row kernels work them out (ekf_first_sighting) only for a batch of landmarks
+// that holds a first sighting at all, which in a running filter is rare.
+template <class T, bool WITH_FIRST = true>
 __device__ __forceinline__ EkfResult<T> ekf_update_one(T mx, T my, T pxx, T pxy, T pyy, T zx, T zy, T s, T c, T px, T py, T q)
 {
     EkfResult<T> r;
@@ -90,8 +99,7 @@ __device__ __forceinline__ EkfResult<T> ekf_update_one(T mx, T my, T pxx, T pxy,
     r.o4 = pyy - (k10 * a01 + k11 * a11);
     const T maha = vx * (i00 * vx + i01 * vy) + vy * (i01 * vx + i11 * vy);
     r.ll = ((ekf_splat<T>(0.0f) - ekf_splat<T>(0.5f) * maha) - ekf_splat<T>(0.5f) * ekf_log(det)) - ekf_splat<T>(1.8378770664f);
-    r.f0 = px + (c * zx + s * zy);
-    r.f1 = py + (c * zy - s * zx);
+    if (WITH_FIRST) ekf_first_sighting<T>(zx, zy, s, c, px, py, r.f0, r.f1);
     return r;
 }
 

@@ -102,7 +102,11 @@ hipError_t launch_build_obs_list(hipStream_t stream, const float* tzx, const flo
 hipError_t launch_ekf_sparse(hipStream_t stream, const EkfArgs& a, const int32_t* id, const float* zx, const float* zy,
                              const int32_t* round, const int32_t* count, const EventPair* ev = nullptr);
 // ---- paged_kernels.hip: landmark maps as copy-on-write pages of kPageLandmarks landmarks (5 planes x 32 floats = 640 B)
-constexpr int kPageLandmarks = 32;
+// (SLAM_PAGE_LANDMARKS: a power of two <= 32, for measurement builds — profiles/collect_page_sizes.sh; the product is built with 32)
+#ifndef SLAM_PAGE_LANDMARKS
+#define SLAM_PAGE_LANDMARKS 32
+#endif
+constexpr int kPageLandmarks = SLAM_PAGE_LANDMARKS;
 // the compact observation list launch_build_obs_list makes: ids ascending, measurements, accumulator rounds, {nobs, highest round}
 struct ObsListView {
     const int32_t* id = nullptr;

@@ -95,6 +95,44 @@ struct EkfLane {   // per-wavefront constants of one particle
     v2f s, c, px, py, q;
 };
 
+// What goes into the row for the two landmarks of a lane, given the update's result in r0 .. r4 / ll: a first sighting
+// (prior P_xx < 0) takes the observed point and P = q I and adds no likelihood term; a landmark without an observation keeps
+// its prior values.  Both cases are decided for the WAVEFRONT first (a ballot each): in a running filter most batches of
+// 128 landmarks hold neither — every landmark seen before, every one observed, or none — and then the selects (and the
+// arithmetic of the first sighting) are skipped altogether.  The values are those of
+//     ob ? (first ? {f0, f1, q, 0, q; 0} : {o0 .. o4; ll}) : {prior; 0}
+// in every case.
+__device__ __forceinline__ void ekf_select(v2f& r0, v2f& r1, v2f& r2, v2f& r3, v2f& r4, v2f& ll, v2f mx, v2f my, v2f pxx, v2f pxy,
+                                           v2f pyy, v2f zx, v2f zy, v2f s, v2f c, v2f px, v2f py, v2f q, bool ob0, bool ob1)
+{
+    if (__ballot(pxx[0] < 0.0f || pxx[1] < 0.0f) != 0) {
+        v2f f0, f1;
+        ekf_first_sighting<v2f>(zx, zy, s, c, px, py, f0, f1);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const bool first = pxx[t] < 0.0f;
+            r0[t] = first ? f0[t] : r0[t];
+            r1[t] = first ? f1[t] : r1[t];
+            r2[t] = first ? q[t] : r2[t];
+            r3[t] = first ? 0.0f : r3[t];
+            r4[t] = first ? q[t] : r4[t];
+            ll[t] = first ? 0.0f : ll[t];
+        }
+    }
+    if (__ballot(!(ob0 && ob1)) != 0) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const bool ob = t ? ob1 : ob0;
+            r0[t] = ob ? r0[t] : mx[t];
+            r1[t] = ob ? r1[t] : my[t];
+            r2[t] = ob ? r2[t] : pxx[t];
+            r3[t] = ob ? r3[t] : pxy[t];
+            r4[t] = ob ? r4[t] : pyy[t];
+            ll[t] = ob ? ll[t] : 0.0f;
+        }
+    }
+}
+
 // NB batches of 128 landmarks starting at lb: all loads first, then the arithmetic, then the stores.  A lane owns
 // landmarks l and l + 64 of each batch, so every access is one 256-byte dword access per wavefront (8-byte
 // accesses, a lane owning neighbours, were measured ~20 % slower whenever the source rows come out of L2).
@@ -146,30 +184,18 @@ __device__ __forceinline__ void ekf_batches(const EkfLane& w, unsigned lb, unsig
             continue;
         }
         const v2f q = w.q;
-        const EkfResult<v2f> u = ekf_update_one<v2f>(mx, my, pxx, pxy, pyy, zx[g], zy[g], w.s, w.c, w.px, w.py, q);
-        const v2f o0 = u.o0, o1 = u.o1, o2 = u.o2, o3 = u.o3, o4 = u.o4, f0 = u.f0, f1 = u.f1;
-        v2f ll = u.ll;
+        const EkfResult<v2f> u = ekf_update_one<v2f, false>(mx, my, pxx, pxy, pyy, zx[g], zy[g], w.s, w.c, w.px, w.py, q);
+        v2f r0 = u.o0, r1 = u.o1, r2 = u.o2, r3 = u.o3, r4 = u.o4, ll = u.ll;
+        ekf_select(r0, r1, r2, r3, r4, ll, mx, my, pxx, pxy, pyy, zx[g], zy[g], w.s, w.c, w.px, w.py, q, obs[g][0], obs[g][1]);
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const bool ob = obs[g][t];
-            const bool first = pxx[t] < 0.0f;
-            // two plain selects per value (nested ternaries came out as exec-mask branches)
-            float r0 = first ? f0[t] : o0[t], r1 = first ? f1[t] : o1[t], r2 = first ? q[t] : o2[t];
-            float r3 = first ? 0.0f : o3[t], r4 = first ? q[t] : o4[t], rl = first ? 0.0f : ll[t];
-            r0 = ob ? r0 : mx[t];
-            r1 = ob ? r1 : my[t];
-            r2 = ob ? r2 : pxx[t];
-            r3 = ob ? r3 : pxy[t];
-            r4 = ob ? r4 : pyy[t];
-            ll[t] = ob ? rl : 0.0f;
+        for (int t = 0; t < 2; ++t)
             if (FULL || use[g][t]) {
-                row_store(w.rout, off[g][t], 0 * w.pl, r0);
-                row_store(w.rout, off[g][t], 1 * w.pl, r1);
-                row_store(w.rout, off[g][t], 2 * w.pl, r2);
-                row_store(w.rout, off[g][t], 3 * w.pl, r3);
-                row_store(w.rout, off[g][t], 4 * w.pl, r4);
+                row_store(w.rout, off[g][t], 0 * w.pl, r0[t]);
+                row_store(w.rout, off[g][t], 1 * w.pl, r1[t]);
+                row_store(w.rout, off[g][t], 2 * w.pl, r2[t]);
+                row_store(w.rout, off[g][t], 3 * w.pl, r3[t]);
+                row_store(w.rout, off[g][t], 4 * w.pl, r4[t]);
             }
-        }
         acc = acc + ll;
     }
 }
@@ -259,26 +285,16 @@ __device__ __forceinline__ void ekf_apply(const EkfBatch<NB>& b, const EkfPose& 
             continue;
         }
         const v2f q = q2;
-        const EkfResult<v2f> u = ekf_update_one<v2f>(mx, my, pxx, pxy, pyy, b.zx[g], b.zy[g], w.s, w.c, w.px, w.py, q);
-        const v2f o0 = u.o0, o1 = u.o1, o2 = u.o2, o3 = u.o3, o4 = u.o4, f0 = u.f0, f1 = u.f1;
-        v2f ll = u.ll;
+        const EkfResult<v2f> u = ekf_update_one<v2f, false>(mx, my, pxx, pxy, pyy, b.zx[g], b.zy[g], w.s, w.c, w.px, w.py, q);
+        v2f r0 = u.o0, r1 = u.o1, r2 = u.o2, r3 = u.o3, r4 = u.o4, ll = u.ll;
+        ekf_select(r0, r1, r2, r3, r4, ll, mx, my, pxx, pxy, pyy, b.zx[g], b.zy[g], w.s, w.c, w.px, w.py, q, b.obs[g][0], b.obs[g][1]);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            const bool ob = b.obs[g][t];
-            const bool first = pxx[t] < 0.0f;
-            float r0 = first ? f0[t] : o0[t], r1 = first ? f1[t] : o1[t], r2 = first ? q[t] : o2[t];
-            float r3 = first ? 0.0f : o3[t], r4 = first ? q[t] : o4[t], rl = first ? 0.0f : ll[t];
-            r0 = ob ? r0 : mx[t];
-            r1 = ob ? r1 : my[t];
-            r2 = ob ? r2 : pxx[t];
-            r3 = ob ? r3 : pxy[t];
-            r4 = ob ? r4 : pyy[t];
-            ll[t] = ob ? rl : 0.0f;
-            row_store(w.rout, b.off[g][t], 0 * pl, r0);
-            row_store(w.rout, b.off[g][t], 1 * pl, r1);
-            row_store(w.rout, b.off[g][t], 2 * pl, r2);
-            row_store(w.rout, b.off[g][t], 3 * pl, r3);
-            row_store(w.rout, b.off[g][t], 4 * pl, r4);
+            row_store(w.rout, b.off[g][t], 0 * pl, r0[t]);
+            row_store(w.rout, b.off[g][t], 1 * pl, r1[t]);
+            row_store(w.rout, b.off[g][t], 2 * pl, r2[t]);
+            row_store(w.rout, b.off[g][t], 3 * pl, r3[t]);
+            row_store(w.rout, b.off[g][t], 4 * pl, r4[t]);
         }
         acc = acc + ll;
     }

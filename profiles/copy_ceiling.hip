@@ -74,6 +74,45 @@ __global__ __launch_bounds__(256) void copy_rows(const float* __restrict__ in, f
     }
 }
 
+
+// G neighbouring rows per wavefront, the source batch kept in REGISTERS while it is stored G times (what
+// ekf_update_group_kernel does with the rows of a repeated ancestor): rows i - i % share .. share a source, share >= G
+template <int NB, int G>
+__global__ __launch_bounds__(256) void copy_rows_group(const float* __restrict__ in, float* __restrict__ out, int n, int Lp, int xcd_chunk,
+                                                       int share)
+{
+    const unsigned lane = threadIdx.x & 63u;
+    const int wave = threadIdx.x >> 6;
+    int bid = blockIdx.x;
+    if (xcd_chunk > 0) bid = (bid & 7) * xcd_chunk + (bid >> 3);
+    const int g0 = (bid * 4 + wave) * G;
+    if (g0 >= n) return;
+    for (int lb = 0; lb + 128 * NB <= Lp; lb += 128 * NB) {
+        float m[NB][2][5];
+        int prev = -1;
+        for (int k = 0; k < G && g0 + k < n; ++k) {
+            const int i = g0 + k, src = share > 1 ? i - i % share : i;
+            if (src != prev) {
+                const float* rin = in + (size_t)src * 5 * Lp;
+#pragma unroll
+                for (int g = 0; g < NB; ++g)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int p = 0; p < 5; ++p) m[g][t][p] = rin[p * Lp + lb + g * 128 + t * 64 + lane];
+                prev = src;
+            }
+            float* rout = out + (size_t)i * 5 * Lp;
+#pragma unroll
+            for (int g = 0; g < NB; ++g)
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int p = 0; p < 5; ++p) __builtin_nontemporal_store(m[g][t][p] + (float)k, &rout[p * Lp + lb + g * 128 + t * 64 + lane]);
+        }
+    }
+}
+
 template <class K> float time_it(K launch, int reps)
 {
     hipEvent_t a, b;
@@ -126,5 +165,18 @@ int main(int argc, char** argv)
     RUNS("dword  nb2 nt  write only", 0, (double)bytes)
     RUNS("dword  nb2 nt  source shared by 16", 16, (double)bytes * (1.0 + 1.0 / 16))
     RUNS("dword  nb2 nt  source shared by 64", 64, (double)bytes * (1.0 + 1.0 / 64))
+#define RUNG(name, G, share, bytes_moved)                                                                          \
+    {                                                                                                              \
+        const int gblocks = (n + 4 * G - 1) / (4 * G), gchunk = (gblocks + 7) / 8;                                 \
+        float ms = time_it([&](int r) {                                                                            \
+            float* src = (r & 1) ? b : a; float* dst = (r & 1) ? a : b;                                            \
+            copy_rows_group<2, G><<<gchunk * 8, 256>>>(src, dst, n, Lp, gchunk, share); }, 20);                     \
+        printf("%-34s %8.1f us  %7.0f GB/s (HBM bytes: %s)\n", name, ms * 1e3, (bytes_moved) / 1e9 / (ms * 1e-3), #bytes_moved); \
+    }
+    RUNG("grouped x2, source shared by 16", 2, 16, (double)bytes * (1.0 + 1.0 / 16))
+    RUNG("grouped x4, source shared by 16", 4, 16, (double)bytes * (1.0 + 1.0 / 16))
+    RUNG("grouped x8, source shared by 16", 8, 16, (double)bytes * (1.0 + 1.0 / 16))
+    RUNG("grouped x4, source shared by 4", 4, 4, (double)bytes * (1.0 + 1.0 / 4))
+    RUNG("grouped x2, nothing shared", 2, 1, 2.0 * (double)bytes)
     return 0;
 }
