@@ -686,7 +686,7 @@ def run_rank(args, ctx, inp):
         ekf_name = "ekf_sparse_kernel" if forms[3] > forms[2] else "ekf_update_kernel (in place)"
     else:
         ekf_name = "ekf_update_group_kernel" if forms[1] > forms[0] else "ekf_update_kernel"
-    if ekf_n and (ekf_ms >= score_ms or args.mode == "ekf"):
+    if ekf_n and (ekf_ms / ekf_n >= score_ms / max(score_n, 1) or args.mode == "ekf"):
         kern, raw_ms, dur_ms, alg = ekf_name, ekf_ms / ekf_n, kernel_ms(ekf_ms, ekf_n), ekf_bytes
     else:
         kern, raw_ms, dur_ms, alg = ("score_poses_kernel", score_ms / max(score_n, 1), kernel_ms(score_ms, score_n), score_bytes)

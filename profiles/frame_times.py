@@ -15,6 +15,7 @@ from __graft_entry__ import load_package  # noqa: E402
 
 layout = sys.argv[1] if len(sys.argv) > 1 else "auto"
 repeats = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+nosync = len(sys.argv) > 3 and sys.argv[3] == "nosync"   # like bench.py's leg: the host runs ahead, one synchronisation per region
 pkg = load_package()
 dev = torch.device("cuda", 0)
 eng = pkg.Engine(0)
@@ -43,6 +44,22 @@ for rep in range(repeats):
     eng.sync()
     del m0
     times, host = [], []
+    if nosync:
+        warm, t0 = 12, 0.0
+        for k in range(52):
+            if k == warm:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+            eng.scan_set_dev(d_scan[k, 0], d_scan[k, 1], beams)
+            eng.obs_set_dev(tabs[k, 0], tabs[k, 1], L)
+            ses.step(0, fr[k]["dp"], True)
+        t1 = time.perf_counter()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        print(f"rep {rep} layout {layout} nosync: {1e3 * (t2 - t0) / 40:.4f} ms per frame (host issued the 40 frames in {1e3 * (t1 - t0):.2f} ms), "
+              f"ended on {'pages' if ses.is_paged() else 'rows'}, conversions {ses.conversions() if hasattr(ses, 'conversions') else '?'}")
+        ses.close()
+        continue
     for k in range(len(fr)):
         t0 = time.perf_counter()
         eng.scan_set_dev(d_scan[k, 0], d_scan[k, 1], beams)
