@@ -14,7 +14,7 @@ B="python3 $ROOT/bench.py --no-cpu-baseline --no-extra-legs"
 step() { echo "[collect] $*"; }
 
 step "kernel trace, default workload (configs[1])"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${TAG}_trace_pf" -- $B --steps 100 --warmup 10 --no-sweep > "$OUT/${TAG}_trace_pf.json" 2> "$OUT/${TAG}_trace_pf.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${TAG}_trace_pf" -- $B --steps 100 --warmup 10 --no-sweep --event-every 1 > "$OUT/${TAG}_trace_pf.json" 2> "$OUT/${TAG}_trace_pf.err"
 step "kernel trace, score-only (configs[2])"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${TAG}_trace_score" -- $B --mode score --particles 1048576 --grid 2048 --steps 50 --warmup 5 > "$OUT/${TAG}_trace_score.json" 2> "$OUT/${TAG}_trace_score.err"
 for C in FETCH_SIZE WRITE_SIZE; do

@@ -32,7 +32,8 @@ def counter(mode, name):
     # both out-of-place kernels (ekf_update_kernel / ekf_update_group_kernel) count as "the EKF kernel"
     rows = [r for r in csv.DictReader(open(f)) if "ekf_update_" in r["Kernel_Name"] and r["Counter_Name"] == name]
     global last_kernel
-    names = [r["Kernel_Name"].split("(")[0].replace("void slam::", "").replace("(anonymous namespace)::", "") for r in rows[4:10]]
+    names = [r["Kernel_Name"].replace("void slam::", "").replace("slam::", "").replace("(anonymous namespace)::", "").split("(")[0]
+             for r in rows[4:10]]
     last_kernel = max(set(names), key=names.count) if names else KERNEL   # the kernel the steady frames ran
     return [float(r["Counter_Value"]) * 1024 for r in rows]
 

@@ -20,7 +20,7 @@ for d in sorted(glob.glob(str(src / f"{tag}_ekfpmc_*"))):
     rows = [r for r in csv.DictReader(open(max(fs, key=os.path.getmtime))) if "ekf_update" in r["Kernel_Name"]]
     for r in rows:
         vals[r["Counter_Name"]].append(float(r["Counter_Value"]))
-        kern = r["Kernel_Name"].split("(")[0]
+        kern = r["Kernel_Name"].replace("void slam::", "").replace("slam::", "").replace("(anonymous namespace)::", "").split("(")[0]
 md = [f"# {tag}: hardware counters of the in-filter EKF kernel (`{kern}`), configs[1], one `rocprofv3 --pmc` pass per group", "",
       "| counter | per-launch average (launches 4.. of `bench.py --steps 8 --warmup 2 --events none --no-sweep`) |", "|---|---|"]
 for name, v in vals.items():
