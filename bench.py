@@ -460,6 +460,15 @@ class ThreadCtx:
 
 
 # ------------------------------------------------------------------------------------------------ one rank
+def settle(torch, seconds=0.25):
+    """Between set-up (allocations, host-to-device copies, session creation) and the first frame: drain the device and let
+    the host sleep.  On the pool's boxes the driver answers something in the set-up some 10-50 ms later by holding the
+    process's queues for 65-80 ms (stage timers normal, host issue times normal, the stream simply stands still:
+    profiles/r03_stall_*.txt); without the pause that lands in the frames that follow in about one run in three."""
+    torch.cuda.synchronize()
+    time.sleep(seconds)
+
+
 def fill_maps(torch, m0, landmarks, L, dev, n):
     """Plausible maps [n][5][Lp]: every landmark near its true place with a loose covariance."""
     lm = torch.from_numpy(landmarks.astype(np.float32)).to(dev)
@@ -581,6 +590,7 @@ def run_rank(args, ctx, inp):
             eng.ekf_update_dev(sweep["maps"][k & 1], sweep["maps"][1 - (k & 1)], 5 * Lp, Lp, L, p[0], p[1], p[2], None, n,
                                MEAS_VAR, loglik_t)
 
+    settle(torch)
     for k in range(args.warmup):
         one_step(k)
     ctx.barrier()
@@ -866,6 +876,7 @@ def extra_legs(args, torch, pkg, eng, dev, inp, kernel_ms):
         eng.sync()
         del m0
         chunk_ms = []
+        settle(torch)
         for k in range(steps + warm):
             if k >= warm and (k - warm) % chunk == 0:
                 torch.cuda.synchronize()

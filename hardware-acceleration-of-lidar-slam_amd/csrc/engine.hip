@@ -146,6 +146,8 @@ int slam_engine_create(int device, slam_engine** out)
         hipHostGetDevicePointer((void**)&e->d_hheads, e->h_heads, 0) != hipSuccess ||
         hipHostMalloc((void**)&e->h_obs, sizeof(int32_t) * 2, hipHostMallocMapped) != hipSuccess ||
         hipHostGetDevicePointer((void**)&e->d_hobs, e->h_obs, 0) != hipSuccess ||
+        hipHostMalloc(&e->h_pf_res, 128, hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer(&e->d_hpf_res, e->h_pf_res, 0) != hipSuccess ||
         e->heads_buf.ensure(2 * sizeof(int32_t)) != hipSuccess ||
         hipMemset(e->heads_buf.p, 0, 2 * sizeof(int32_t)) != hipSuccess ||   // the gate's flag + the ticket word of quantise_scan_kernel
         e->scan_buf.ensure(sizeof(float) * 2 * SLAM_MAX_BEAMS) != hipSuccess ||
@@ -213,6 +215,7 @@ int slam_engine_destroy(slam_engine* e)
     if (e->h_gate) (void)hipHostFree(e->h_gate);
     if (e->h_heads) (void)hipHostFree(e->h_heads);
     if (e->h_obs) (void)hipHostFree(e->h_obs);
+    if (e->h_pf_res) (void)hipHostFree(e->h_pf_res);
     e->obs_list.release();
     e->heads_buf.release();
     e->gate_buf.release();

@@ -127,6 +127,11 @@ struct slam_engine {
     bool obs_table_owned = false;   // the table is the engine's own copy (slam_obs_upload_host), not the caller's arrays
     int32_t* h_obs = nullptr;
     int32_t* d_hobs = nullptr;
+    // 128 bytes of mapped host memory the engine's (one) particle-filter session delivers its results through.  It belongs to
+    // the ENGINE, not to the session: freeing pinned host memory makes the driver hold the process's queues for 65-80 ms some
+    // 10-50 ms later (profiles/r03_stall_trigger.txt) — a session that came and went would stall the frames of the next one.
+    void* h_pf_res = nullptr;
+    void* d_hpf_res = nullptr;
     int ekf_inplace_form = -1;   // slam_ekf_inplace_form_set: -1 by the feedback, 0 whole rows, 1 observed landmarks only
     int64_t ekf_inplace_launches[2] = { 0, 0 };
     slam_comm* comm = nullptr; // the communicator made on this engine, if any: host-side waits poll it for failures

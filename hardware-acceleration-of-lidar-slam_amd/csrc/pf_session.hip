@@ -396,10 +396,12 @@ int create_common(slam_engine* e, const slam_pf_config* cfg, slam_comm* comm, in
          dev_alloc((void**)&pf->count, n * 4) == hipSuccess && dev_alloc((void**)&pf->first, n * 4) == hipSuccess &&
          dev_alloc((void**)&pf->res_dev, 64) == hipSuccess && dev_alloc((void**)&pf->sums_acc, 64) == hipSuccess &&
          dev_alloc(&pf->res_all, 64 * G) == hipSuccess &&
-         hipMemset(pf->sums_acc, 0, 64) == hipSuccess &&
-         hipHostMalloc((void**)&pf->h_res, 128, hipHostMallocMapped) == hipSuccess &&
-         hipHostGetDevicePointer((void**)&pf->d_hres, pf->h_res, 0) == hipSuccess;
-    if (ok) memset(pf->h_res, 0, 128);
+         hipMemset(pf->sums_acc, 0, 64) == hipSuccess;
+    // results come back through the engine's mapped buffer (one session per engine; see engine_internal.h for why the
+    // session does not allocate its own); the engine was drained above, so nothing of an earlier session writes to it any more
+    pf->h_res = static_cast<decltype(pf->h_res)>(e->h_pf_res);
+    pf->d_hres = static_cast<decltype(pf->d_hres)>(e->d_hpf_res);
+    if (ok) memset(e->h_pf_res, 0, 128);
     if (comm)
         ok = ok && dev_alloc((void**)&pf->pose_all, 3 * n * G * 4) == hipSuccess &&
              dev_alloc((void**)&pf->pose_stage, 3 * cap * 4) == hipSuccess &&
@@ -470,8 +472,7 @@ int slam_pf_destroy(slam_pf* pf)
                      (void*)pf->rbuf, (void*)pf->res_dev, (void*)pf->sums_acc, pf->res_all })
         (void)hipFree(p);
     (void)hipFree(pf->sel);
-    if (pf->h_res) (void)hipHostFree(pf->h_res);
-    delete pf;
+    delete pf;   // h_res is the engine's
     return SLAM_OK;
 }
 

@@ -15,7 +15,9 @@ from __graft_entry__ import load_package  # noqa: E402
 
 layout = sys.argv[1] if len(sys.argv) > 1 else "auto"
 repeats = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-nosync = len(sys.argv) > 3 and sys.argv[3] == "nosync"   # like bench.py's leg: the host runs ahead, one synchronisation per region
+nosync = len(sys.argv) > 3 and sys.argv[3] in ("nosync", "stages")   # like bench.py's leg: the host runs ahead, one synchronisation per region
+settle = float(sys.argv[4]) if len(sys.argv) > 4 else 0.0               # seconds of host sleep between session set-up and the first (warm-up) frame
+stages = len(sys.argv) > 3 and sys.argv[3] == "stages"                # ... with every stage bracketed by HIP events: which stage holds a stall
 pkg = load_package()
 dev = torch.device("cuda", 0)
 eng = pkg.Engine(0)
@@ -47,8 +49,15 @@ for rep in range(repeats):
     if nosync:
         warm, t0 = 12, 0.0
         for k in range(52):
+            if k == 0 and settle > 0:   # before the warm-up frames, so that the timed frames follow warm ones directly
+                torch.cuda.synchronize()
+                time.sleep(settle)
             if k == warm:
                 torch.cuda.synchronize()
+                if stages:
+                    eng.profile_enable(*range(eng.PROF_COUNT))
+                    for kk in range(eng.PROF_COUNT):
+                        eng.profile_read(kk)
                 t0 = time.perf_counter()
             eng.scan_set_dev(d_scan[k, 0], d_scan[k, 1], beams)
             eng.obs_set_dev(tabs[k, 0], tabs[k, 1], L)
@@ -56,6 +65,11 @@ for rep in range(repeats):
         t1 = time.perf_counter()
         torch.cuda.synchronize()
         t2 = time.perf_counter()
+        if stages:
+            tot = {eng.PROF_NAMES[kk]: eng.profile_read(kk) for kk in range(eng.PROF_COUNT)}
+            eng.profile_enable()
+            print(f"rep {rep} stages (total ms over 40 frames): " + ", ".join(f"{k} {v[0]:.3f}" for k, v in tot.items() if v[1]) +
+                  f"; sum {sum(v[0] for v in tot.values()):.3f}, wall {1e3 * (t2 - t0):.3f}")
         print(f"rep {rep} layout {layout} nosync: {1e3 * (t2 - t0) / 40:.4f} ms per frame (host issued the 40 frames in {1e3 * (t1 - t0):.2f} ms), "
               f"ended on {'pages' if ses.is_paged() else 'rows'}, conversions {ses.conversions() if hasattr(ses, 'conversions') else '?'}")
         ses.close()
