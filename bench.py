@@ -461,10 +461,11 @@ class ThreadCtx:
 
 # ------------------------------------------------------------------------------------------------ one rank
 def settle(torch, seconds=0.25):
-    """Between set-up (allocations, host-to-device copies, session creation) and the first frame: drain the device and let
-    the host sleep.  On the pool's boxes the driver answers something in the set-up some 10-50 ms later by holding the
-    process's queues for 65-80 ms (stage timers normal, host issue times normal, the stream simply stands still:
-    profiles/r03_stall_*.txt); without the pause that lands in the frames that follow in about one run in three."""
+    """Between set-up (engine and session creation, allocations) and the first frame: drain the device and let the host
+    sleep.  The driver answers an allocation of pinned host memory (hipHostMalloc: the engine makes a few when it is
+    created) some 10-50 ms later by holding the process's queues for 65-80 ms — stage timers normal, host issue times
+    normal, the stream simply stands still (profiles/r03_stall_trigger.txt, r03_stall_frames.txt, DESIGN.md section 8);
+    without the pause that can land in the frames that follow."""
     torch.cuda.synchronize()
     time.sleep(seconds)
 
@@ -862,8 +863,7 @@ def extra_legs(args, torch, pkg, eng, dev, inp, kernel_ms):
     tabs = obs_tables(torch, fr, L, dev)
     e2e = {"what": "configs[1] (65536 x 500, 360 beams, 1024^2 EDT) with the 32 nearest landmarks observed per frame, every "
                    "frame resampled: whole frames on the C session; `*_ms` = median over chunks of 10 frames (one "
-                   "synchronisation per chunk; `*_ms_chunks` lists them: legs on pages showed one-off device-side stalls of 2-50 ms "
-                   "on some boxes of the pool, cause not found, see DESIGN.md section 8)", "steps": steps}
+                   "synchronisation per chunk; `*_ms_chunks` lists them)", "steps": steps}
     for layout in ("rows", "pages", "auto"):
         ses = pkg.PfSession(eng, n, L, sigma=SIGMA, meas_var=MEAS_VAR, score_gain=SCORE_GAIN, seed=1234, map_layout=layout)
         g = torch.Generator(device="cpu").manual_seed(1234)
