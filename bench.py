@@ -604,10 +604,10 @@ def run_rank(args, ctx, inp):
     forms0 = eng.ekf_form_counts() + eng.ekf_inplace_form_counts()
     # A HIP-event bracket around one kernel costs the STREAM ~12 us (rocprofv3 timeline of this command: ~6 us of idle
     # stream before and after the bracketed kernel, none between the other launches), so only every `--event-every`-th frame
-    # of the timed region carries it: the kernel's duration is still measured live, inside the timed region, on the kernel's
+    # (default: every 4th, every 2nd in runs of fewer than 40 steps) of the timed region carries it: the kernel's duration is still measured live, inside the timed region, on the kernel's
     # own stream, while the measurement itself costs the frame rate ~1.5 % instead of ~6 %.  `roofline.launches` says how
     # many launches were bracketed; --event-every 1 brackets every frame.
-    every = max(1, args.event_every)
+    every = max(1, args.event_every if args.event_every > 0 else (4 if args.steps >= 40 else 2))   # short runs: at least ~10 samples
     t0 = time.perf_counter()
     for k in range(args.warmup, args.warmup + args.steps):
         if every > 1:
@@ -927,8 +927,9 @@ def parse_args():
                          "process on ONE card (--device-index, default 0), exchanging through slam_comm_create_local")
     ap.add_argument("--device-index", type=int, default=None, help="force every rank onto this GPU (--transport local)")
     ap.add_argument("--host-sensor", action="store_true", help="upload scan + observations from the host every frame")
-    ap.add_argument("--event-every", type=int, default=4,
-                    help="bracket the timed kernels with HIP events in every N-th frame of the timed region (1 = every frame)")
+    ap.add_argument("--event-every", type=int, default=0,
+                    help="bracket the timed kernels with HIP events in every N-th frame of the timed region (1 = every frame; "
+                         "default 0 = every 4th frame, every 2nd when --steps < 40)")
     ap.add_argument("--events", choices=["dominant", "all", "none"], default="dominant",
                     help="kernels bracketed by HIP events inside the timed region (a pair costs a few us of stream time)")
     ap.add_argument("--observed", type=int, default=0,
