@@ -602,6 +602,7 @@ def run_rank(args, ctx, inp):
         eng.profile_read(kk)
     migrated = 0
     forms0 = eng.ekf_form_counts() + eng.ekf_inplace_form_counts()
+    fused0 = eng.frame_fusion_count()
     # A HIP-event bracket around one kernel costs the STREAM ~12 us (rocprofv3 timeline of this command: ~6 us of idle
     # stream before and after the bracketed kernel, none between the other launches), so only every `--event-every`-th frame
     # (default: every 4th, every 2nd in runs of fewer than 40 steps) of the timed region carries it: the kernel's duration is still measured live, inside the timed region, on the kernel's
@@ -619,6 +620,7 @@ def run_rank(args, ctx, inp):
     eng.profile_enable()
     forms1 = eng.ekf_form_counts() + eng.ekf_inplace_form_counts()
     forms = tuple(b - a for a, b in zip(forms0, forms1))   # EKF launches of the timed region, by kernel (out of place x2, in place x2)
+    fused_n = eng.frame_fusion_count() - fused0             # ... of which went out fused with the motion + score launch
     paged_in_region = pf.is_paged()
     elapsed = ctx.max_over_ranks(elapsed)
     migrated = ctx.max_over_ranks(migrated / max(args.steps, 1))
@@ -636,10 +638,12 @@ def run_rank(args, ctx, inp):
     # every stage of a frame through the per-stage timers: a short extra pass, outside the timing (the trajectory simply
     # continues; the brackets cost stream time, which is why the timed region carries only the dominant kernel's)
     eng.profile_enable(*range(eng.PROF_COUNT))
+    eng.frame_fusion_set(False)   # the stages one by one: score and landmark update as two launches (same bits)
     extra = min(10, args.steps)
     for k in range(extra):
         one_step(args.warmup + args.steps + k)
     eng.profile_enable()
+    eng.frame_fusion_set(True)
     stage_avg_ms = {}
     for kk in range(eng.PROF_COUNT):
         ms, cnt = eng.profile_read(kk)
@@ -695,6 +699,8 @@ def run_rank(args, ctx, inp):
         ekf_name = "ekf_paged_kernel"
     elif forms[2] + forms[3] > forms[0] + forms[1]:
         ekf_name = "ekf_sparse_kernel" if forms[3] > forms[2] else "ekf_update_kernel (in place)"
+    elif fused_n > forms[1] // 2:
+        ekf_name = "frame_front_kernel"   # motion + score and the grouped landmark update in one launch
     else:
         ekf_name = "ekf_update_group_kernel" if forms[1] > forms[0] else "ekf_update_kernel"
     if ekf_n and (ekf_ms / ekf_n >= score_ms / max(score_n, 1) or args.mode == "ekf"):
@@ -715,14 +721,14 @@ def run_rank(args, ctx, inp):
     if traffic and dur_ms > 0:
         achieved, a_kernel = traffic / (dur_ms * 1e-3) / 1e9, kern
         basis = f"hbm_traffic (PMC record of this workload and kernel, {traffic_src}) / this run's launch time"
-    elif kern.startswith("ekf_update") and no_reuse and args.mode == "pf":
+    elif (kern.startswith("ekf_update") or kern.startswith("frame_front")) and no_reuse and args.mode == "pf":
         achieved, a_kernel = no_reuse["achieved"], no_reuse["kernel"]
         basis = "no_reuse sweep (no PMC record for this workload and kernel): HBM bytes of a launch without shared rows / its launch time"
     else:
         achieved, a_kernel, basis = logical, kern, "algorithmic bytes / launch time in the timed region"
     if no_reuse:
         ro_frac, ro_basis = no_reuse["read_only_frac"], "no-reuse sweep"
-    elif kern.startswith("ekf") and dur_ms > 0:
+    elif (kern.startswith("ekf") or kern.startswith("frame_front")) and dur_ms > 0:
         ro_frac, ro_basis = 20 * n * L_obs / (dur_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "in-filter launches of the timed region"
     else:
         ro_frac, ro_basis = None, None
@@ -756,16 +762,22 @@ def run_rank(args, ctx, inp):
                               "registers: `logical_rate_gbs` (SURVEY 8d's 40 B per particle and observed landmark / launch time) is "
                               "then not an HBM rate; `achieved` is one, see `achieved_basis` / `achieved_kernel`; `no_reuse` is the "
                               "row kernel streaming every row from HBM" if kern.startswith("ekf_update") else
+                              "ONE launch holds the frame's motion sample + scan-match score (scoring workgroups: gathers out of L2) and "
+                              "its landmark update (grouped row kernel: HBM writes), interleaved; `avg_launch_ms` is that launch, "
+                              "`algorithmic_bytes_per_launch` the update's 40 B per particle and observed landmark; `stage_avg_ms` has "
+                              "the two as separate launches (slam_frame_fusion_set(0)); `no_reuse` is the row kernel alone streaming "
+                              "every row from HBM" if kern.startswith("frame_front") else
                               "paged maps: the update reads the touched pages of the ancestors (shared pages out of L2) and writes "
                               "fresh pages; `logical_rate_gbs` is SURVEY 8d's 40 B per particle and observed landmark / launch time"
                               if kern.startswith("ekf") else
                               "EDT gathers are served by L2 / Infinity Cache: logical-byte rate, not HBM traffic"),
                      "avg_launch_ms": dur_ms, "avg_event_bracket_ms": raw_ms,
                      "event_bracket_overhead_ms": bracket_overhead_ms,
-                     "launches": int(ekf_n if kern.startswith("ekf") else score_n),
+                     "launches": int(score_n if kern.startswith("score") else ekf_n),
                      "event_sampling": f"HIP-event bracket in every {every}{'st' if every == 1 else 'th'} frame of the timed region "
                                        f"({args.steps} frames); a bracket idles the stream ~12 us",
-                     "ekf_launches_by_kernel": {"ekf_update_kernel": forms[0], "ekf_update_group_kernel": forms[1],
+                     "ekf_launches_by_kernel": {"ekf_update_kernel": forms[0], "ekf_update_group_kernel": forms[1] - fused_n,
+                                                "frame_front_kernel (score + grouped update)": fused_n,
                                                 "ekf_update_kernel(in place)": forms[2], "ekf_sparse_kernel": forms[3]},
                      "other_kernel_avg_ms": {"score_poses_kernel": kernel_ms(score_ms, score_n),
                                              ekf_name: kernel_ms(ekf_ms, ekf_n)}},
@@ -906,8 +918,8 @@ def free_port():
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=200, help="timed frames (SURVEY 8d: 200 timed frames after 20 warm-up)")
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--mode", choices=["pf", "score", "ekf"], default="pf")
     ap.add_argument("--particles", type=int, default=65536, help="per GPU (weak scaling, the default)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",

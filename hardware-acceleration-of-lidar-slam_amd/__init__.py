@@ -108,6 +108,8 @@ SIGNATURES = {
     "slam_exchange_set_capacity": (_i, [_vp, _i]),
     "slam_ekf_form_set": (_i, [_vp, _i]),
     "slam_ekf_form_counts": (_i, [_vp, _vp]),
+    "slam_frame_fusion_set": (_i, [_vp, _i]),
+    "slam_frame_fusion_count": (_i, [_vp, _vp]),
     "slam_ekf_inplace_form_set": (_i, [_vp, _i]),
     "slam_pf_paged_set": (_i, [_vp, _i]),
     "slam_pf_is_paged": (_i, [_vp]),
@@ -406,6 +408,15 @@ class Engine:
         c = (C.c_int64 * 2)()
         self._ck(self.lib.slam_ekf_form_counts(self.h, c), "ekf_form_counts")
         return int(c[0]), int(c[1])
+
+    def frame_fusion_set(self, on: bool):
+        """The front of a single-GPU frame on rows (motion + score and the landmark update) as one launch (default) or two."""
+        self._ck(self.lib.slam_frame_fusion_set(self.h, 1 if on else 0), "frame_fusion_set")
+
+    def frame_fusion_count(self) -> int:
+        c = C.c_int64(0)
+        self._ck(self.lib.slam_frame_fusion_count(self.h, C.byref(c)), "frame_fusion_count")
+        return int(c.value)
 
     def pf_paged_set(self, on: bool):
         """Sessions made from now on keep their maps as copy-on-write pages (one GPU; same results as rows)."""

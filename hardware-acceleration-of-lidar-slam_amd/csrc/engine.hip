@@ -757,6 +757,73 @@ int slam_ekf_update_dev(slam_engine* e, const float* d_map_in, float* d_map_out,
     return SLAM_OK;
 }
 
+int slam_frame_front_dev(slam_engine* e, int slot, const float* d_src_x, const float* d_src_y, const float* d_src_th,
+                         const int32_t* d_anc, float* d_x, float* d_y, float* d_th, int n, int64_t first_id, const float dp[3],
+                         const float sigma[3], uint64_t seed, uint32_t frame, float* d_score, int32_t* d_count,
+                         const float* d_map_in, float* d_map_out, int64_t row_stride, int plane_stride, int nlandmarks,
+                         float meas_var, bool* launched)
+{
+    ENTER(e);
+    *launched = false;
+    static const int env_fusion = getenv("SLAM_FRAME_FUSION") ? atoi(getenv("SLAM_FRAME_FUSION")) : -1;
+    if (!(env_fusion >= 0 ? env_fusion != 0 : e->frame_fusion)) return SLAM_OK;
+    // the checks of slam_motion_score_dev and of slam_ekf_update_dev (out of place)
+    if (n <= 0 || first_id < 0 || !dp || !sigma || !d_src_x || !d_src_y || !d_src_th || !d_x || !d_y || !d_th || !d_score ||
+        !d_count || !d_anc || !d_map_in || !d_map_out || d_map_in == d_map_out)
+        return SLAM_OK;   // the two calls will say what is wrong
+    if (d_src_x == d_x || d_src_y == d_y || d_src_th == d_th) return SLAM_ERR_INVALID_ARG;
+    if (nlandmarks <= 128 || plane_stride < nlandmarks || row_stride < 5 * (int64_t)plane_stride || !(meas_var > 0.0f))
+        return SLAM_OK;
+    if (int rc = check_score_inputs(e, slot)) return rc;
+    if (e->obs_nlandmarks < 0 || e->obs_nlandmarks != nlandmarks) return SLAM_ERR_NOT_READY;
+    const int group = e->ekf_group_size(n, true);
+    if (!frame_front_fits(n, nlandmarks, group)) return SLAM_OK;
+    HIP_TRY(e->ll_buf.ensure(sizeof(float) * (size_t)n));
+    EkfArgs a;
+    a.map_in = d_map_in;
+    a.map_out = d_map_out;
+    a.row_stride = row_stride;
+    a.plane_stride = plane_stride;
+    a.nlandmarks = nlandmarks;
+    a.x = d_x;   // not read by the fused launch: the update works out its motion samples itself
+    a.y = d_y;
+    a.th = d_th;
+    a.anc = d_anc;
+    a.n = n;
+    a.obs_zx = e->d_obs_zx;
+    a.obs_zy = e->d_obs_zy;
+    a.meas_var = meas_var;
+    a.loglik = e->ll_buf.as<float>();
+    a.loglik_user = nullptr;
+    a.xcd_chunk = 0;
+    MotionIO io{ d_src_x, d_src_y, d_src_th, d_anc, d_x, d_y, d_th };
+    // one bracket for the whole launch: it counts as the frame's landmark update (the dominant stage)
+    HIP_TRY(launch_frame_front(e->stream, score_grid(e->grid[slot]), e->d_bx, e->d_by, e->nbeams, io, first_id, dp, sigma, seed,
+                               frame, d_score, d_count, a, group, e->prof_next(SLAM_PROF_EKF), launched));
+    if (*launched) {
+        e->ll_n = n;
+        e->ekf_form_launches[1]++;
+        e->front_launches++;
+    }
+    return SLAM_OK;
+}
+
+int slam_frame_fusion_set(slam_engine* e, int on)
+{
+    ENTER(e);
+    if (on < 0 || on > 1) return SLAM_ERR_INVALID_ARG;
+    e->frame_fusion = on != 0;
+    return SLAM_OK;
+}
+
+int slam_frame_fusion_count(slam_engine* e, int64_t* launches)
+{
+    ENTER(e);
+    if (!launches) return SLAM_ERR_INVALID_ARG;
+    *launches = e->front_launches;
+    return SLAM_OK;
+}
+
 int slam_ekf_form_set(slam_engine* e, int form)
 {
     ENTER(e);

@@ -132,6 +132,8 @@ struct slam_engine {
     // 10-50 ms later (profiles/r03_stall_trigger.txt) — a session that came and went would stall the frames of the next one.
     void* h_pf_res = nullptr;
     void* d_hpf_res = nullptr;
+    bool frame_fusion = true;       // slam_frame_fusion_set
+    int64_t front_launches = 0;
     int ekf_inplace_form = -1;   // slam_ekf_inplace_form_set: -1 by the feedback, 0 whole rows, 1 observed landmarks only
     int64_t ekf_inplace_launches[2] = { 0, 0 };
     slam_comm* comm = nullptr; // the communicator made on this engine, if any: host-side waits poll it for failures
@@ -217,6 +219,14 @@ struct ProfScope {
 };
 
 // helpers implemented in engine.hip
+// slam_motion_score_dev + slam_ekf_update_dev (out of place, through the resample indices d_anc) as ONE launch
+// (launch_frame_front).  *launched = false: the shapes do not fit or fusion is off — nothing was issued, the caller makes
+// the two calls.  Used by the slam_pf session for single-GPU frames on rows.
+extern "C" int slam_frame_front_dev(slam_engine* e, int slot, const float* d_src_x, const float* d_src_y, const float* d_src_th,
+                         const int32_t* d_anc, float* d_x, float* d_y, float* d_th, int n, int64_t first_id, const float dp[3],
+                         const float sigma[3], uint64_t seed, uint32_t frame, float* d_score, int32_t* d_count,
+                         const float* d_map_in, float* d_map_out, int64_t row_stride, int plane_stride, int nlandmarks,
+                         float meas_var, bool* launched);
 int slam_engine_fail_hip(slam_engine* e, hipError_t err, const char* what);
 slam::ScoreGrid slam_engine_score_grid(const slam_engine* e, int slot);
 // FastMatch on grid `slot` with the beam count read from device memory (d_nbeams, at most nbeams_max) and the

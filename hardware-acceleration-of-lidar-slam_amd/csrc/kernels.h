@@ -91,6 +91,15 @@ struct EkfArgs {
 // group_size: 0 = one wavefront per particle; 2 / 4 / 8 = the grouped out-of-place form (that many neighbouring particles
 // per wavefront share their source rows in registers) — a speed choice only, every form gives the same bits
 hipError_t launch_ekf_update(hipStream_t stream, const EkfArgs& a, const EventPair* ev = nullptr, int group_size = 0);
+// motion sample + scan-match score AND the grouped out-of-place landmark update in ONE launch (single-GPU frames on rows): the
+// gathers of the scorer run in the shadow of the update's row stores.  `a.x / a.y / a.th` are not read (the update works out
+// its particles' motion samples itself, the same bits the scorer writes to io.x / io.y / io.th).  *launched = false: shapes
+// that this kernel does not take; nothing was issued.
+bool frame_front_fits(int n, int nlandmarks, int group_size);   // the shapes launch_frame_front takes
+hipError_t launch_frame_front(hipStream_t stream, const ScoreGrid& g, const float* bx, const float* by, int nbeams,
+                              const MotionIO& io, int64_t first_id, const float dp[3], const float sigma[3], uint64_t seed,
+                              uint32_t frame, float* score, int32_t* count, const EkfArgs& a, int group_size,
+                              const EventPair* ev, bool* launched);
 
 // carry / prev_resampled (optional): see logweight_kernel — the weights a frame without resample left behind
 // In-place update of the OBSERVED landmarks only (frames that keep their population): the observation table is first

@@ -16,6 +16,7 @@
 
 #include "det_math.h"
 #include "ekf_math.h"
+#include "score_body.h"
 #include "kernels.h"
 
 namespace slam {
@@ -312,24 +313,37 @@ __device__ __forceinline__ float lane_value(float v, int k)   // lane k's value,
 #ifndef EKF_GROUP_WPE
 #define EKF_GROUP_WPE 6
 #endif
+// EKF_GROUP_NB: batches of 128 landmarks a wavefront of the grouped kernels holds in registers per pass (measurement builds)
+#ifndef EKF_GROUP_NB
+#define EKF_GROUP_NB 2
+#endif
 #define EKF_GROUP_ATTR __attribute__((amdgpu_waves_per_eu(EKF_GROUP_WPE, EKF_GROUP_WPE)))
-template <int NB, int G>
-__global__ __launch_bounds__(kEkfWaves * 64) EKF_GROUP_ATTR void ekf_update_group_kernel(EkfArgs a)
+// `bid`: the workgroup's index after the XCD-contiguous renumbering; s_acc: per particle of the group the 128 accumulators of
+// the specification.  OWN_MOTION (the fused front kernel of a frame, below): the poses are not read from a.x / a.y / a.th but
+// worked out here — pose = motion_sample(source pose of the ancestor), the very computation the scoring workgroups of the
+// same launch make for the same particle (Philox is counter-based: the same bits) — so that the update waits for nobody.
+template <int NB, int G, bool OWN_MOTION>
+__device__ __forceinline__ void ekf_group_body(const EkfArgs& a, int bid, float (*s_acc)[G][128], const MotionIO& mio,
+                                               const MotionParams& mpar)
 {
-    __shared__ float s_acc[kEkfWaves][G][128];   // per particle of the group: the 128 accumulators of the specification
     const unsigned lane = threadIdx.x & 63u;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    int bid = blockIdx.x;
-    if (a.xcd_chunk > 0) bid = (bid & 7) * a.xcd_chunk + (bid >> 3);   // each XCD a contiguous eighth (see ekf_update_kernel)
     const int g0 = (bid * kEkfWaves + wave) * G;
     if (g0 >= a.n) return;
     const int nslots = a.n - g0 < G ? a.n - g0 : G;
     // lane k prepares particle g0 + k: its source row and the trig of its heading; read back with v_readlane below
     const int mine = g0 + ((int)lane < nslots ? (int)lane : 0);
     const int src_l = a.anc ? a.anc[mine] : mine;
-    float st_l, ct_l;
-    det_sincosf(a.th[mine], st_l, ct_l);
-    const float px_l = a.x[mine], py_l = a.y[mine];
+    float st_l, ct_l, px_l, py_l;
+    if constexpr (OWN_MOTION) {
+        float th_l;
+        motion_sample_one(mpar, (uint64_t)mine, mio.sx[src_l], mio.sy[src_l], mio.sth[src_l], px_l, py_l, th_l);
+        det_sincosf(th_l, st_l, ct_l);
+    } else {
+        det_sincosf(a.th[mine], st_l, ct_l);
+        px_l = a.x[mine];
+        py_l = a.y[mine];
+    }
 #pragma unroll
     for (int k = 0; k < G; ++k) {
         s_acc[wave][k][lane] = 0.0f;
@@ -414,6 +428,57 @@ __global__ __launch_bounds__(kEkfWaves * 64) EKF_GROUP_ATTR void ekf_update_grou
             a.loglik[i] = total;
             if (a.loglik_user) a.loglik_user[i] = total;
         }
+    }
+}
+
+template <int NB, int G>
+__global__ __launch_bounds__(kEkfWaves * 64) EKF_GROUP_ATTR void ekf_update_group_kernel(EkfArgs a)
+{
+    __shared__ float s_acc[kEkfWaves][G][128];
+    int bid = blockIdx.x;
+    if (a.xcd_chunk > 0) bid = (bid & 7) * a.xcd_chunk + (bid >> 3);   // each XCD a contiguous eighth (see ekf_update_kernel)
+    ekf_group_body<NB, G, false>(a, bid, s_acc, MotionIO{}, MotionParams{});
+}
+
+// ---- the FRONT of a single-GPU frame in one launch: motion sample + scan-match score (score_body.h) and the grouped
+// out-of-place landmark update side by side.  The two are bound by different units — the scorer by the texture addresser
+// (gathers out of L2), the update by HBM writes — and neither needs the other's output: both start from the resample
+// indices and the previous poses (the update works out its particles' motion samples itself).  As two launches they run one
+// after the other (a second stream with an event fork and join costs more than it wins: DESIGN.md section 11.4); here the
+// workgroups of both kinds are dealt out interleaved — of every `score_octets + ekf_octets` consecutive octets of workgroups
+// (an octet = one workgroup per XCD) the scoring ones are spread evenly — so the gathers run in the shadow of the row
+// stores.  Same bits as the two launches (same device functions).
+struct FrontArgs {
+    ScoreGrid g;
+    const float *bx, *by;
+    int nbeams;
+    float* score;
+    int32_t* count;
+    MotionIO mio;
+    MotionParams mpar;
+    EkfArgs a;
+    int score_blocks;    // 256-thread slices of poses to score
+    int score_octets;    // ceil(score_blocks / 8)
+    int ekf_octets;      // update workgroups per XCD (the xcd_chunk of ekf_update_group_kernel)
+};
+
+template <int NB, int G, int LPP, int DEPTH>
+__global__ __launch_bounds__(kEkfWaves * 64) EKF_GROUP_ATTR void frame_front_kernel(FrontArgs f)
+{
+    static_assert(kScoreBlock == kEkfWaves * 64, "both kinds of workgroup have 256 threads");
+    extern __shared__ float4 s_pair[];
+    __shared__ float s_acc[kEkfWaves][G][128];
+    const int o = (int)blockIdx.x >> 3, xcd = (int)blockIdx.x & 7;
+    const int64_t total = (int64_t)f.score_octets + f.ekf_octets;
+    const int before = (int)((int64_t)o * f.score_octets / total);          // scoring octets among octets 0 .. o - 1
+    const int upto = (int)((int64_t)(o + 1) * f.score_octets / total);      // ... among 0 .. o
+    if (upto > before) {   // a scoring octet (wave-uniform, workgroup-uniform)
+        const int sb = before * 8 + xcd;
+        if (sb >= f.score_blocks) return;
+        score_poses_body<false, LPP, DEPTH, true>(f.g, f.bx, f.by, f.nbeams, f.mio.x, f.mio.y, f.mio.th, nullptr, f.a.n, f.score,
+                                                  f.count, f.mio, f.mpar, sb, s_pair);
+    } else {
+        ekf_group_body<NB, G, true>(f.a, xcd * f.ekf_octets + (o - before), s_acc, f.mio, f.mpar);
     }
 }
 
@@ -1574,9 +1639,9 @@ hipError_t launch_ekf_update(hipStream_t stream, const EkfArgs& a_in, const Even
         }
         if (ev) (void)hipEventRecord(ev->start, stream);
         switch (G) {
-        case 2: ekf_update_group_kernel<2, 2><<<gblocks, kEkfWaves * 64, 0, stream>>>(a); break;
-        case 8: ekf_update_group_kernel<2, 8><<<gblocks, kEkfWaves * 64, 0, stream>>>(a); break;
-        default: ekf_update_group_kernel<2, 4><<<gblocks, kEkfWaves * 64, 0, stream>>>(a); break;
+        case 2: ekf_update_group_kernel<EKF_GROUP_NB, 2><<<gblocks, kEkfWaves * 64, 0, stream>>>(a); break;
+        case 8: ekf_update_group_kernel<EKF_GROUP_NB, 8><<<gblocks, kEkfWaves * 64, 0, stream>>>(a); break;
+        default: ekf_update_group_kernel<EKF_GROUP_NB, 4><<<gblocks, kEkfWaves * 64, 0, stream>>>(a); break;
         }
         if (ev) (void)hipEventRecord(ev->stop, stream);
         return hipGetLastError();
@@ -1591,6 +1656,57 @@ hipError_t launch_ekf_update(hipStream_t stream, const EkfArgs& a_in, const Even
     else if (nb == 1) ekf_update_kernel<1, true><<<blocks, kEkfWaves * 64, 0, stream>>>(a);
     else ekf_update_kernel<2, true><<<blocks, kEkfWaves * 64, 0, stream>>>(a);
     if (ev) (void)hipEventRecord(ev->stop, stream);
+    return hipGetLastError();
+}
+
+bool frame_front_fits(int n, int nlandmarks, int group_size)
+{
+    static const int wave_max = getenv("SLAM_SCORE_WAVE_MAX") ? atoi(getenv("SLAM_SCORE_WAVE_MAX")) : kWaveMaxPoses;
+    if (n < wave_max || nlandmarks <= 128 || (group_size != 2 && group_size != 4)) return false;
+    return (n + kEkfWaves * group_size - 1) / (kEkfWaves * group_size) >= 64;
+}
+
+// The front of a single-GPU frame in one launch (frame_front_kernel).  *launched = false when the shapes do not fit it (few
+// particles: the one-wavefront-per-pose scorer; short rows; too few update workgroups for the XCD-contiguous numbering): the
+// caller then issues the two launches.
+hipError_t launch_frame_front(hipStream_t stream, const ScoreGrid& g, const float* bx, const float* by, int nbeams,
+                              const MotionIO& io, int64_t first_id, const float dp[3], const float sigma[3], uint64_t seed,
+                              uint32_t frame, float* score, int32_t* count, const EkfArgs& a_in, int group_size,
+                              const EventPair* ev, bool* launched)
+{
+    *launched = false;
+    const int n = a_in.n;
+    static const int quad_max = getenv("SLAM_SCORE_QUAD_MAX") ? atoi(getenv("SLAM_SCORE_QUAD_MAX")) : kQuadMaxPoses;
+    if (a_in.map_in == a_in.map_out || !frame_front_fits(n, a_in.nlandmarks, group_size)) return hipSuccess;
+    const int G = group_size;
+    const int gblocks = (n + kEkfWaves * G - 1) / (kEkfWaves * G);
+    const bool quad = n < quad_max;
+    FrontArgs f;
+    f.g = g;
+    f.bx = bx;
+    f.by = by;
+    f.nbeams = nbeams;
+    f.score = score;
+    f.count = count;
+    f.mio = io;
+    f.mpar = make_motion_params(first_id, dp, sigma, seed, frame);
+    f.a = a_in;
+    f.ekf_octets = (gblocks + 7) / 8;
+    f.a.xcd_chunk = f.ekf_octets;
+    f.score_blocks = (int)(((quad ? 4L : 1L) * n + kScoreBlock - 1) / kScoreBlock);
+    f.score_octets = (f.score_blocks + 7) / 8;
+    const int grid = 8 * (f.score_octets + f.ekf_octets);
+    const size_t lds = sizeof(float2) * (size_t)(nbeams + (quad ? 4 * kQuadDepth : kLaneDepth));
+    if (ev) (void)hipEventRecord(ev->start, stream);
+    if (quad) {
+        if (G == 2) frame_front_kernel<EKF_GROUP_NB, 2, 4, kQuadDepth><<<grid, kEkfWaves * 64, lds, stream>>>(f);
+        else frame_front_kernel<EKF_GROUP_NB, 4, 4, kQuadDepth><<<grid, kEkfWaves * 64, lds, stream>>>(f);
+    } else {
+        if (G == 2) frame_front_kernel<EKF_GROUP_NB, 2, 1, kLaneDepth><<<grid, kEkfWaves * 64, lds, stream>>>(f);
+        else frame_front_kernel<EKF_GROUP_NB, 4, 1, kLaneDepth><<<grid, kEkfWaves * 64, lds, stream>>>(f);
+    }
+    if (ev) (void)hipEventRecord(ev->stop, stream);
+    *launched = true;
     return hipGetLastError();
 }
 

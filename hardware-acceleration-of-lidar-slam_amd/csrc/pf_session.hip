@@ -598,10 +598,22 @@ static int pf_step_impl(slam_pf* pf, int slot, const float dp[3], int use_observ
     const int32_t* anc = pf->has_anc ? pf->anc[cur] : nullptr;
     const int64_t first_id = (int64_t)pf->rank * n;
     int rc;
+    // 1 + 2 + 3 in ONE launch when the frame allows it (a single-GPU session on rows that resamples every frame, landmarks
+    // observed, long rows, enough particles): motion sample + scan-match score and the out-of-place landmark update side by
+    // side, the scorer's gathers in the shadow of the update's row stores (slam_frame_front_dev; the same bits)
+    bool fused = false;
+    if (!comm && !pf->paged && !pf->gated && anc && L > 0 && use_observations && e->obs_nlandmarks == L) {
+        rc = slam_frame_front_dev(e, slot, src, src + sn, src + 2 * sn, anc, dst, dst + sn, dst + 2 * sn, n, first_id, dp,
+                                  pf->cfg.sigma, pf->cfg.seed, pf->frame, pf->score, pf->count, pf->map[pf->map_cur],
+                                  pf->map[1 - pf->map_cur], 5 * (int64_t)pf->Lp, pf->Lp, L, pf->cfg.meas_var, &fused);
+        if (rc != SLAM_OK) return rc;
+    }
     // 1 + 2. motion (+ the fused gather of the previous resample) and scan-match score, one launch.  Sharded: the
     // ancestors' poses come out of the array of every rank's poses, so this launch needs nothing from the exchange
     // below and keeps the GPU busy while the host picks up the exchange plan.
-    if (comm && pf->has_anc) {
+    if (fused) {
+        rc = SLAM_OK;
+    } else if (comm && pf->has_anc) {
         if ((rc = comm_all_gather_finish(comm)) != SLAM_OK) return rc;
         const float* pa = pf->pose_all;
         rc = slam_motion_score_dev(e, slot, pa, pa + sn, pa + 2 * sn, pf->pose_idx[cur], dst, dst + sn, dst + 2 * sn, n,
@@ -713,8 +725,9 @@ static int pf_step_impl(slam_pf* pf, int slot, const float dp[3], int use_observ
         rc = slam_logweight_ekf_dev(e, pf->score, pf->cfg.score_gain, n, pf->logw, d_max);
     } else if (ekf) {
         if (sample_obs) SLAM_HIP_TRY(e, launch_obs_count(e->stream, e->d_obs_zx, e->d_obs_zy, L, d_hobs, ++pf->obs_seq_issued, pf->votes));
-        rc = slam_ekf_update_dev(e, pf->map[mc], pf->map[mn], 5 * (int64_t)pf->Lp, pf->Lp, L, dst, dst + sn, dst + 2 * sn, anc, n,
-                                 pf->cfg.meas_var, nullptr);
+        rc = fused ? SLAM_OK   // the update went out with the score
+                   : slam_ekf_update_dev(e, pf->map[mc], pf->map[mn], 5 * (int64_t)pf->Lp, pf->Lp, L, dst, dst + sn, dst + 2 * sn, anc,
+                                         n, pf->cfg.meas_var, nullptr);
         if (rc != SLAM_OK) return rc;
         pf->map_cur = mn;
         rc = slam_logweight_ekf_dev(e, pf->score, pf->cfg.score_gain, n, pf->logw, d_max);

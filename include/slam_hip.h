@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define SLAM_ABI_VERSION 3
+#define SLAM_ABI_VERSION 4
 
 typedef enum {
     SLAM_OK = 0,
@@ -238,8 +238,17 @@ int slam_ekf_update_dev(slam_engine *e, const float *d_map_in, float *d_map_out,
  * first kernel, 1 / 2 the second with 4 / 2 particles per wavefront (tests, measurements; the environment variable
  * SLAM_EKF_GROUP overrides). */
 int slam_ekf_form_set(slam_engine *e, int form);
-/* out-of-place EKF launches of this engine so far: counts[0] one wavefront per particle, counts[1] the grouped kernel */
+/* out-of-place EKF launches of this engine so far: counts[0] one wavefront per particle, counts[1] the grouped kernel
+ * (by itself or inside the fused front launch below) */
 int slam_ekf_form_counts(slam_engine *e, int64_t counts[2]);
+/* The FRONT of a frame of a single-GPU slam_pf session on rows — motion sample + scan-match score (FastMatch's inner loop,
+ * main.c:459-518, for every particle) and the out-of-place landmark update — goes out as ONE launch whose scoring and
+ * updating workgroups are dealt out interleaved: the scorer's gathers (texture addresser, L2) run in the shadow of the
+ * update's row stores (HBM).  Same bits as the two launches.  on = 1 (the initial state) / 0: two launches (stage timers,
+ * measurements; the environment variable SLAM_FRAME_FUSION overrides).  Sharded, gated and paged sessions, short rows and
+ * small populations always take the two launches.  slam_frame_fusion_count: fused launches of this engine so far. */
+int slam_frame_fusion_set(slam_engine *e, int on);
+int slam_frame_fusion_count(slam_engine *e, int64_t *launches);
 /* The in-place update (d_map_in == d_map_out: frames that keep their population, slam_resample_gate_set) also has two
  * kernels with the SAME bits: whole rows in batches of 128 landmarks, and the observed landmarks only, from a list
  * the engine compacts out of the observation table once per table (nlandmarks <= 65536).  form = -1 (initial): the

@@ -30,7 +30,8 @@ Lp = (L + 31) // 32 * 32
 def counter(mode, name):
     f = max(glob.glob(str(src / f"{tag}_pmc_{name}_{mode}" / "*" / "*counter_collection.csv")), key=os.path.getmtime)   # the newest run
     # both out-of-place kernels (ekf_update_kernel / ekf_update_group_kernel) count as "the EKF kernel"
-    rows = [r for r in csv.DictReader(open(f)) if "ekf_update_" in r["Kernel_Name"] and r["Counter_Name"] == name]
+    rows = [r for r in csv.DictReader(open(f)) if ("ekf_update_" in r["Kernel_Name"] or "frame_front_kernel" in r["Kernel_Name"])
+            and r["Counter_Name"] == name]
     global last_kernel
     names = [r["Kernel_Name"].replace("void slam::", "").replace("slam::", "").replace("(anonymous namespace)::", "").split("(")[0]
              for r in rows[4:10]]

@@ -17,7 +17,7 @@ for d in sorted(glob.glob(str(src / f"{tag}_ekfpmc_*"))):
     fs = glob.glob(d + "/*/*counter_collection.csv")
     if not fs:
         continue
-    rows = [r for r in csv.DictReader(open(max(fs, key=os.path.getmtime))) if "ekf_update" in r["Kernel_Name"]]
+    rows = [r for r in csv.DictReader(open(max(fs, key=os.path.getmtime))) if "ekf_update" in r["Kernel_Name"] or "frame_front_kernel" in r["Kernel_Name"]]
     for r in rows:
         vals[r["Counter_Name"]].append(float(r["Counter_Value"]))
         kern = r["Kernel_Name"].replace("void slam::", "").replace("slam::", "").replace("(anonymous namespace)::", "").split("(")[0]

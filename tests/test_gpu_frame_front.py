@@ -1,0 +1,71 @@
+"""The front of a single-GPU frame on rows as ONE launch (frame_front_kernel: motion sample + scan-match score and the grouped
+out-of-place landmark update, interleaved workgroups) against the two launches it replaces: the same bits — poses, scores'
+consequences (weights -> resample indices -> heaviest particle), maps — frame after frame, for both lane mappings of the
+scorer (4 lanes per pose below 131 072 particles, 1 above) and both group sizes of the update.  The two-launch path is the one
+the rest of the suite pins against the CPU specification (tests/test_gpu_pf.py, test_gpu_configs.py run fused by default
+wherever the shapes fit, so both are checked there as well)."""
+import numpy as np
+import pytest
+import torch
+
+from __graft_entry__ import load_package
+from conftest import bits
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda", 0)
+
+
+def _run(fused, n, L, frames, form=-1):
+    import _shard_worker as W
+
+    pkg = load_package()
+    meta, edt, bx, by, lm = W.make_world(L=L)
+    x, y, th, mp = W.init_state(n, L, lm)
+    eng = pkg.Engine(0)
+    eng.frame_fusion_set(fused)
+    eng.ekf_form_set(form)
+    eng.grid_set_dev(0, torch.from_numpy(edt).to(DEV), pkg.grid_meta(meta.rows, meta.cols, meta.ld, meta.pixel, meta.min_x, meta.min_y))
+    eng.scan_upload(bx, by)
+    ses = pkg.PfSession(eng, n, L, seed=91, sigma=(0.02, 0.02, 0.004), meas_var=0.02, score_gain=0.05, map_layout="rows")
+    ses.set_poses(x, y, th)
+    ses.set_map(mp)
+    del mp
+    out = {"best": [], "maps": {}}
+    rng = np.random.default_rng(5)
+    for f in range(frames):
+        ids = np.sort(rng.choice(L, size=(L if f % 3 else max(L // 3, 1)), replace=False)).astype(np.int32)   # all, or a third
+        z = lm[ids] + np.float32(0.01) * np.float32(f % 5)
+        eng.obs_upload(ids, z[:, 0].copy(), z[:, 1].copy(), L)
+        ses.step(0, [0.01, -0.005, 0.002], True)
+        out["best"].append(ses.best())
+        if f in (1, frames - 1):
+            sel = np.unique(np.concatenate([np.arange(0, n, max(n // 257, 1)), [n - 1]])).astype(np.int32)
+            out["maps"][f] = ses.map_rows(sel) if hasattr(ses, "map_rows") else ses.maps()[sel]
+    out["pose"] = ses.poses()
+    out["fused_launches"] = eng.frame_fusion_count()
+    out["forms"] = eng.ekf_form_counts()
+    ses.close()
+    eng.close()
+    return out
+
+
+@pytest.mark.parametrize("n,L,form", [(16384, 300, -1), (16384, 300, 2), (16384, 300, 1), (5000, 513, -1), (140000, 200, -1)])
+def test_fused_front_gives_the_bits_of_the_two_launches(n, L, form):
+    frames = 7
+    two = _run(False, n, L, frames, form)
+    one = _run(True, n, L, frames, form)
+    assert two["fused_launches"] == 0
+    assert one["fused_launches"] == frames - 1, one["fused_launches"]   # the first frame has no resample indices yet
+    assert np.array_equal(bits(one["pose"]), bits(two["pose"]))
+    for f, m in two["maps"].items():
+        assert np.array_equal(bits(one["maps"][f]), bits(m)), f
+    for a, b in zip(one["best"], two["best"]):
+        assert a[2] == b[2] and a[1] == b[1] and np.array_equal(bits(a[0]), bits(b[0]))
+
+
+def test_shapes_the_fused_front_does_not_take():
+    """Short rows (<= 128 landmarks), few particles (the one-wavefront-per-pose scorer) and the one-wavefront-per-particle
+    update (ekf form 0) keep the two launches."""
+    assert _run(True, 4096, 100, 4)["fused_launches"] == 0
+    assert _run(True, 2048, 300, 4)["fused_launches"] == 0
+    assert _run(True, 16384, 300, 4, form=0)["fused_launches"] == 0
