@@ -156,6 +156,11 @@ def make_landmarks(L, rng):
     return lm
 
 
+def preroll_frames(args):
+    """Frames the filter runs (untimed) before the W warm-up steps, so that the timed steps see a filter in steady state."""
+    return max(0, args.preroll) if args.mode == "pf" else 0
+
+
 def build_inputs(args):
     """Everything synthetic, as numpy (identical on every rank; made once per process)."""
     rng = np.random.default_rng(4321)
@@ -164,7 +169,7 @@ def build_inputs(args):
     pixel = np.float32(20.48 / args.grid)
     min_x, min_y = np.float32(-4.24), np.float32(-10.24)
     occ = occupancy(args.grid, float(pixel), float(min_x), float(min_y))
-    nframes = args.steps + args.warmup + 12   # + the short per-stage timing pass after the timed region
+    nframes = preroll_frames(args) + args.steps + args.warmup + 12   # + the short per-stage timing pass after the timed region
     frames = make_frames(nframes, args.beams, landmarks, rng, args.observed)
     return dict(L=L, landmarks=landmarks, pixel=pixel, min_x=min_x, min_y=min_y, occ=occ, frames=frames)
 
@@ -460,14 +465,17 @@ class ThreadCtx:
 
 
 # ------------------------------------------------------------------------------------------------ one rank
-def settle(torch, seconds=0.25):
+SETTLE_S = 0.25
+
+
+def settle(torch, seconds=None):
     """Between set-up (engine and session creation, allocations) and the first frame: drain the device and let the host
     sleep.  The driver answers an allocation of pinned host memory (hipHostMalloc: the engine makes a few when it is
     created) some 10-50 ms later by holding the process's queues for 65-80 ms — stage timers normal, host issue times
     normal, the stream simply stands still (profiles/r03_stall_trigger.txt, r03_stall_frames.txt, DESIGN.md section 8);
     without the pause that can land in the frames that follow."""
     torch.cuda.synchronize()
-    time.sleep(seconds)
+    time.sleep(SETTLE_S if seconds is None else seconds)
 
 
 def fill_maps(torch, m0, landmarks, L, dev, n):
@@ -562,7 +570,10 @@ def run_rank(args, ctx, inp):
 
     sweep = {}
 
+    off = preroll_frames(args)   # frames[0 .. off) are the pre-roll: step k of the bench is frame off + k
+
     def one_step(k):
+        k += off
         fr = frames[k]
         if args.host_sensor:
             eng.scan_upload(fr["bx"], fr["by"])
@@ -592,6 +603,13 @@ def run_rank(args, ctx, inp):
                                MEAS_VAR, loglik_t)
 
     settle(torch)
+    # Pre-roll: the filter starts from poses spread 5 cm / 0.01 rad around the truth and needs on the order of a
+    # hundred frames to settle to the spread its motion noise and its observations sustain; until then neighbouring particles
+    # lie farther apart, the scorer's gathers of a wavefront fall into more cache lines and a frame takes up to 20 % longer
+    # (front kernel 193 us at frame 3, 175 at 40, 160 at 90, 155 at 140: profiles/r03_early_frames.md).  The metric is a
+    # steady-state rate, so these frames run before the W warm-up steps, untimed; --preroll 0 starts cold.
+    for k in range(-off, 0):
+        one_step(k)
     for k in range(args.warmup):
         one_step(k)
     ctx.barrier()
@@ -679,7 +697,7 @@ def run_rank(args, ctx, inp):
         p, ma, mb, _ = views()
         base = args.warmup + args.steps
         for k in range(12):
-            eng.obs_set_dev(*obs_v[(base + k) % len(frames)], L)
+            eng.obs_set_dev(*obs_v[(off + base + k) % len(frames)], L)
             eng.ekf_update_dev((ma, mb)[k & 1], (mb, ma)[k & 1], 5 * Lp, Lp, L, p[0], p[1], p[2], None, n, MEAS_VAR, loglik_t)
         eng.profile_enable()
         nr_ms, nr_n = eng.profile_read(eng.PROF_EKF)
@@ -749,6 +767,7 @@ def run_rank(args, ctx, inp):
                    "rows_received_per_frame_max_rank": migrated if world > 1 else 0,
                    "distinct_ancestor_frac": distinct_frac,
                    "resample_ess_frac": args.ess,
+                   "preroll_frames": off,
                    "map_layout": {"requested": args.map_layout, "in_timed_region": "pages (copy-on-write, 32 landmarks)" if paged_in_region else "rows"},
                    "frames_resampled": (pf.frames_resampled() if 0 < args.ess < 1 else None)},
         "roofline": {"bound": "hbm", "kernel": kern, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -869,7 +888,7 @@ def extra_legs(args, torch, pkg, eng, dev, inp, kernel_ms):
     n, L, Lp = 65536, 500, 512
     rng = np.random.default_rng(4321)
     lm = make_landmarks(L, rng)
-    steps, warm, chunk = 40, 12, 10
+    steps, warm, chunk = 40, 12 + preroll_frames(args), 10   # the same pre-roll as the main path
     fr = make_frames(steps + warm, args.beams, lm, rng, 32)
     d_scan = torch.from_numpy(np.stack([np.stack([f["bx"], f["by"]]) for f in fr])).to(dev)
     tabs = obs_tables(torch, fr, L, dev)
@@ -939,6 +958,11 @@ def parse_args():
                          "process on ONE card (--device-index, default 0), exchanging through slam_comm_create_local")
     ap.add_argument("--device-index", type=int, default=None, help="force every rank onto this GPU (--transport local)")
     ap.add_argument("--host-sensor", action="store_true", help="upload scan + observations from the host every frame")
+    ap.add_argument("--preroll", type=int, default=120,
+                    help="--mode pf: untimed frames the filter runs before the W warm-up steps, so that the timed steps see a "
+                         "filter in steady state (0 = start cold from the 5 cm / 0.01 rad initial spread)")
+    ap.add_argument("--settle-ms", type=float, default=250.0,
+                    help="host sleep between set-up and the warm-up frames (see settle(); 0 = none)")
     ap.add_argument("--event-every", type=int, default=0,
                     help="bracket the timed kernels with HIP events in every N-th frame of the timed region (1 = every frame; "
                          "default 0 = every 4th frame, every 2nd when --steps < 40)")
@@ -960,6 +984,8 @@ def parse_args():
                     help="diagnostics, --gpus 1 only: run the multi-GPU code path (every RCCL collective, the sharded index "
                          "kernels, the plan read-back) on a one-rank group to price its control overhead")
     args = ap.parse_args()
+    global SETTLE_S
+    SETTLE_S = max(0.0, args.settle_ms * 1e-3)
     if args.paged:
         args.map_layout = "pages"
     if args.mode != "pf":

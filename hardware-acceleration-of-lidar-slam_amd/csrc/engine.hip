@@ -767,6 +767,7 @@ int slam_frame_front_dev(slam_engine* e, int slot, const float* d_src_x, const f
     *launched = false;
     static const int env_fusion = getenv("SLAM_FRAME_FUSION") ? atoi(getenv("SLAM_FRAME_FUSION")) : -1;
     if (!(env_fusion >= 0 ? env_fusion != 0 : e->frame_fusion)) return SLAM_OK;
+    if (e->prof_mask & (1 << SLAM_PROF_SCORE)) return SLAM_OK;   // the score stage is being timed: it stays a launch of its own
     // the checks of slam_motion_score_dev and of slam_ekf_update_dev (out of place)
     if (n <= 0 || first_id < 0 || !dp || !sigma || !d_src_x || !d_src_y || !d_src_th || !d_x || !d_y || !d_th || !d_score ||
         !d_count || !d_anc || !d_map_in || !d_map_out || d_map_in == d_map_out)

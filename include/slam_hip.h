@@ -246,7 +246,8 @@ int slam_ekf_form_counts(slam_engine *e, int64_t counts[2]);
  * updating workgroups are dealt out interleaved: the scorer's gathers (texture addresser, L2) run in the shadow of the
  * update's row stores (HBM).  Same bits as the two launches.  on = 1 (the initial state) / 0: two launches (stage timers,
  * measurements; the environment variable SLAM_FRAME_FUSION overrides).  Sharded, gated and paged sessions, short rows and
- * small populations always take the two launches.  slam_frame_fusion_count: fused launches of this engine so far. */
+ * small populations always take the two launches, and so does every frame while SLAM_PROF_SCORE is being timed
+ * (slam_profile_enable: a fused launch is bracketed as SLAM_PROF_EKF).  slam_frame_fusion_count: fused launches of this engine so far. */
 int slam_frame_fusion_set(slam_engine *e, int on);
 int slam_frame_fusion_count(slam_engine *e, int64_t *launches);
 /* The in-place update (d_map_in == d_map_out: frames that keep their population, slam_resample_gate_set) also has two
