@@ -19,8 +19,8 @@ step "kernel trace, score-only (configs[2])"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${TAG}_trace_score" -- $B --mode score --particles 1048576 --grid 2048 --steps 50 --warmup 5 > "$OUT/${TAG}_trace_score.json" 2> "$OUT/${TAG}_trace_score.err"
 for C in FETCH_SIZE WRITE_SIZE; do
   step "pmc $C: pf default, pf --observed 32, ekf sweep (calibration)"
-  rocprofv3 --pmc $C --output-format csv -d "$OUT/${TAG}_pmc_${C}_pf" -- $B --mode pf --steps 8 --warmup 2 --events none > /dev/null 2> "$OUT/${TAG}_pmc_${C}_pf.err"
-  rocprofv3 --pmc $C --output-format csv -d "$OUT/${TAG}_pmc_${C}_pfobs32" -- $B --mode pf --observed 32 --map-layout rows --steps 8 --warmup 2 --events none > /dev/null 2> "$OUT/${TAG}_pmc_${C}_pfobs32.err"
+  rocprofv3 --pmc $C --output-format csv -d "$OUT/${TAG}_pmc_${C}_pf" -- $B --mode pf --steps 8 --warmup 2 --preroll 0 --events none > /dev/null 2> "$OUT/${TAG}_pmc_${C}_pf.err"
+  rocprofv3 --pmc $C --output-format csv -d "$OUT/${TAG}_pmc_${C}_pfobs32" -- $B --mode pf --observed 32 --map-layout rows --steps 8 --warmup 2 --preroll 0 --events none > /dev/null 2> "$OUT/${TAG}_pmc_${C}_pfobs32.err"
   rocprofv3 --pmc $C --output-format csv -d "$OUT/${TAG}_pmc_${C}_ekf" -- $B --mode ekf --steps 8 --warmup 2 --events none > /dev/null 2> "$OUT/${TAG}_pmc_${C}_ekf.err"
 done
 step "copy ceilings: the EKF's row access shape, and scattered pages (pure copies, no arithmetic)"
@@ -33,6 +33,6 @@ k=0
 for G in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_INSTS_VALU SQ_INSTS_VMEM_WR" "SQ_INSTS_VMEM_RD SQ_INSTS_SALU" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM" \
          "SQ_WAIT_INST_ANY SQ_WAIT_ANY" "VALUBusy" "MemUnitStalled" "WriteUnitStalled" "GRBM_GUI_ACTIVE"; do
   k=$((k + 1))
-  timeout -k 5 150 rocprofv3 --pmc $G --output-format csv -d "$OUT/${TAG}_ekfpmc_$k" -- $B --mode pf --steps 8 --warmup 2 --events none --no-sweep > /dev/null 2> "$OUT/${TAG}_ekfpmc_$k.err" || echo "[collect] ekf pmc pass $k ($G) FAILED"
+  timeout -k 5 150 rocprofv3 --pmc $G --output-format csv -d "$OUT/${TAG}_ekfpmc_$k" -- $B --mode pf --steps 8 --warmup 2 --preroll 0 --events none --no-sweep > /dev/null 2> "$OUT/${TAG}_ekfpmc_$k.err" || echo "[collect] ekf pmc pass $k ($G) FAILED"
 done
 step done

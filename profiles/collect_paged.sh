@@ -19,6 +19,6 @@ for L in 500 5000; do
 done
 for C in FETCH_SIZE WRITE_SIZE; do
   echo "[collect_paged] pmc $C, 500 landmarks, pages"
-  timeout -k 5 200 rocprofv3 --pmc $C --output-format csv -d "$OUT/${TAG}_pagedpmc_${C}" -- $B --paged --steps 12 --warmup 2 --events none > /dev/null 2> "$OUT/${TAG}_pagedpmc_${C}.err"
+  timeout -k 5 200 rocprofv3 --pmc $C --output-format csv -d "$OUT/${TAG}_pagedpmc_${C}" -- $B --paged --steps 12 --warmup 2 --preroll 0 --events none > /dev/null 2> "$OUT/${TAG}_pagedpmc_${C}.err"
 done
 echo "[collect_paged] done"

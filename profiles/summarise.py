@@ -74,8 +74,8 @@ for mode, key, K in (("pf", f"pf:{n}:360:{L}:1024", L), ("pfobs32", f"pf:{n}:360
               f"{(rd + wr) / 1e6:.1f} MB per launch vs {alg / 1e6:.1f} MB algorithmic (40 B x n x {K} observed).")
 md += ["", "The writes are the 20 B x n x 512 of the padded rows (every row is rewritten by the out-of-place update); the reads are "
        "only the rows of the DISTINCT resample ancestors — the offspring of one ancestor are neighbouring particles and "
-       "re-read its row from L2.  The launches after the timed region in each list are bench.py's no-reuse sweep (identity "
-       "ancestors): read = write = 671 MB."]
+       "re-read its row from L2.  The launches after the timed region in each list are bench.py's stage pass (the two-launch "
+       "path) and its no-reuse sweep (identity ancestors: read = write = 671 MB)."]
 (here / "traffic.json").write_text(json.dumps(traffic, indent=1) + "\n")
 (here / f"{tag}_pmc_ekf.md").write_text("\n".join(md) + "\n")
 print("\n".join(md[-6:]))
