@@ -28,7 +28,7 @@ for L in (500, 5000):
         f = newest(f"{tag}_pagedtrace_{L}_{P}/*/*kernel_stats.csv")
         for r in csv.DictReader(open(f)):
             name = r["Name"].replace("void ", "").replace("slam::(anonymous namespace)::", "").split("(")[0]
-            if any(k in name for k in ("ekf_", "score_poses", "page_", "free_list", "ancestors_from", "quantise_scan", "logweight")):
+            if any(k in name for k in ("ekf_", "frame_front", "score_poses", "page_", "free_list", "ancestors_from", "quantise_scan", "logweight")):
                 stats.setdefault(name, {})[P] = (int(r["Calls"]), float(r["AverageNs"]) / 1e3)
     for name, v in sorted(stats.items(), key=lambda kv: -max(x[1] * x[0] for x in kv[1].values())):
         if max(x[0] for x in v.values()) < 20:
