@@ -1680,7 +1680,10 @@ hipError_t launch_frame_front(hipStream_t stream, const ScoreGrid& g, const floa
     if (a_in.map_in == a_in.map_out || !frame_front_fits(n, a_in.nlandmarks, group_size)) return hipSuccess;
     const int G = group_size;
     const int gblocks = (n + kEkfWaves * G - 1) / (kEkfWaves * G);
-    const bool quad = n < quad_max;
+    // inside the fused launch the scorer's latency is hidden anyway; what counts is how long its wavefronts hold slots the
+    // update would fill: SLAM_FRONT_QUAD_MAX = population below which the 4-lanes-per-pose scorer is used here (measurements)
+    static const int front_quad_max = getenv("SLAM_FRONT_QUAD_MAX") ? atoi(getenv("SLAM_FRONT_QUAD_MAX")) : quad_max;
+    const bool quad = n < front_quad_max;
     FrontArgs f;
     f.g = g;
     f.bx = bx;
