@@ -108,6 +108,7 @@ SIGNATURES = {
     "slam_exchange_set_capacity": (_i, [_vp, _i]),
     "slam_ekf_form_set": (_i, [_vp, _i]),
     "slam_ekf_form_counts": (_i, [_vp, _vp]),
+    "slam_selftest_reciprocal": (_i, [_vp, _vp, _vp]),
     "slam_frame_fusion_set": (_i, [_vp, _i]),
     "slam_frame_fusion_count": (_i, [_vp, _vp]),
     "slam_ekf_inplace_form_set": (_i, [_vp, _i]),
@@ -408,6 +409,12 @@ class Engine:
         c = (C.c_int64 * 2)()
         self._ck(self.lib.slam_ekf_form_counts(self.h, c), "ekf_form_counts")
         return int(c[0]), int(c[1])
+
+    def selftest_reciprocal(self):
+        """(mismatches, values checked) of the landmark update's fast reciprocal against IEEE division, every float in range."""
+        bad, seen = C.c_int64(-1), C.c_int64(0)
+        self._ck(self.lib.slam_selftest_reciprocal(self.h, C.byref(bad), C.byref(seen)), "selftest_reciprocal")
+        return int(bad.value), int(seen.value)
 
     def frame_fusion_set(self, on: bool):
         """The front of a single-GPU frame on rows (motion + score and the landmark update) as one launch (default) or two."""

@@ -53,8 +53,51 @@ __device__ __forceinline__ v2f det_logf2(v2f x)
 template <class T> __device__ __forceinline__ T ekf_splat(float a);
 template <> __device__ __forceinline__ float ekf_splat<float>(float a) { return a; }
 template <> __device__ __forceinline__ v2f ekf_splat<v2f>(float a) { return bc2(a); }
-__device__ __forceinline__ float ekf_rcp(float d) { return 1.0f / d; }   // IEEE division (correctly rounded)
-__device__ __forceinline__ v2f ekf_rcp(v2f d) { return (v2f){1.0f / d[0], 1.0f / d[1]}; }
+// 1 / d, correctly rounded (the specification says 1.0f / det: IEEE division, what the CPU computes).  hipcc's expansion of an
+// IEEE float division is v_div_scale x2, v_rcp, a Newton step, two quotient corrections with v_div_fmas, v_div_fixup — eleven
+// instructions per value, a fifth of the landmark update's arithmetic after the logarithm.  When the numerator is 1 and the
+// denominator's exponent lies in [-60, 60] neither scale nor fix-up does anything, and what remains is the reciprocal
+// estimate and six fused multiply-adds — the same operations on the same values, hence the same bits
+// (slam_selftest_reciprocal walks every float of that range on the device and compares with the compiler's division:
+// tests/test_gpu_pf.py).  Outside the range (wave-uniform test) the division itself.
+__device__ __forceinline__ bool ekf_rcp_in_range(float d)
+{
+    return ((__float_as_uint(d) >> 23) & 0xffu) - 67u <= 120u;   // 2^-60 <= |d| < 2^61, finite
+}
+__device__ __forceinline__ float ekf_rcp_core(float d)
+{
+    float r = __builtin_amdgcn_rcpf(d);
+    const float e = __builtin_fmaf(-d, r, 1.0f);
+    r = __builtin_fmaf(e, r, r);
+    float t = __builtin_fmaf(-d, r, 1.0f);
+    float q = __builtin_fmaf(t, r, r);
+    t = __builtin_fmaf(-d, q, 1.0f);
+    return __builtin_fmaf(t, r, q);
+}
+// (SLAM_EKF_PLAIN_DIV: measurement builds with the division itself everywhere)
+__device__ __forceinline__ float ekf_rcp(float d)
+{
+#ifndef SLAM_EKF_PLAIN_DIV
+    if (__ballot(!ekf_rcp_in_range(d)) == 0) return ekf_rcp_core(d);
+#endif
+    return 1.0f / d;
+}
+__device__ __forceinline__ v2f ekf_rcp(v2f d)
+{
+#ifndef SLAM_EKF_PLAIN_DIV
+    if (__ballot(!(ekf_rcp_in_range(d[0]) && ekf_rcp_in_range(d[1]))) == 0) {
+        v2f r = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+        const v2f one = {1.0f, 1.0f}, nd = -d;
+        const v2f e = __builtin_elementwise_fma(nd, r, one);
+        r = __builtin_elementwise_fma(e, r, r);
+        v2f t = __builtin_elementwise_fma(nd, r, one);
+        v2f q = __builtin_elementwise_fma(t, r, r);
+        t = __builtin_elementwise_fma(nd, q, one);
+        return __builtin_elementwise_fma(t, r, q);
+    }
+#endif
+    return (v2f){1.0f / d[0], 1.0f / d[1]};
+}
 __device__ __forceinline__ float ekf_log(float d) { return det_logf(d); }
 __device__ __forceinline__ v2f ekf_log(v2f d) { return det_logf2(d); }
 

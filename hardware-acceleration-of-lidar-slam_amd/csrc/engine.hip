@@ -301,6 +301,25 @@ int slam_profile_copy_ceiling(slam_engine* e, const float* d_src, float* d_dst, 
     return rc;
 }
 
+int slam_selftest_reciprocal(slam_engine* e, int64_t* mismatches, int64_t* checked)
+{
+    ENTER(e);
+    if (!mismatches || !checked) return SLAM_ERR_INVALID_ARG;
+    unsigned long long* d = nullptr;
+    HIP_TRY(hipMalloc((void**)&d, 16));
+    int rc = SLAM_OK;
+    unsigned long long h[2] = { 0, 0 };
+    hipError_t err = hipMemsetAsync(d, 0, 16, e->stream);
+    if (err == hipSuccess) err = launch_selftest_reciprocal(e->stream, d);
+    if (err == hipSuccess) err = hipMemcpyAsync(h, d, 16, hipMemcpyDeviceToHost, e->stream);
+    if (err == hipSuccess) err = hipStreamSynchronize(e->stream);
+    if (err != hipSuccess) rc = fail_hip(e, err, "slam_selftest_reciprocal");
+    (void)hipFree(d);
+    *mismatches = (int64_t)h[0];
+    *checked = (int64_t)h[1];
+    return rc;
+}
+
 int slam_engine_set_stream(slam_engine* e, void* hip_stream)
 {
     ENTER(e);

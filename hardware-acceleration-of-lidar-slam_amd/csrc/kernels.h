@@ -95,6 +95,7 @@ hipError_t launch_ekf_update(hipStream_t stream, const EkfArgs& a, const EventPa
 // gathers of the scorer run in the shadow of the update's row stores.  `a.x / a.y / a.th` are not read (the update works out
 // its particles' motion samples itself, the same bits the scorer writes to io.x / io.y / io.th).  *launched = false: shapes
 // that this kernel does not take; nothing was issued.
+hipError_t launch_selftest_reciprocal(hipStream_t stream, unsigned long long* out /* [2], zeroed: mismatches, values checked */);
 bool frame_front_fits(int n, int nlandmarks, int group_size);   // the shapes launch_frame_front takes
 hipError_t launch_frame_front(hipStream_t stream, const ScoreGrid& g, const float* bx, const float* by, int nbeams,
                               const MotionIO& io, int64_t first_id, const float dp[3], const float sigma[3], uint64_t seed,

@@ -1713,6 +1713,33 @@ hipError_t launch_frame_front(hipStream_t stream, const ScoreGrid& g, const floa
     return hipGetLastError();
 }
 
+// every float whose exponent lies in the fast reciprocal's range (both signs): ekf_rcp_core against the compiler's IEEE
+// division, the scalar form and the packed one; out[0] += mismatches, out[1] += values checked
+namespace {
+__global__ __launch_bounds__(256) void selftest_reciprocal_kernel(unsigned long long* __restrict__ out)
+{
+    unsigned long long bad = 0, seen = 0;
+    for (uint64_t b = (uint64_t)blockIdx.x * 256 + threadIdx.x; b < (1ull << 32); b += (uint64_t)gridDim.x * 256) {
+        const float d = __uint_as_float((uint32_t)b);
+        if (!ekf_rcp_in_range(d)) continue;
+        const float exact = 1.0f / d;
+        const float fast = ekf_rcp_core(d);
+        const v2f two = ekf_rcp((v2f){d, -d});   // (every lane here is in range: the packed fast path)
+        bad += (__float_as_uint(exact) != __float_as_uint(fast)) || (__float_as_uint(two[0]) != __float_as_uint(exact)) ||
+               (__float_as_uint(two[1]) != (__float_as_uint(exact) ^ 0x80000000u));
+        ++seen;
+    }
+    if (bad) atomicAdd(&out[0], bad);
+    atomicAdd(&out[1], seen);
+}
+}  // namespace
+
+hipError_t launch_selftest_reciprocal(hipStream_t stream, unsigned long long* out)
+{
+    selftest_reciprocal_kernel<<<256 * 16, 256, 0, stream>>>(out);
+    return hipGetLastError();
+}
+
 constexpr int kMaxWeightBlocks = 2048;
 static int capped_blocks(int n) { const int b = blocks_for(n); return b < kMaxWeightBlocks ? b : kMaxWeightBlocks; }
 int logweight_scratch_elems(int n) { return capped_blocks(n > 0 ? n : 1); }

@@ -110,6 +110,11 @@ int slam_profile_bracket_overhead(slam_engine *e, double *overhead_ms);
  * wave accesses, all loads of two batches before their stores, XCD-contiguous workgroup numbering, streaming stores —
  * the addressing of the update without its arithmetic); *ms_per_copy is the average duration from HIP events.  Any
  * kernel that reads 20 B and writes 20 B per (particle, landmark) is bounded by it: measurement support, not a stage. */
+/* Self-check of the landmark update's reciprocal (csrc/ekf_math.h): the update computes 1 / det without the scaling and
+ * fix-up steps of a general IEEE division whenever det's exponent lies in [-60, 60]; this walks every float of that range
+ * on the device (2 x 121 x 2^23 values) and compares with the compiler's correctly rounded division.  *mismatches must
+ * come back 0. */
+int slam_selftest_reciprocal(slam_engine *e, int64_t *mismatches, int64_t *checked);
 int slam_profile_copy_ceiling(slam_engine *e, const float *d_src, float *d_dst, int64_t rows, int plane_stride, int reps,
                               double *ms_per_copy);
 

@@ -798,3 +798,14 @@ def test_rccl_collectives_single_rank(eng, orc, tmp_path):
     """))
     r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "RCCL single-rank path == single-GPU path" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+def test_fast_reciprocal_equals_ieee_division_for_every_float_in_range():
+    """csrc/ekf_math.h: 1 / det without the scale / fix-up steps of a general division when det's exponent is in [-60, 60].
+    Every float of that range, both signs, scalar and packed form, against the compiler's correctly rounded division."""
+    pkg = load_package()
+    eng = pkg.Engine(0)
+    bad, seen = eng.selftest_reciprocal()
+    eng.close()
+    assert seen == 2 * 121 * (1 << 23), seen
+    assert bad == 0, bad
