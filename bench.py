@@ -36,7 +36,9 @@ One JSON line on stdout (rank 0).  Beyond the contract's fields:
   stage_avg_ms  every stage of a frame through the ABI's per-stage timers (a short pass after the timed region)
   north_star, copy_ceiling, end_to_end_obs32   (N = 1, default workload) bounded extra legs after the timed region:
                 the EKF sweep at 1 048 576 x 1 000, a pure copy of the same shape, and the configs[1] frame with the 32
-                nearest landmarks observed on rows and on pages.  They never touch `value`.
+                nearest landmarks observed on rows and on pages; `headline_round2_method`: configs[1] measured the way
+                BENCH_r01 / BENCH_r02 were (cold filter, 5 + 20 frames, every frame bracketed), as two launches and fused.
+                They never touch `value`.
   cpu_baseline  the CPU port of the same frame loop (oracle/, one thread) on a bounded sample; cpu_baseline_threads:
                 its per-particle stages on up to 16 host threads; cpu_baseline_main_c: the reference's own pipeline
                 (main.c rows A1-A8) on this host's CPU — the compiled reference when oracle/_ref/ travelled here, and
@@ -924,6 +926,45 @@ def extra_legs(args, torch, pkg, eng, dev, inp, kernel_ms):
         e2e[f"{layout}_ended_on"] = "pages" if ses.is_paged() else "rows"
         ses.close()
     res["end_to_end_obs32"] = e2e
+
+    # ---- (d) the headline workload measured the way rounds 1 and 2 measured it, for comparison with their driver records:
+    # a cold filter (no pre-roll), 5 warm-up + 20 timed frames, score and landmark update as two launches, the update of EVERY
+    # frame bracketed by HIP events.  The difference to `value` is method (steady state, sampled brackets) and the fused front.
+    fr = make_frames(25, args.beams, lm, rng, 0)
+    d_scan = torch.from_numpy(np.stack([np.stack([f["bx"], f["by"]]) for f in fr])).to(dev)
+    tabs = obs_tables(torch, fr, L, dev)
+    old = {}
+    for name, fuse in (("two_launches_cold_every_frame_bracketed", False), ("fused_front_cold_every_frame_bracketed", True)):
+        ses = pkg.PfSession(eng, n, L, sigma=SIGMA, meas_var=MEAS_VAR, score_gain=SCORE_GAIN, seed=1234, map_layout="rows")
+        g = torch.Generator(device="cpu").manual_seed(1234)
+        ses.set_poses(*[(p0[k] + s * torch.randn(n, generator=g)).numpy() for k, s in ((0, 0.05), (1, 0.05), (2, 0.01))])
+        m0 = torch.zeros((n, 5, Lp), dtype=torch.float32, device=dev)
+        fill_maps(torch, m0, lm, L, dev, n)
+        torch.cuda.synchronize()
+        ses.set_map_dev(m0, 5 * Lp, Lp)
+        eng.sync()
+        del m0
+        eng.frame_fusion_set(fuse)
+        settle(torch)
+        for k in range(25):
+            if k == 5:
+                torch.cuda.synchronize()
+                eng.profile_enable(eng.PROF_EKF)
+                eng.profile_read(eng.PROF_EKF)
+                t0 = time.perf_counter()
+            eng.scan_set_dev(d_scan[k, 0], d_scan[k, 1], args.beams)
+            eng.obs_set_dev(tabs[k, 0], tabs[k, 1], L)
+            ses.step(0, fr[k]["dp"], True)
+        torch.cuda.synchronize()
+        ms = 1e3 * (time.perf_counter() - t0) / 20
+        eng.profile_enable()
+        kms, kn = eng.profile_read(eng.PROF_EKF)
+        old[name] = {"ms_per_step": ms, "particle_updates_per_s": n / (ms * 1e-3), "bracketed_kernel_avg_ms": kernel_ms(kms, kn)}
+        ses.close()
+    eng.frame_fusion_set(True)
+    old["what"] = ("configs[1] as BENCH_r01 / BENCH_r02 measured it (--steps 20 --warmup 5 from a cold start, every frame's dominant "
+                   "launch bracketed), with the front as two launches (round 2's frame) and fused")
+    res["headline_round2_method"] = old
     return res
 
 
