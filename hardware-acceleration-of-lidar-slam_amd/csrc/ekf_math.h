@@ -101,9 +101,71 @@ __device__ __forceinline__ v2f ekf_rcp(v2f d)
 __device__ __forceinline__ float ekf_log(float d) { return det_logf(d); }
 __device__ __forceinline__ v2f ekf_log(v2f d) { return det_logf2(d); }
 
-// What the update of a landmark that HAS been seen before gives (o0..o4 = mu_x, mu_y, P_xx, P_xy, P_yy; ll = its
-// log-likelihood term) and what a first sighting gives (f0, f1: the observed point in the world frame; P = q I, no term).
-// The caller selects: prior P_xx < 0 -> first sighting; no observation -> the prior values, no term.
+// ---- The update of one landmark, in the WORLD frame (specification: oracle/slam_oracle_pf.c orc_ekf_update).
+// The observation model is z = H (m - t) with H a rotation and R = q I, so
+//     S_sensor = H P H^T + q I = H (P + q I) H^T,   K = P H^T S_sensor^-1 = P (P + q I)^-1 H^T = W H^T,
+//     K nu = W (H^T nu) = W (w - mu)   with w = t + H^T z the observed point in the world frame,
+//     P' = (I - K H) P = (I - W) P,    nu^T S_sensor^-1 nu = (w - mu)^T (P + q I)^-1 (w - mu),   det S_sensor = det (P + q I):
+// everything that involves the covariance — S^-1, the gain W, P', the determinant's logarithm — depends on the prior P and
+// on q ALONE, not on the particle's pose and not on the measurement.  The offspring of one ancestor share its P, so a
+// wavefront that updates several of them (the grouped kernels) works that part out ONCE per landmark; per particle there
+// remain the observed point w, the innovation d = w - mu, mu' = mu + W d and the Mahalanobis term.  Round 3 replaced the
+// sensor-frame formulation (the same algebra with H carried through every product: ~160 vector instructions per landmark
+// pair and particle) by this one: ~75 shared + ~31 per particle.
+
+// the part that depends on the prior covariance and q only
+template <class T> struct EkfShared {
+    T i00, i01, i11;        // (P + q I)^-1
+    T w00, w01, w10, w11;   // gain in the world frame, W = P (P + q I)^-1
+    T o2, o3, o4;           // posterior covariance (I - W) P: P_xx, P_xy, P_yy
+    T hl;                   // 0.5 * log det (P + q I)
+};
+
+template <class T> __device__ __forceinline__ EkfShared<T> ekf_shared(T pxx, T pxy, T pyy, T q)
+{
+    EkfShared<T> h;
+    const T a = pxx + q, c = pyy + q;
+    const T det = a * c - pxy * pxy;
+    const T idet = ekf_rcp(det);
+    h.i00 = c * idet;
+    h.i01 = -pxy * idet;
+    h.i11 = a * idet;
+    h.w00 = pxx * h.i00 + pxy * h.i01;
+    h.w01 = pxx * h.i01 + pxy * h.i11;
+    h.w10 = pxy * h.i00 + pyy * h.i01;
+    h.w11 = pxy * h.i01 + pyy * h.i11;
+    h.o2 = pxx - (h.w00 * pxx + h.w01 * pxy);
+    h.o3 = pxy - (h.w00 * pxy + h.w01 * pyy);
+    h.o4 = pyy - (h.w10 * pxy + h.w11 * pyy);
+    h.hl = ekf_splat<T>(0.5f) * ekf_log(det);
+    return h;
+}
+
+// the part that depends on the particle: its pose (px, py, heading sine s / cosine c), the prior mean and the measurement
+template <class T> struct EkfParticle {
+    T o0, o1;   // posterior mean
+    T ll;       // log-likelihood term
+    T wx, wy;   // the observed point in the world frame (what a first sighting stores)
+};
+
+template <class T>
+__device__ __forceinline__ EkfParticle<T> ekf_particle(const EkfShared<T>& h, T mx, T my, T zx, T zy, T s, T c, T px, T py)
+{
+    EkfParticle<T> r;
+    r.wx = px + (c * zx + s * zy);
+    r.wy = py + (c * zy - s * zx);
+    const T dx = r.wx - mx, dy = r.wy - my;
+    r.o0 = mx + (h.w00 * dx + h.w01 * dy);
+    r.o1 = my + (h.w10 * dx + h.w11 * dy);
+    const T maha = dx * (h.i00 * dx + h.i01 * dy) + dy * (h.i01 * dx + h.i11 * dy);
+    r.ll = ((ekf_splat<T>(0.0f) - ekf_splat<T>(0.5f) * maha) - h.hl) - ekf_splat<T>(1.8378770664f);
+    return r;
+}
+
+// Both parts for one landmark and one particle.  What the update of a landmark that HAS been seen before gives (o0..o4 =
+// mu_x, mu_y, P_xx, P_xy, P_yy; ll = its log-likelihood term) and what a first sighting gives (f0, f1: the observed point
+// in the world frame; P = q I, no term).  The caller selects: prior P_xx < 0 -> first sighting; no observation -> the prior
+// values, no term.
 template <class T> struct EkfResult {
     T o0, o1, o2, o3, o4, ll, f0, f1;
 };
@@ -115,34 +177,21 @@ template <class T> __device__ __forceinline__ void ekf_first_sighting(T zx, T zy
     f1 = py + (c * zy - s * zx);
 }
 
-// prior (mx, my, pxx, pxy, pyy), observation (zx, zy) in the sensor frame, pose (px, py, heading sine s / cosine c), q = R.
-// WITH_FIRST = false leaves f0 / f1 unset: the row kernels work them out (ekf_first_sighting) only for a batch of landmarks
-// that holds a first sighting at all, which in a running filter is rare.
+// prior (mx, my, pxx, pxy, pyy), observation (zx, zy) in the sensor frame, pose (px, py, heading sine s / cosine c), q = R
 template <class T, bool WITH_FIRST = true>
 __device__ __forceinline__ EkfResult<T> ekf_update_one(T mx, T my, T pxx, T pxy, T pyy, T zx, T zy, T s, T c, T px, T py, T q)
 {
+    const EkfShared<T> h = ekf_shared<T>(pxx, pxy, pyy, q);
+    const EkfParticle<T> u = ekf_particle<T>(h, mx, my, zx, zy, s, c, px, py);
     EkfResult<T> r;
-    const T dx = mx - px, dy = my - py;
-    const T vx = zx - (c * dx - s * dy);
-    const T vy = zy - (s * dx + c * dy);
-    const T a00 = c * pxx - s * pxy, a01 = c * pxy - s * pyy;
-    const T a10 = s * pxx + c * pxy, a11 = s * pxy + c * pyy;
-    const T s00 = (a00 * c - a01 * s) + q;
-    const T s01 = a00 * s + a01 * c;
-    const T s11 = (a10 * s + a11 * c) + q;
-    const T det = s00 * s11 - s01 * s01;
-    const T idet = ekf_rcp(det);
-    const T i00 = s11 * idet, i01 = -s01 * idet, i11 = s00 * idet;
-    const T k00 = a00 * i00 + a10 * i01, k01 = a00 * i01 + a10 * i11;
-    const T k10 = a01 * i00 + a11 * i01, k11 = a01 * i01 + a11 * i11;
-    r.o0 = mx + (k00 * vx + k01 * vy);
-    r.o1 = my + (k10 * vx + k11 * vy);
-    r.o2 = pxx - (k00 * a00 + k01 * a10);
-    r.o3 = pxy - (k00 * a01 + k01 * a11);
-    r.o4 = pyy - (k10 * a01 + k11 * a11);
-    const T maha = vx * (i00 * vx + i01 * vy) + vy * (i01 * vx + i11 * vy);
-    r.ll = ((ekf_splat<T>(0.0f) - ekf_splat<T>(0.5f) * maha) - ekf_splat<T>(0.5f) * ekf_log(det)) - ekf_splat<T>(1.8378770664f);
-    if (WITH_FIRST) ekf_first_sighting<T>(zx, zy, s, c, px, py, r.f0, r.f1);
+    r.o0 = u.o0;
+    r.o1 = u.o1;
+    r.o2 = h.o2;
+    r.o3 = h.o3;
+    r.o4 = h.o4;
+    r.ll = u.ll;
+    r.f0 = u.wx;   // the same expression as ekf_first_sighting
+    r.f1 = u.wy;
     return r;
 }
 

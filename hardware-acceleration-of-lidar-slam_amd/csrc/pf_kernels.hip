@@ -260,8 +260,12 @@ __global__ __launch_bounds__(kEkfWaves * 64) void ekf_update_kernel(EkfArgs a)
 // the same tests cover both kernels); the per-particle accumulators live in LDS between batches.
 template <int NB>
 struct EkfBatch {   // NB batches of 128 landmarks of one source row + the observations of those landmarks
-    v2f m[NB][5], zx[NB], zy[NB];
-    bool obs[NB][2];
+    v2f mx[NB], my[NB];        // prior means
+    v2f p2[NB], p3[NB], p4[NB];   // what goes into the covariance planes: (I - W) P, q I for a first sighting, the prior without an observation
+    EkfShared<v2f> sh[NB];     // the pose-independent part of the update (csrc/ekf_math.h), worked out once per source row
+    v2f zx[NB], zy[NB];
+    bool obs[NB][2], first[NB][2];
+    bool any_obs[NB], all_obs[NB], any_first[NB];   // wave-uniform
     unsigned off[NB][2];
 };
 
@@ -270,34 +274,83 @@ struct EkfPose {   // one particle of the group (wave-uniform values)
     v2f s, c, px, py;
 };
 
-// update NB batches already in registers with one particle's pose and store them to its row (FULL batches only: every
-// lane's landmarks lie inside the padded row; landmarks beyond L count as "not observed", padding is copied along)
+// A new source row is in registers (b.mx / b.my and the prior covariance pxx / pxy / pyy of batch g): everything about it
+// that does not depend on the particle — the gain, the posterior covariance, the determinant's logarithm (ekf_shared) and
+// the selection of what the covariance planes receive (a first sighting: q I; no observation: the prior).
 template <int NB>
-__device__ __forceinline__ void ekf_apply(const EkfBatch<NB>& b, const EkfPose& w, int pl, v2f q2, v2f& acc)
+__device__ __forceinline__ void ekf_prepare(EkfBatch<NB>& b, int g, v2f pxx, v2f pxy, v2f pyy, v2f q)
+{
+    b.p2[g] = pxx;
+    b.p3[g] = pxy;
+    b.p4[g] = pyy;
+    b.first[g][0] = pxx[0] < 0.0f;
+    b.first[g][1] = pxx[1] < 0.0f;
+    b.any_first[g] = __ballot(b.first[g][0] || b.first[g][1]) != 0;
+    if (!b.any_obs[g]) return;   // no observation among these 128 landmarks: the rows are copied
+    b.sh[g] = ekf_shared<v2f>(pxx, pxy, pyy, q);
+    v2f r2 = b.sh[g].o2, r3 = b.sh[g].o3, r4 = b.sh[g].o4;
+    if (b.any_first[g]) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            r2[t] = b.first[g][t] ? q[t] : r2[t];
+            r3[t] = b.first[g][t] ? 0.0f : r3[t];
+            r4[t] = b.first[g][t] ? q[t] : r4[t];
+        }
+    }
+    if (!b.all_obs[g]) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            r2[t] = b.obs[g][t] ? r2[t] : pxx[t];
+            r3[t] = b.obs[g][t] ? r3[t] : pxy[t];
+            r4[t] = b.obs[g][t] ? r4[t] : pyy[t];
+        }
+    }
+    b.p2[g] = r2;
+    b.p3[g] = r3;
+    b.p4[g] = r4;
+}
+
+// update NB prepared batches with one particle's pose and store them to its row (FULL batches only: every lane's landmarks
+// lie inside the padded row; landmarks beyond L count as "not observed", padding is copied along).  Per particle there is
+// the observed point in the world frame, the innovation, the new mean and the likelihood term (ekf_particle); the values
+// are those of ekf_update_one + ekf_select.
+template <int NB>
+__device__ __forceinline__ void ekf_apply(const EkfBatch<NB>& b, const EkfPose& w, int pl, v2f& acc)
 {
 #pragma unroll
     for (int g = 0; g < NB; ++g) {
-        const v2f mx = b.m[g][0], my = b.m[g][1], pxx = b.m[g][2], pxy = b.m[g][3], pyy = b.m[g][4];
-        if (__ballot(b.obs[g][0] || b.obs[g][1]) == 0) {   // no observation among these 128 landmarks: plain copy
+        v2f r0 = b.mx[g], r1 = b.my[g];
+        if (b.any_obs[g]) {
+            const EkfParticle<v2f> u = ekf_particle<v2f>(b.sh[g], b.mx[g], b.my[g], b.zx[g], b.zy[g], w.s, w.c, w.px, w.py);
+            v2f ll = u.ll;
+            r0 = u.o0;
+            r1 = u.o1;
+            if (b.any_first[g]) {
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+                for (int t = 0; t < 2; ++t) {
+                    r0[t] = b.first[g][t] ? u.wx[t] : r0[t];
+                    r1[t] = b.first[g][t] ? u.wy[t] : r1[t];
+                    ll[t] = b.first[g][t] ? 0.0f : ll[t];
+                }
+            }
+            if (!b.all_obs[g]) {
 #pragma unroll
-                for (int p = 0; p < 5; ++p) row_store(w.rout, b.off[g][t], p * pl, b.m[g][p][t]);
-            continue;
+                for (int t = 0; t < 2; ++t) {
+                    r0[t] = b.obs[g][t] ? r0[t] : b.mx[g][t];
+                    r1[t] = b.obs[g][t] ? r1[t] : b.my[g][t];
+                    ll[t] = b.obs[g][t] ? ll[t] : 0.0f;
+                }
+            }
+            acc = acc + ll;
         }
-        const v2f q = q2;
-        const EkfResult<v2f> u = ekf_update_one<v2f, false>(mx, my, pxx, pxy, pyy, b.zx[g], b.zy[g], w.s, w.c, w.px, w.py, q);
-        v2f r0 = u.o0, r1 = u.o1, r2 = u.o2, r3 = u.o3, r4 = u.o4, ll = u.ll;
-        ekf_select(r0, r1, r2, r3, r4, ll, mx, my, pxx, pxy, pyy, b.zx[g], b.zy[g], w.s, w.c, w.px, w.py, q, b.obs[g][0], b.obs[g][1]);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             row_store(w.rout, b.off[g][t], 0 * pl, r0[t]);
             row_store(w.rout, b.off[g][t], 1 * pl, r1[t]);
-            row_store(w.rout, b.off[g][t], 2 * pl, r2[t]);
-            row_store(w.rout, b.off[g][t], 3 * pl, r3[t]);
-            row_store(w.rout, b.off[g][t], 4 * pl, r4[t]);
+            row_store(w.rout, b.off[g][t], 2 * pl, b.p2[g][t]);
+            row_store(w.rout, b.off[g][t], 3 * pl, b.p3[g][t]);
+            row_store(w.rout, b.off[g][t], 4 * pl, b.p4[g][t]);
         }
-        acc = acc + ll;
     }
 }
 
@@ -307,13 +360,17 @@ __device__ __forceinline__ float lane_value(float v, int k)   // lane k's value,
     return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), k));
 }
 
-// EKF_GROUP_WPE: waves per SIMD the register allocation is held to.  Left alone the kernel takes 82 VGPRs = 5 waves; held
-// to 6 (80 VGPRs, two dwords of scratch) it measured 149 -> 147 us at 64k x 500 and 4.13 -> 3.96 ms at 1M x 1000 in the
-// filter; held to 8 (64 VGPRs, 100 bytes of scratch) 295 us / 7.5 ms.
+// EKF_GROUP_NB: batches of 128 landmarks a wavefront of the grouped kernels holds in registers per pass; EKF_GROUP_WPE: waves
+// per SIMD the register allocation is held to.  With the pose-independent part of the update hoisted (ekf_prepare) a batch
+// costs 13 register pairs: two batches need 97 VGPRs (5 waves at 96 with two dwords of scratch), one batch 69 (7 waves).
+// Interleaved A/B on one box (profiles/ab.py, 64k x 500 in the filter): 2 batches at 5 waves — fused front 125.7 us
+// (0.1558 ms per frame), update alone 122-134 us; 1 batch at 7 waves — fused front 143.8 us (0.1678 ms), update alone
+// 125 us; 1M x 1000: 4.23 against 4.31 ms fused, 4.19 against 4.30 ms alone.  2 batches at 6 waves spill 13 dwords
+// (161-178 us), 1 batch at 8 waves 6 dwords (151-167 us).  Before the hoisting (sensor-frame arithmetic, 80 VGPRs, 2 batches
+// at 6 waves): fused front 148-153 us, update alone 133-149 us.
 #ifndef EKF_GROUP_WPE
-#define EKF_GROUP_WPE 6
+#define EKF_GROUP_WPE 5
 #endif
-// EKF_GROUP_NB: batches of 128 landmarks a wavefront of the grouped kernels holds in registers per pass (measurement builds)
 #ifndef EKF_GROUP_NB
 #define EKF_GROUP_NB 2
 #endif
@@ -385,23 +442,34 @@ __device__ __forceinline__ void ekf_group_body(const EkfArgs& a, int bid, float 
                 b.zy[g][t] = in ? vy : nan;
                 b.obs[g][t] = b.zx[g][t] == b.zx[g][t] && b.zy[g][t] == b.zy[g][t];
             }
+#pragma unroll
+        for (int g = 0; g < NB; ++g) {
+            b.any_obs[g] = __ballot(b.obs[g][0] || b.obs[g][1]) != 0;
+            b.all_obs[g] = __ballot(!(b.obs[g][0] && b.obs[g][1])) == 0;
+        }
         int prev = -1;
         for (int k = 0; k < nslots; ++k) {
             const int src = __builtin_amdgcn_readlane(src_l, k);
             if (src != prev) {   // a new ancestor: its batch into registers (wave-uniform branch)
                 const __amdgpu_buffer_rsrc_t rin =
                     __builtin_amdgcn_make_buffer_rsrc((void*)uniform_gptr(a.map_in + (int64_t)src * a.row_stride), 0, row_bytes, 0x00020000);
+                v2f pr[NB][3];
 #pragma unroll
                 for (int g = 0; g < NB; ++g)
 #pragma unroll
-                    for (int t = 0; t < 2; ++t)
+                    for (int t = 0; t < 2; ++t) {
+                        b.mx[g][t] = row_load(rin, b.off[g][t], 0 * pl);
+                        b.my[g][t] = row_load(rin, b.off[g][t], 1 * pl);
 #pragma unroll
-                        for (int p = 0; p < 5; ++p) b.m[g][p][t] = row_load(rin, b.off[g][t], p * pl);
+                        for (int p = 0; p < 3; ++p) pr[g][p][t] = row_load(rin, b.off[g][t], (2 + p) * pl);
+                    }
+#pragma unroll
+                for (int g = 0; g < NB; ++g) ekf_prepare<NB>(b, g, pr[g][0], pr[g][1], pr[g][2], q2);
                 prev = src;
             }
             const EkfPose w = pose_of(k);
             v2f acc = (v2f){s_acc[wave][k][lane], s_acc[wave][k][lane + 64]};
-            ekf_apply<NB>(b, w, pl, q2, acc);
+            ekf_apply<NB>(b, w, pl, acc);
             s_acc[wave][k][lane] = acc[0];
             s_acc[wave][k][lane + 64] = acc[1];
         }
