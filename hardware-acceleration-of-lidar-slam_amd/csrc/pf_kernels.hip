@@ -368,8 +368,10 @@ __device__ __forceinline__ float lane_value(float v, int k)   // lane k's value,
 // 125 us; 1M x 1000: 4.23 against 4.31 ms fused, 4.19 against 4.30 ms alone.  2 batches at 6 waves spill 13 dwords
 // (161-178 us), 1 batch at 8 waves 6 dwords (151-167 us).  Before the hoisting (sensor-frame arithmetic, 80 VGPRs, 2 batches
 // at 6 waves): fused front 148-153 us, update alone 133-149 us.
+// 4 waves (97 VGPRs, nothing spilled) against 5 on another, slower box: fused front 142.7 against 147.3 us, update alone
+// 145.0 against 146.3 us; equal at 2000 landmarks and with 32 of 500 observed.
 #ifndef EKF_GROUP_WPE
-#define EKF_GROUP_WPE 5
+#define EKF_GROUP_WPE 4
 #endif
 #ifndef EKF_GROUP_NB
 #define EKF_GROUP_NB 2
