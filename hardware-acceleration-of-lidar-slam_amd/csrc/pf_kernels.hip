@@ -514,7 +514,7 @@ __global__ __launch_bounds__(kEkfWaves * 64) EKF_GROUP_ATTR void ekf_update_grou
 // out-of-place landmark update side by side.  The two are bound by different units — the scorer by the texture addresser
 // (gathers out of L2), the update by HBM writes — and neither needs the other's output: both start from the resample
 // indices and the previous poses (the update works out its particles' motion samples itself).  As two launches they run one
-// after the other (a second stream with an event fork and join costs more than it wins: DESIGN.md section 11.4); here the
+// after the other (a second stream with an event fork and join costs more than it wins: DESIGN.md section 11.5); here the
 // workgroups of both kinds are dealt out interleaved — of every `score_octets + ekf_octets` consecutive octets of workgroups
 // (an octet = one workgroup per XCD) the scoring ones are spread evenly — so the gathers run in the shadow of the row
 // stores.  Same bits as the two launches (same device functions).

@@ -11,7 +11,8 @@ from pathlib import Path
 tag = sys.argv[1]
 here = Path(__file__).resolve().parent
 src = Path(sys.argv[2]) if len(sys.argv) > 2 else here.parent / "gpurun_out"
-f = sorted(glob.glob(str(src / f"{tag}_trace_pf" / "*" / "*kernel_trace.csv")))[-1]
+import os
+f = max(glob.glob(str(src / f"{tag}_trace_pf" / "*" / "*kernel_trace.csv")), key=os.path.getmtime)   # the newest run
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
 KEYS = ("score_poses", "ekf_update_group", "ekf_update_kernel", "logweight", "quantise_scan", "ancestors_from_scan", "obs_count")
 

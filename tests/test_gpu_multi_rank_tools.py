@@ -43,7 +43,8 @@ def test_bench_two_ranks_paged_local_transport():
                "--paged", "--observed", "32")
     assert r.returncode == 0, r.stderr[-2000:]
     out = json.loads(r.stdout.strip().splitlines()[-1])
-    assert out["n_gpus"] == 2 and out["roofline"]["kernel"] == "ekf_paged_kernel"
+    # at 8 192 particles per rank the paged update and the scorer take about as long as each other: either may be the dominant kernel
+    assert out["n_gpus"] == 2 and out["roofline"]["kernel"] in ("ekf_paged_kernel", "score_poses_kernel")
     assert out["config"]["map_layout"]["in_timed_region"].startswith("pages")
 
 
