@@ -607,8 +607,9 @@ def run_rank(args, ctx, inp):
     settle(torch)
     # Pre-roll: the filter starts from poses spread 5 cm / 0.01 rad around the truth and needs on the order of a
     # hundred frames to settle to the spread its motion noise and its observations sustain; until then neighbouring particles
-    # lie farther apart, the scorer's gathers of a wavefront fall into more cache lines and a frame takes up to 20 % longer
-    # (front kernel 193 us at frame 3, 175 at 40, 160 at 90, 155 at 140: profiles/r03_early_frames.md).  The metric is a
+    # lie farther apart, the scorer's gathers of a wavefront fall into more cache lines and a frame takes up to 10 % longer
+    # (front kernel 156-161 us over the first 30 frames, 147 at 40-50, 143-145 from 90 on: profiles/r03_early_frames.md;
+    # with the sensor-frame update of rounds 1-2 it was 193 us at frame 3 and 154 at 140).  The metric is a
     # steady-state rate, so these frames run before the W warm-up steps, untimed; --preroll 0 starts cold.
     for k in range(-off, 0):
         one_step(k)

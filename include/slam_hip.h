@@ -202,7 +202,10 @@ int slam_motion_score_dev(slam_engine *e, int slot, const float *d_src_x, const 
                           float *d_score, int32_t *d_count);
 
 /* A10: per-particle x per-landmark 2x2 EKF correction (FastSLAM 1.0, known correspondences,
- * cartesian sensor-frame observations z = H (m - t), H = [[ct,-st],[st,ct]]).
+ * cartesian sensor-frame observations z = H (m - t), H = [[ct,-st],[st,ct]], noise R = meas_var * I).  H being a rotation
+ * and R isotropic, the update is carried out in the world frame: w = t + H^T z, S = P + R, W = P S^-1, mu' = mu + W (w - mu),
+ * P' = (I - W) P, log-likelihood term -1/2 (w - mu)^T S^-1 (w - mu) - 1/2 log det S - log 2 pi — the sensor-frame Kalman
+ * update in other words, in the fixed operation order of csrc/ekf_math.h == oracle/slam_oracle_pf.c.
  * The observations of the current frame are sensor data like the scan: hand them over once per frame,
  * either as a list from the host (slam_obs_upload_host: landmark ids unique and < nlandmarks, no NaN
  * measurements, nlandmarks <= SLAM_MAX_OBS) or as a table that is already on the device
