@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 DEV = torch.device("cuda", 0)
 
 
-def _run(fused, n, L, frames, form=-1):
+def _run(fused, n, L, frames, form=-1, nbeams=None):
     import _shard_worker as W
 
     pkg = load_package()
@@ -25,7 +25,7 @@ def _run(fused, n, L, frames, form=-1):
     eng.frame_fusion_set(fused)
     eng.ekf_form_set(form)
     eng.grid_set_dev(0, torch.from_numpy(edt).to(DEV), pkg.grid_meta(meta.rows, meta.cols, meta.ld, meta.pixel, meta.min_x, meta.min_y))
-    eng.scan_upload(bx, by)
+    eng.scan_upload(bx[:nbeams], by[:nbeams]) if nbeams else eng.scan_upload(bx, by)
     ses = pkg.PfSession(eng, n, L, seed=91, sigma=(0.02, 0.02, 0.004), meas_var=0.02, score_gain=0.05, map_layout="rows")
     ses.set_poses(x, y, th)
     ses.set_map(mp)
@@ -49,11 +49,12 @@ def _run(fused, n, L, frames, form=-1):
     return out
 
 
-@pytest.mark.parametrize("n,L,form", [(16384, 300, -1), (16384, 300, 2), (16384, 300, 1), (5000, 513, -1), (140000, 200, -1)])
-def test_fused_front_gives_the_bits_of_the_two_launches(n, L, form):
+@pytest.mark.parametrize("n,L,form,nbeams", [(16384, 300, -1, None), (16384, 300, 2, None), (16384, 300, 1, None), (5000, 513, -1, None),
+                                              (140000, 200, -1, None), (3073, 130, -1, 37), (4099, 129, 1, 1)])
+def test_fused_front_gives_the_bits_of_the_two_launches(n, L, form, nbeams):
     frames = 7
-    two = _run(False, n, L, frames, form)
-    one = _run(True, n, L, frames, form)
+    two = _run(False, n, L, frames, form, nbeams)
+    one = _run(True, n, L, frames, form, nbeams)
     assert two["fused_launches"] == 0
     assert one["fused_launches"] == frames - 1, one["fused_launches"]   # the first frame has no resample indices yet
     assert np.array_equal(bits(one["pose"]), bits(two["pose"]))
