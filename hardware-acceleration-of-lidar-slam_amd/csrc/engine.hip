@@ -768,7 +768,7 @@ int slam_ekf_update_dev(slam_engine* e, const float* d_map_in, float* d_map_out,
         }
         e->ekf_inplace_launches[sparse ? 1 : 0]++;
     } else {
-        const int group = nlandmarks > 128 ? e->ekf_group_size(n, d_anc != nullptr) : 0;
+        const int group = nlandmarks > 128 ? e->ekf_group_size(n, d_anc != nullptr, plane_stride, false) : 0;
         HIP_TRY(launch_ekf_update(e->stream, a, e->prof_next(SLAM_PROF_EKF), group));
         e->ekf_form_launches[group ? 1 : 0]++;
     }
@@ -796,7 +796,7 @@ int slam_frame_front_dev(slam_engine* e, int slot, const float* d_src_x, const f
         return SLAM_OK;
     if (int rc = check_score_inputs(e, slot)) return rc;
     if (e->obs_nlandmarks < 0 || e->obs_nlandmarks != nlandmarks) return SLAM_ERR_NOT_READY;
-    const int group = e->ekf_group_size(n, true);
+    const int group = e->ekf_group_size(n, true, plane_stride, true);
     if (!frame_front_fits(n, nlandmarks, group)) return SLAM_OK;
     HIP_TRY(e->ll_buf.ensure(sizeof(float) * (size_t)n));
     EkfArgs a;

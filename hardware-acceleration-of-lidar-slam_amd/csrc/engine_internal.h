@@ -141,14 +141,21 @@ struct slam_engine {
     bool pf_paged = false;     // slam_pf_paged_set: sessions made from now on keep their maps as copy-on-write pages
     int ekf_form = -1;         // slam_ekf_form_set: -1 choose by the feedback, 0 row per wavefront, 1 / 2 grouped by 4 / 2
     int64_t ekf_form_launches[2] = { 0, 0 };   // out-of-place launches so far: [0] one wavefront per particle, [1] grouped
-    // particles per wavefront of an out-of-place update that gathers through `anc` (0 = one wavefront per particle): 4 when
-    // neighbours share ancestors (fewer than 3 distinct in 10 slots, as far as the last resample stage reported), else 2
-    int ekf_group_size(int n, bool has_anc) const
+    // particles per wavefront of an out-of-place update that gathers through `anc` (0 = one wavefront per particle).  With the
+    // covariance part of the update hoisted (ekf_prepare) the kernel is memory-bound and behaves like the grouped pure copy of
+    // profiles/copy_ceiling.hip: 2 rows per wavefront beat 4 and 8 (update alone at 64k x 500: 133 | 145 | 155 us; fused
+    // front at 512k x 5000: 8.10 against 9.00 ms, at 64k x 2000: 0.558 against 0.578 ms per frame) — except in the fused
+    // front of a small frame, where 4 keep the number of updating workgroups per scoring workgroup low (64k x 500: 143
+    // against 160 us) as long as neighbours share ancestors (fewer than 3 distinct in 10 slots, as far as the last resample
+    // stage reported).
+    int ekf_group_size(int n, bool has_anc, int plane_stride, bool fused) const
     {
         if (ekf_form >= 0) return ekf_form == 0 ? 0 : (ekf_form == 2 ? 2 : 4);
         if (!has_anc) return 0;
+        if (!fused) return 2;
         const int heads = h_heads[0], hn = h_heads[1];
-        return hn == n && (int64_t)heads * 10 < (int64_t)n * 3 ? 4 : 2;
+        const bool few_distinct = hn == n && (int64_t)heads * 10 < (int64_t)n * 3;
+        return few_distinct && (int64_t)n * plane_stride < (int64_t)1 << 26 ? 4 : 2;
     }
 
     slam::GateOut gate_next()
