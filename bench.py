@@ -38,7 +38,8 @@ One JSON line on stdout (rank 0).  Beyond the contract's fields:
                 the EKF sweep at 1 048 576 x 1 000, a pure copy of the same shape, and the configs[1] frame with the 32
                 nearest landmarks observed on rows and on pages; `headline_round2_method`: configs[1] measured the way
                 BENCH_r01 / BENCH_r02 were (cold filter, 5 + 20 frames, every frame bracketed), as two launches and fused.
-                They never touch `value`.
+                `sharded_rehearsal_2_ranks_one_card`: the sharded session (two ranks as threads on this card, in-process
+                transport) with its per-stage timers, run as a child process.  They never touch `value`.
   cpu_baseline  the CPU port of the same frame loop (oracle/, one thread) on a bounded sample; cpu_baseline_threads:
                 its per-particle stages on up to 16 host threads; cpu_baseline_main_c: the reference's own pipeline
                 (main.c rows A1-A8) on this host's CPU — the compiled reference when oracle/_ref/ travelled here, and
@@ -831,7 +832,31 @@ def run_rank(args, ctx, inp):
     torch.cuda.synchronize()
     ctx.finish()
     eng.close()
+    if legs_ok and args.mode == "pf" and not args.no_extra_legs and not args.force_collectives:
+        out["sharded_rehearsal_2_ranks_one_card"] = sharded_rehearsal(args)
     return out
+
+
+def sharded_rehearsal(args):
+    """The sharded code path on THIS box, in the driver's record: `bench.py --gpus 2 --transport local` as a child process —
+    two ranks of the C session as threads sharing this card through the in-process transport, every exchange step of a frame
+    (all-reduce, all-gathers, exchange plan, rows packed, sent and unpacked) and the per-stage timers.  Not a scaling figure:
+    the ranks share one GPU and the transport is device copies behind a host rendezvous; RCCL between ranks needs more than
+    one GPU."""
+    cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--transport", "local", "--steps", "40", "--warmup", "10",
+           "--particles", "32768", "--no-cpu-baseline", "--no-extra-legs", "--no-sweep", "--settle-ms", str(args.settle_ms)]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode != 0 or not line:
+            return {"error": (r.stderr or r.stdout)[-300:]}
+        d = json.loads(line[-1])
+        return {"command": "bench.py " + " ".join(cmd[2:]), "n_gpus": d["n_gpus"], "transport": d["config"]["transport"],
+                "particles_total": d["config"]["particles_total"], "ms_per_step": d["ms_per_step"],
+                "rows_received_per_frame_max_rank": d["config"]["rows_received_per_frame_max_rank"],
+                "stage_avg_ms": d["stage_avg_ms"], "note": "rehearsal of the sharded path on one card, not a scaling figure"}
+    except Exception as ex:
+        return {"error": f"{type(ex).__name__}: {ex}"}
 
 
 def extra_legs(args, torch, pkg, eng, dev, inp, kernel_ms):
