@@ -15,12 +15,19 @@ pytestmark = pytest.mark.gpu
 DEV = torch.device("cuda", 0)
 
 
-def _run(fused, n, L, frames, form=-1, nbeams=None):
+def _run(fused, n, L, frames, form=-1, nbeams=None, random_cov=False):
     import _shard_worker as W
 
     pkg = load_package()
     meta, edt, bx, by, lm = W.make_world(L=L)
     x, y, th, mp = W.init_state(n, L, lm)
+    if random_cov:   # every particle its own covariances (symmetric positive definite) and its own unseen landmarks
+        rng0 = np.random.default_rng(17)
+        a = (0.02 + 0.2 * rng0.random((n, L))).astype(np.float32)
+        c = (0.02 + 0.2 * rng0.random((n, L))).astype(np.float32)
+        mp[:, 2], mp[:, 4] = a, c
+        mp[:, 3] = ((rng0.random((n, L)) - 0.5) * np.sqrt(a * c)).astype(np.float32)
+        mp[:, 2][rng0.random((n, L)) < 0.05] = -1.0
     eng = pkg.Engine(0)
     eng.frame_fusion_set(fused)
     eng.ekf_form_set(form)
@@ -70,3 +77,19 @@ def test_shapes_the_fused_front_does_not_take():
     assert _run(True, 4096, 100, 4)["fused_launches"] == 0
     assert _run(True, 2048, 300, 4)["fused_launches"] == 0
     assert _run(True, 16384, 300, 4, form=0)["fused_launches"] == 0
+
+
+@pytest.mark.parametrize("n,L", [(16384, 300), (6000, 700)])
+def test_hoisted_grouped_update_equals_the_update_of_one_particle_at_a_time(n, L):
+    """The grouped kernels work out the covariance part of the update once per source row (ekf_prepare); the kernel with one
+    wavefront per particle (ekf form 0) does everything per particle.  Same bits, with covariances and unseen landmarks that
+    differ from particle to particle."""
+    frames = 6
+    per_particle = _run(False, n, L, frames, form=0, random_cov=True)
+    for fused, form in ((True, -1), (False, 1), (False, 2)):
+        grouped = _run(fused, n, L, frames, form=form, random_cov=True)
+        assert np.array_equal(bits(grouped["pose"]), bits(per_particle["pose"]))
+        for f, m in per_particle["maps"].items():
+            assert np.array_equal(bits(grouped["maps"][f]), bits(m)), (fused, form, f)
+        for a, b in zip(grouped["best"], per_particle["best"]):
+            assert a[2] == b[2] and a[1] == b[1] and np.array_equal(bits(a[0]), bits(b[0]))
