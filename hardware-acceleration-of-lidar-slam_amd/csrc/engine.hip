@@ -7,6 +7,7 @@
 // (Submodule_2/Hadrware_acclereated.cpp:842-845).  There is no CPU fallback anywhere in this file.
 
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -84,6 +85,37 @@ void philox_host(uint32_t c[4], uint32_t k0, uint32_t k1)
 
 }  // namespace
 
+// Every pinned host buffer of the engine comes out of ONE allocation (mapped into the device): an allocation of pinned host
+// memory is answered by the driver some 10-50 ms later with a 65-80 ms hold of the process's queues (DESIGN.md section 8,
+// profiles/r03_stall_trigger.txt), so the engine makes one, when it is created, instead of eight.
+static hipError_t engine_host_block(slam_engine* e)
+{
+    auto up = [](size_t b) { return (b + 255) / 256 * 256; };
+    const size_t b_fm = up(sizeof(float) * (kFmIn + kFmOut + 4)), b_plan = up(sizeof(int32_t) * (SLAM_PLAN_WORDS(kMaxRanks) + 1)),
+                 b_small = 256, b_res = 256, b_stage = up(sizeof(float) * kStageSlots * kStageFloats);
+    const size_t total = b_fm + b_plan + 3 * b_small + b_res + b_stage;
+    hipError_t err = hipHostMalloc(&e->h_block, total, hipHostMallocMapped);
+    if (err != hipSuccess) return err;
+    void* dblock = nullptr;
+    if ((err = hipHostGetDevicePointer(&dblock, e->h_block, 0)) != hipSuccess) return err;
+    char *h = static_cast<char*>(e->h_block), *d = static_cast<char*>(dblock);
+    size_t off = 0;
+    auto take = [&](size_t bytes, auto*& hp, auto*& dp) {
+        hp = reinterpret_cast<std::remove_reference_t<decltype(hp)>>(h + off);
+        dp = reinterpret_cast<std::remove_reference_t<decltype(dp)>>(d + off);
+        off += bytes;
+    };
+    take(b_fm, e->h_fm, e->d_hfm);
+    take(b_plan, e->h_plan, e->d_hplan);
+    take(b_small, e->h_gate, e->d_hgate);
+    take(b_small, e->h_heads, e->d_hheads);
+    take(b_small, e->h_obs, e->d_hobs);
+    take(b_res, e->h_pf_res, e->d_hpf_res);
+    e->h_stage = reinterpret_cast<float*>(h + off);
+    memset(e->h_block, 0, total);
+    return hipSuccess;
+}
+
 extern "C" {
 
 int slam_abi_version(void) { return SLAM_ABI_VERSION; }
@@ -135,24 +167,11 @@ int slam_engine_create(int device, slam_engine** out)
     if (hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking) != hipSuccess ||
         e->fm_buf.ensure(sizeof(float) * (kFmIn + kFmOut)) != hipSuccess ||
         e->fm_work.ensure(sizeof(float) * kLattice * SLAM_MAX_BEAMS) != hipSuccess ||
-        hipHostMalloc((void**)&e->h_fm, sizeof(float) * (kFmIn + kFmOut + 4), hipHostMallocMapped) != hipSuccess ||
-        hipHostGetDevicePointer((void**)&e->d_hfm, e->h_fm, 0) != hipSuccess ||
-        hipHostMalloc((void**)&e->h_plan, sizeof(int32_t) * (SLAM_PLAN_WORDS(kMaxRanks) + 1), hipHostMallocMapped) != hipSuccess ||
-        hipHostGetDevicePointer((void**)&e->d_hplan, e->h_plan, 0) != hipSuccess ||
-        hipHostMalloc((void**)&e->h_gate, sizeof(int32_t) * 2, hipHostMallocMapped) != hipSuccess ||
-        hipHostGetDevicePointer((void**)&e->d_hgate, e->h_gate, 0) != hipSuccess ||
+        engine_host_block(e) != hipSuccess ||
         e->gate_buf.ensure(kGateBufWords * sizeof(int32_t)) != hipSuccess ||   // flag | ticket | accumulators: see kernels.h
-        hipHostMalloc((void**)&e->h_heads, sizeof(int32_t) * 2, hipHostMallocMapped) != hipSuccess ||
-        hipHostGetDevicePointer((void**)&e->d_hheads, e->h_heads, 0) != hipSuccess ||
-        hipHostMalloc((void**)&e->h_obs, sizeof(int32_t) * 2, hipHostMallocMapped) != hipSuccess ||
-        hipHostGetDevicePointer((void**)&e->d_hobs, e->h_obs, 0) != hipSuccess ||
-        hipHostMalloc(&e->h_pf_res, 128, hipHostMallocMapped) != hipSuccess ||
-        hipHostGetDevicePointer(&e->d_hpf_res, e->h_pf_res, 0) != hipSuccess ||
         e->heads_buf.ensure(2 * sizeof(int32_t)) != hipSuccess ||
         hipMemset(e->heads_buf.p, 0, 2 * sizeof(int32_t)) != hipSuccess ||   // the gate's flag + the ticket word of quantise_scan_kernel
-        e->scan_buf.ensure(sizeof(float) * 2 * SLAM_MAX_BEAMS) != hipSuccess ||
-        hipHostMalloc((void**)&e->h_stage, sizeof(float) * kStageSlots * kStageFloats, hipHostMallocDefault) !=
-            hipSuccess) {
+        e->scan_buf.ensure(sizeof(float) * 2 * SLAM_MAX_BEAMS) != hipSuccess) {
         snprintf(g_create_err, sizeof g_create_err, "allocating the engine's buffers on device %d: %s", device,
                  hipGetErrorString(hipGetLastError()));
         slam_engine_destroy(e);
@@ -201,7 +220,6 @@ int slam_engine_destroy(slam_engine* e)
     e->ll_buf.release();
     e->shard_buf.release();
     e->first_buf.release();
-    if (e->h_stage) (void)hipHostFree(e->h_stage);
     for (auto& ev : e->stage_ev)
         if (ev) (void)hipEventDestroy(ev);
     for (auto& b : e->host_io) b.release();
@@ -210,12 +228,7 @@ int slam_engine_destroy(slam_engine* e)
             (void)hipEventDestroy(p.start);
             (void)hipEventDestroy(p.stop);
         }
-    if (e->h_fm) (void)hipHostFree(e->h_fm);
-    if (e->h_plan) (void)hipHostFree(e->h_plan);
-    if (e->h_gate) (void)hipHostFree(e->h_gate);
-    if (e->h_heads) (void)hipHostFree(e->h_heads);
-    if (e->h_obs) (void)hipHostFree(e->h_obs);
-    if (e->h_pf_res) (void)hipHostFree(e->h_pf_res);
+    if (e->h_block) (void)hipHostFree(e->h_block);   // every pinned buffer of the engine at once
     e->obs_list.release();
     e->heads_buf.release();
     e->gate_buf.release();

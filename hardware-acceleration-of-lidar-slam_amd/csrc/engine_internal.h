@@ -130,6 +130,7 @@ struct slam_engine {
     // 128 bytes of mapped host memory the engine's (one) particle-filter session delivers its results through.  It belongs to
     // the ENGINE, not to the session: freeing pinned host memory makes the driver hold the process's queues for 65-80 ms some
     // 10-50 ms later (profiles/r03_stall_trigger.txt) — a session that came and went would stall the frames of the next one.
+    void* h_block = nullptr;        // the one pinned allocation every h_* pointer of the engine points into
     void* h_pf_res = nullptr;
     void* d_hpf_res = nullptr;
     bool frame_fusion = true;       // slam_frame_fusion_set
