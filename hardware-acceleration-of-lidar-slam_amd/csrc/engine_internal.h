@@ -147,8 +147,8 @@ struct slam_engine {
     // profiles/copy_ceiling.hip: 2 rows per wavefront beat 4 and 8 (update alone at 64k x 500: 133 | 145 | 155 us; fused
     // front at 512k x 5000: 8.10 against 9.00 ms, at 64k x 2000: 0.558 against 0.578 ms per frame) — except in the fused
     // front of a small frame, where 4 keep the number of updating workgroups per scoring workgroup low (64k x 500: 143
-    // against 160 us) as long as neighbours share ancestors (fewer than 3 distinct in 10 slots, as far as the last resample
-    // stage reported).
+    // against 160 us; 3 particles per wavefront: 143.5 against 142.6 us fused, 138 against 134 us alone) as long as neighbours
+    // share ancestors (fewer than 3 distinct in 10 slots, as far as the last resample stage reported).
     int ekf_group_size(int n, bool has_anc, int plane_stride, bool fused) const
     {
         if (ekf_form >= 0) return ekf_form == 0 ? 0 : (ekf_form == 2 ? 2 : 4);
