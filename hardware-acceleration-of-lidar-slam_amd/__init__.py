@@ -111,6 +111,7 @@ SIGNATURES = {
     "slam_selftest_reciprocal": (_i, [_vp, _vp, _vp]),
     "slam_frame_fusion_set": (_i, [_vp, _i]),
     "slam_frame_fusion_count": (_i, [_vp, _vp]),
+    "slam_frame_front_last": (_i, [_vp, _vp]),
     "slam_ekf_inplace_form_set": (_i, [_vp, _i]),
     "slam_pf_paged_set": (_i, [_vp, _i]),
     "slam_pf_is_paged": (_i, [_vp]),
@@ -420,6 +421,12 @@ class Engine:
         """The front of a single-GPU frame on rows (motion + score and the landmark update) as one launch (default) or two."""
         self._ck(self.lib.slam_frame_fusion_set(self.h, 1 if on else 0), "frame_fusion_set")
 
+    def frame_front_last(self):
+        """(particles per updating wavefront, lanes per pose) of the last fused front launch; (0, 0) before the first."""
+        info = (C.c_int32 * 2)()
+        self._ck(self.lib.slam_frame_front_last(self.h, info), "frame_front_last")
+        return int(info[0]), int(info[1])
+
     def frame_fusion_count(self) -> int:
         c = C.c_int64(0)
         self._ck(self.lib.slam_frame_fusion_count(self.h, C.byref(c)), "frame_fusion_count")
@@ -516,7 +523,7 @@ class PfView(C.Structure):
 
     _fields_ = [("pose", C.c_void_p), ("map", C.c_void_p), ("map_spare", C.c_void_p), ("anc", C.c_void_p), ("row_stride", C.c_int64),
                 ("plane_stride", C.c_int32), ("map_rows", C.c_int32), ("score", C.c_void_p), ("logw", C.c_void_p),
-                ("loglik", C.c_void_p)]
+                ("loglik", C.c_void_p), ("count", C.c_void_p)]
 
 
 class PfPagedView(C.Structure):
@@ -644,6 +651,7 @@ class PfSession:
                 "score": DeviceArray(v.score, (self.n,), "<f4", self) if v.score else None,
                 "logw": DeviceArray(v.logw, (self.n,), "<f4", self) if v.logw else None,
                 "loglik": DeviceArray(v.loglik, (self.n,), "<f4", self) if v.loglik else None,
+                "count": DeviceArray(v.count, (self.n,), "<i4", self) if v.count else None,
                 "plane_stride": v.plane_stride, "row_stride": v.row_stride}
 
     def paged_view(self):

@@ -195,7 +195,10 @@ int comm_wait_stream(slam_comm* c)
     for (long spin = 0;; ++spin) {
         const hipError_t q = hipStreamQuery(c->e->stream);
         if (q == hipSuccess) return SLAM_OK;
-        if (q != hipErrorNotReady) return slam_engine_fail_hip(c->e, q, "hipStreamQuery");
+        if (q != hipErrorNotReady) {   // this rank cannot go on: release the peers before reporting
+            comm_abort(c);
+            return slam_engine_fail_hip(c->e, q, "hipStreamQuery");
+        }
         if ((spin & 1023) == 1023) {
             if (int rc = comm_poll(c)) return rc;
             if (now_s() - t0 > c->timeout_s) {

@@ -830,10 +830,13 @@ int slam_frame_front_dev(slam_engine* e, int slot, const float* d_src_x, const f
     a.loglik_user = nullptr;
     a.xcd_chunk = 0;
     MotionIO io{ d_src_x, d_src_y, d_src_th, d_anc, d_x, d_y, d_th };
+    int lanes = 0;
     // one bracket for the whole launch: it counts as the frame's landmark update (the dominant stage)
     HIP_TRY(launch_frame_front(e->stream, score_grid(e->grid[slot]), e->d_bx, e->d_by, e->nbeams, io, first_id, dp, sigma, seed,
-                               frame, d_score, d_count, a, group, e->prof_next(SLAM_PROF_EKF), launched));
+                               frame, d_score, d_count, a, group, e->prof_next(SLAM_PROF_EKF), launched, &lanes));
     if (*launched) {
+        e->front_last[0] = group;
+        e->front_last[1] = lanes;
         e->ll_n = n;
         e->ekf_form_launches[1]++;
         e->front_launches++;
@@ -854,6 +857,15 @@ int slam_frame_fusion_count(slam_engine* e, int64_t* launches)
     ENTER(e);
     if (!launches) return SLAM_ERR_INVALID_ARG;
     *launches = e->front_launches;
+    return SLAM_OK;
+}
+
+int slam_frame_front_last(slam_engine* e, int32_t info[2])
+{
+    ENTER(e);
+    if (!info) return SLAM_ERR_INVALID_ARG;
+    info[0] = e->front_last[0];
+    info[1] = e->front_last[1];
     return SLAM_OK;
 }
 

@@ -135,6 +135,7 @@ struct slam_engine {
     void* d_hpf_res = nullptr;
     bool frame_fusion = true;       // slam_frame_fusion_set
     int64_t front_launches = 0;
+    int32_t front_last[2] = { 0, 0 };   // slam_frame_front_last: particles per updating wavefront, lanes per pose
     int ekf_inplace_form = -1;   // slam_ekf_inplace_form_set: -1 by the feedback, 0 whole rows, 1 observed landmarks only
     int64_t ekf_inplace_launches[2] = { 0, 0 };
     slam_comm* comm = nullptr; // the communicator made on this engine, if any: host-side waits poll it for failures

@@ -87,6 +87,18 @@ struct EkfArgs {
     float* loglik;        // [n], always written
     float* loglik_user;   // optional second copy for the caller
     int xcd_chunk;        // set by the launcher: workgroups per XCD when the grid is renumbered XCD-contiguously, else 0
+    // ---- split layout (cov != nullptr; split_kernels.hip): map_in / map_out hold the MEANS only — rows of two planes
+    // (mu_x, mu_y) of plane_stride floats, row_stride floats apart — and the covariance planes (P_xx, P_xy, P_yy) exist once
+    // per COVARIANCE CLASS: in the world-frame update the posterior covariance of a landmark depends on its prior covariance,
+    // on q and on whether the frame observes it, never on the particle, so particles whose covariances were equal once stay
+    // equal for ever and share one row cov[class].  The update reads it (launch_cov_update rewrites it afterwards, once per
+    // class), hands the class of the source particle on to its offspring and marks it as still in use.
+    const float* cov = nullptr;       // [classes][3][plane_stride]
+    int64_t cov_stride = 0;           // floats between the rows of two classes
+    const int32_t* cls_in = nullptr;  // class of every source particle
+    int32_t* cls_out = nullptr;       // class of every particle of this frame
+    uint32_t* cstamp = nullptr;       // [classes]: stamp_now = "a particle of this frame belongs to the class"
+    uint32_t stamp_now = 0;
 };
 // group_size: 0 = one wavefront per particle; 2 / 4 / 8 = the grouped out-of-place form (that many neighbouring particles
 // per wavefront share their source rows in registers) — a speed choice only, every form gives the same bits
@@ -100,7 +112,48 @@ bool frame_front_fits(int n, int nlandmarks, int group_size);   // the shapes la
 hipError_t launch_frame_front(hipStream_t stream, const ScoreGrid& g, const float* bx, const float* by, int nbeams,
                               const MotionIO& io, int64_t first_id, const float dp[3], const float sigma[3], uint64_t seed,
                               uint32_t frame, float* score, int32_t* count, const EkfArgs& a, int group_size,
-                              const EventPair* ev, bool* launched);
+                              const EventPair* ev, bool* launched, int* lanes_per_pose = nullptr);
+
+// ---- split_kernels.hip: the covariance classes of the split layout (see EkfArgs)
+// The posterior covariance of every class that is still in use, in place, once per class: P' = (I - W) P for an observed
+// landmark seen before, q I for a first sighting, the prior without an observation — the values every particle of the class
+// would have written into its own row (ekf_math.h: ekf_shared).  `live`: the classes that were in use after the previous
+// frame, cnt[phase] of them; those that still are (cstamp == stamp_now) are updated and appended to the next list (cnt[(phase
+// + 1) % 3]; cnt[(phase + 2) % 3] is zeroed for the frame after).  bound >= cnt[phase]: the launch's width (the host's stale
+// knowledge is good enough: the list only shrinks).  h_live (mapped host memory): {cnt[phase], epoch}.
+struct CovArgs {
+    float* cov;
+    int64_t cov_stride;
+    int plane_stride, nlandmarks;
+    const float *obs_zx, *obs_zy;
+    float meas_var;
+    const int32_t* live_in;
+    int32_t* live_out;
+    int32_t* cnt;          // [3]
+    int phase;
+    const uint32_t* cstamp;
+    uint32_t stamp_now;
+    int32_t* h_live;
+    uint32_t epoch;
+};
+hipError_t launch_cov_update(hipStream_t stream, const CovArgs& a, int bound, const EventPair* ev = nullptr);
+// rows [n][5][plane_stride_in] (row_stride_in floats apart) -> means [n][2][Lp], classes, class rows [..][3][Lp]: neighbouring
+// particles whose three covariance planes are equal bit for bit share a class (classes are numbered 0, 1, .. in particle
+// order; all particles alike -> one class).  scratch: split_scratch_words(n) int32 words.  live[k] = k, cnt[phase] = number
+// of classes (cnt[other] = 0), every class stamped stamp_now; h_live = {classes, epoch}.
+size_t split_scratch_words(int n);
+hipError_t launch_split_from_rows(hipStream_t stream, const float* rows, int64_t row_stride_in, int plane_stride_in, int nlandmarks,
+                                  int n, int Lp, float* mean, float* cov, int32_t* cls, int32_t* live, int32_t* cnt, int phase,
+                                  uint32_t* cstamp, uint32_t stamp_now, int32_t* h_live, uint32_t epoch, void* scratch);
+// out row k = [means of particle idx[k] (or k) | the covariance planes of its class], nlandmarks columns of each plane
+hipError_t launch_rows_from_split(hipStream_t stream, const float* mean, const float* cov, const int32_t* cls, int Lp,
+                                  const int32_t* idx, int count, float* rows, int64_t row_stride, int plane_stride, int nlandmarks);
+// a frame without a landmark update: means and classes follow their particles (out[i] = in[anc[i]])
+hipError_t launch_split_gather(hipStream_t stream, const float* mean_in, float* mean_out, const int32_t* cls_in, int32_t* cls_out,
+                               int Lp, const int32_t* anc, int n, uint32_t* cstamp, uint32_t stamp_now);
+// every particle: all landmarks "not seen yet", one class
+hipError_t launch_split_reset(hipStream_t stream, float* mean, float* cov, int32_t* cls, int Lp, int n, int32_t* live, int32_t* cnt,
+                              int phase, uint32_t* cstamp, uint32_t stamp_now, int32_t* h_live, uint32_t epoch);
 
 // carry / prev_resampled (optional): see logweight_kernel — the weights a frame without resample left behind
 // In-place update of the OBSERVED landmarks only (frames that keep their population): the observation table is first

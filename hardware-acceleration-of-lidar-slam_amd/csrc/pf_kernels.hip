@@ -510,6 +510,193 @@ __global__ __launch_bounds__(kEkfWaves * 64) EKF_GROUP_ATTR void ekf_update_grou
     ekf_group_body<NB, G, false>(a, bid, s_acc, MotionIO{}, MotionParams{});
 }
 
+// ---- the same grouped update on the SPLIT layout (EkfArgs::cov != nullptr): a particle's row holds its landmark MEANS only,
+// the covariance planes exist once per covariance class (kernels.h; the classes' own update: split_kernels.hip).  Per particle
+// and landmark the update then reads 8 bytes (the ancestor's means, kept in registers for the offspring in the group) and
+// writes 8, instead of 20 and 20; the class's covariance row — the same few KB for every wavefront once the population
+// descends from few classes — comes out of L2.  Arithmetic, operation order and log-likelihood summation are those of
+// ekf_group_body (ekf_shared + ekf_particle): the same bits.  Rows are walked in whole passes of NB batches up to L; lanes
+// whose landmarks lie beyond the row's planes get the buffer offset 0xffffffff, which the hardware's range check turns into
+// "load 0, drop the store" (score_body.h uses the same device), so no pass needs a predicated form.
+template <int NB>
+struct SplitBatch {
+    v2f mx[NB], my[NB];        // prior means of the current source row
+    EkfShared<v2f> sh[NB];     // the pose-independent part of the update, from the current class's covariance row
+    v2f zx[NB], zy[NB];
+    bool obs[NB][2], first[NB][2];
+    bool any_obs[NB], all_obs[NB], any_first[NB];   // wave-uniform
+    unsigned off[NB][2];
+};
+
+template <int NB>
+__device__ __forceinline__ void split_apply(const SplitBatch<NB>& b, const EkfPose& w, int pl, v2f& acc)
+{
+#pragma unroll
+    for (int g = 0; g < NB; ++g) {
+        v2f r0 = b.mx[g], r1 = b.my[g];
+        if (b.any_obs[g]) {
+            const EkfParticle<v2f> u = ekf_particle<v2f>(b.sh[g], b.mx[g], b.my[g], b.zx[g], b.zy[g], w.s, w.c, w.px, w.py);
+            v2f ll = u.ll;
+            r0 = u.o0;
+            r1 = u.o1;
+            if (b.any_first[g]) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    r0[t] = b.first[g][t] ? u.wx[t] : r0[t];
+                    r1[t] = b.first[g][t] ? u.wy[t] : r1[t];
+                    ll[t] = b.first[g][t] ? 0.0f : ll[t];
+                }
+            }
+            if (!b.all_obs[g]) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    r0[t] = b.obs[g][t] ? r0[t] : b.mx[g][t];
+                    r1[t] = b.obs[g][t] ? r1[t] : b.my[g][t];
+                    ll[t] = b.obs[g][t] ? ll[t] : 0.0f;
+                }
+            }
+            acc = acc + ll;
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            row_store(w.rout, b.off[g][t], 0, r0[t]);
+            row_store(w.rout, b.off[g][t], pl, r1[t]);
+        }
+    }
+}
+
+template <int NB, int G, bool OWN_MOTION>
+__device__ __forceinline__ void ekf_split_body(const EkfArgs& a, int bid, float (*s_acc)[G][128], const MotionIO& mio,
+                                               const MotionParams& mpar)
+{
+    const unsigned lane = threadIdx.x & 63u;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int g0 = (bid * kEkfWaves + wave) * G;
+    if (g0 >= a.n) return;
+    const int nslots = a.n - g0 < G ? a.n - g0 : G;
+    // lane k prepares particle g0 + k: source row, class, pose; read back with v_readlane below
+    const int mine = g0 + ((int)lane < nslots ? (int)lane : 0);
+    const int src_l = a.anc ? a.anc[mine] : mine;
+    const int cls_l = a.cls_in[src_l];
+    float st_l, ct_l, px_l, py_l;
+    if constexpr (OWN_MOTION) {
+        float th_l;
+        motion_sample_one(mpar, (uint64_t)mine, mio.sx[src_l], mio.sy[src_l], mio.sth[src_l], px_l, py_l, th_l);
+        det_sincosf(th_l, st_l, ct_l);
+    } else {
+        det_sincosf(a.th[mine], st_l, ct_l);
+        px_l = a.x[mine];
+        py_l = a.y[mine];
+    }
+    if ((int)lane < nslots) {   // the class follows the particle and is still in use
+        a.cls_out[mine] = cls_l;
+        a.cstamp[cls_l] = a.stamp_now;
+    }
+#pragma unroll
+    for (int k = 0; k < G; ++k) {
+        s_acc[wave][k][lane] = 0.0f;
+        s_acc[wave][k][lane + 64] = 0.0f;
+    }
+    const int pl = __builtin_amdgcn_readfirstlane(a.plane_stride * 4);
+    const int mean_bytes = 2 * pl, cov_bytes = 3 * pl;
+    const gchar* ozx = uniform_gptr(a.obs_zx);
+    const gchar* ozy = uniform_gptr(a.obs_zy);
+    const unsigned L = (unsigned)a.nlandmarks, room = (unsigned)a.plane_stride;
+    const v2f q2 = bc2(a.meas_var);
+    const float nan = __uint_as_float(0x7fc00000u);
+
+    auto pose_of = [&](int k) {
+        EkfPose w;
+        const int i = g0 + k;
+        w.rout = __builtin_amdgcn_make_buffer_rsrc((void*)uniform_gptr(a.map_out + (int64_t)i * a.row_stride), 0, mean_bytes, 0x00020000);
+        w.s = bc2(lane_value(st_l, k));
+        w.c = bc2(lane_value(ct_l, k));
+        w.px = bc2(lane_value(px_l, k));
+        w.py = bc2(lane_value(py_l, k));
+        return w;
+    };
+
+    for (unsigned lb = 0; lb < L; lb += 128u * NB) {
+        SplitBatch<NB> b;
+#pragma unroll
+        for (int g = 0; g < NB; ++g)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const unsigned l = lb + (unsigned)g * 128u + 64u * t + lane;
+                const bool in = l < L;
+                b.off[g][t] = l < room ? l * 4u : 0xffffffffu;   // beyond the planes: loads give 0, stores are dropped
+                const unsigned zo = (in ? l : 0u) * 4u;
+                const float vx = *(const gfloat*)(ozx + zo), vy = *(const gfloat*)(ozy + zo);
+                b.zx[g][t] = in ? vx : nan;
+                b.zy[g][t] = in ? vy : nan;
+                b.obs[g][t] = b.zx[g][t] == b.zx[g][t] && b.zy[g][t] == b.zy[g][t];
+            }
+#pragma unroll
+        for (int g = 0; g < NB; ++g) {
+            b.any_obs[g] = __ballot(b.obs[g][0] || b.obs[g][1]) != 0;
+            b.all_obs[g] = __ballot(!(b.obs[g][0] && b.obs[g][1])) == 0;
+        }
+        int prev = -1, prev_cls = -1;
+        for (int k = 0; k < nslots; ++k) {
+            const int src = __builtin_amdgcn_readlane(src_l, k);
+            const int cls = __builtin_amdgcn_readlane(cls_l, k);
+            const bool new_cls = cls != prev_cls;
+            v2f pr[NB][3];
+            if (src != prev) {   // a new ancestor: its means into registers (wave-uniform branch)
+                const __amdgpu_buffer_rsrc_t rin =
+                    __builtin_amdgcn_make_buffer_rsrc((void*)uniform_gptr(a.map_in + (int64_t)src * a.row_stride), 0, mean_bytes, 0x00020000);
+#pragma unroll
+                for (int g = 0; g < NB; ++g)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        b.mx[g][t] = row_load(rin, b.off[g][t], 0);
+                        b.my[g][t] = row_load(rin, b.off[g][t], pl);
+                    }
+                prev = src;
+            }
+            if (new_cls) {   // a new class: its covariances, and everything about the update that depends on them alone
+                const __amdgpu_buffer_rsrc_t rc =
+                    __builtin_amdgcn_make_buffer_rsrc((void*)uniform_gptr(a.cov + (int64_t)cls * a.cov_stride), 0, cov_bytes, 0x00020000);
+#pragma unroll
+                for (int g = 0; g < NB; ++g)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int p = 0; p < 3; ++p) pr[g][p][t] = row_load(rc, b.off[g][t], p * pl);
+#pragma unroll
+                for (int g = 0; g < NB; ++g) {
+                    b.first[g][0] = pr[g][0][0] < 0.0f;
+                    b.first[g][1] = pr[g][0][1] < 0.0f;
+                    b.any_first[g] = __ballot(b.first[g][0] || b.first[g][1]) != 0;
+                    if (b.any_obs[g]) b.sh[g] = ekf_shared<v2f>(pr[g][0], pr[g][1], pr[g][2], q2);
+                }
+                prev_cls = cls;
+            }
+            const EkfPose w = pose_of(k);
+            v2f acc = (v2f){s_acc[wave][k][lane], s_acc[wave][k][lane + 64]};
+            split_apply<NB>(b, w, pl, acc);
+            s_acc[wave][k][lane] = acc[0];
+            s_acc[wave][k][lane + 64] = acc[1];
+        }
+    }
+    for (int k = 0; k < nslots; ++k) {
+        const float total = wave_xor_tree_sum(s_acc[wave][k][lane] + s_acc[wave][k][lane + 64]);
+        if (lane == 0) {
+            a.loglik[g0 + k] = total;
+            if (a.loglik_user) a.loglik_user[g0 + k] = total;
+        }
+    }
+}
+
+template <int NB, int G>
+__global__ __launch_bounds__(kEkfWaves * 64) EKF_GROUP_ATTR void ekf_split_kernel(EkfArgs a)
+{
+    __shared__ float s_acc[kEkfWaves][G][128];
+    int bid = blockIdx.x;
+    if (a.xcd_chunk > 0) bid = (bid & 7) * a.xcd_chunk + (bid >> 3);
+    ekf_split_body<NB, G, false>(a, bid, s_acc, MotionIO{}, MotionParams{});
+}
+
 // ---- the FRONT of a single-GPU frame in one launch: motion sample + scan-match score (score_body.h) and the grouped
 // out-of-place landmark update side by side.  The two are bound by different units — the scorer by the texture addresser
 // (gathers out of L2), the update by HBM writes — and neither needs the other's output: both start from the resample
@@ -533,7 +720,7 @@ struct FrontArgs {
     int score_span;      // the scoring octets lie among the first score_span octets of the grid
 };
 
-template <int NB, int G, int LPP, int DEPTH>
+template <int NB, int G, int LPP, int DEPTH, bool SPLIT = false>
 __global__ __launch_bounds__(kEkfWaves * 64) EKF_GROUP_ATTR void frame_front_kernel(FrontArgs f)
 {
     static_assert(kScoreBlock == kEkfWaves * 64, "both kinds of workgroup have 256 threads");
@@ -551,6 +738,8 @@ __global__ __launch_bounds__(kEkfWaves * 64) EKF_GROUP_ATTR void frame_front_ker
         if (sb >= f.score_blocks) return;
         score_poses_body<false, LPP, DEPTH, true>(f.g, f.bx, f.by, f.nbeams, f.mio.x, f.mio.y, f.mio.th, nullptr, f.a.n, f.score,
                                                   f.count, f.mio, f.mpar, sb, s_pair);
+    } else if constexpr (SPLIT) {
+        ekf_split_body<NB, G, true>(f.a, xcd * f.ekf_octets + (o - before), s_acc, f.mio, f.mpar);
     } else {
         ekf_group_body<NB, G, true>(f.a, xcd * f.ekf_octets + (o - before), s_acc, f.mio, f.mpar);
     }
@@ -1692,6 +1881,20 @@ hipError_t launch_ekf_update(hipStream_t stream, const EkfArgs& a_in, const Even
         a.xcd_chunk = (blocks + 7) / 8;
         blocks = 8 * a.xcd_chunk;
     }
+    if (a.cov) {   // split layout: always the grouped form (2 particles per wavefront unless the caller asks for 4)
+        const int G = group_size == 4 ? 4 : 2;
+        int gblocks = (a.n + kEkfWaves * G - 1) / (kEkfWaves * G);
+        a.xcd_chunk = 0;
+        if (gblocks >= 64) {
+            a.xcd_chunk = (gblocks + 7) / 8;
+            gblocks = 8 * a.xcd_chunk;
+        }
+        if (ev) (void)hipEventRecord(ev->start, stream);
+        if (G == 4) ekf_split_kernel<EKF_GROUP_NB, 4><<<gblocks, kEkfWaves * 64, 0, stream>>>(a);
+        else ekf_split_kernel<EKF_GROUP_NB, 2><<<gblocks, kEkfWaves * 64, 0, stream>>>(a);
+        if (ev) (void)hipEventRecord(ev->stop, stream);
+        return hipGetLastError();
+    }
     const bool copy = a.map_in != a.map_out;   // in place: rows without an observation stay as they are
     // out of place, more than one batch per row: optionally the grouped form (group_size neighbouring particles per
     // wavefront, shared source rows stay in registers); the caller knows roughly how many distinct ancestors the last
@@ -1746,7 +1949,7 @@ bool frame_front_fits(int n, int nlandmarks, int group_size)
 hipError_t launch_frame_front(hipStream_t stream, const ScoreGrid& g, const float* bx, const float* by, int nbeams,
                               const MotionIO& io, int64_t first_id, const float dp[3], const float sigma[3], uint64_t seed,
                               uint32_t frame, float* score, int32_t* count, const EkfArgs& a_in, int group_size,
-                              const EventPair* ev, bool* launched)
+                              const EventPair* ev, bool* launched, int* lanes_per_pose)
 {
     *launched = false;
     const int n = a_in.n;
@@ -1778,7 +1981,15 @@ hipError_t launch_frame_front(hipStream_t stream, const ScoreGrid& g, const floa
     f.score_span = (int)(span > f.score_octets ? span : f.score_octets);
     const size_t lds = sizeof(float2) * (size_t)(nbeams + (quad ? 4 * kQuadDepth : kLaneDepth));
     if (ev) (void)hipEventRecord(ev->start, stream);
-    if (quad) {
+    if (f.a.cov) {   // split layout
+        if (quad) {
+            if (G == 2) frame_front_kernel<EKF_GROUP_NB, 2, 4, kQuadDepth, true><<<grid, kEkfWaves * 64, lds, stream>>>(f);
+            else frame_front_kernel<EKF_GROUP_NB, 4, 4, kQuadDepth, true><<<grid, kEkfWaves * 64, lds, stream>>>(f);
+        } else {
+            if (G == 2) frame_front_kernel<EKF_GROUP_NB, 2, 1, kLaneDepth, true><<<grid, kEkfWaves * 64, lds, stream>>>(f);
+            else frame_front_kernel<EKF_GROUP_NB, 4, 1, kLaneDepth, true><<<grid, kEkfWaves * 64, lds, stream>>>(f);
+        }
+    } else if (quad) {
         if (G == 2) frame_front_kernel<EKF_GROUP_NB, 2, 4, kQuadDepth><<<grid, kEkfWaves * 64, lds, stream>>>(f);
         else frame_front_kernel<EKF_GROUP_NB, 4, 4, kQuadDepth><<<grid, kEkfWaves * 64, lds, stream>>>(f);
     } else {
@@ -1787,6 +1998,7 @@ hipError_t launch_frame_front(hipStream_t stream, const ScoreGrid& g, const floa
     }
     if (ev) (void)hipEventRecord(ev->stop, stream);
     *launched = true;
+    if (lanes_per_pose) *lanes_per_pose = quad ? 4 : 1;
     return hipGetLastError();
 }
 

@@ -87,6 +87,8 @@ struct slam_pf {
     bool last_ekf = false;          // the last frame ran the landmark update (its log-likelihoods are in the engine)
     int32_t* sel = nullptr;         // grow-only scratch of slam_pf_get_map_rows_host: chosen particles | their source rows
     int sel_cap = 0;
+    float* conv_tmp = nullptr;      // grow-only scratch of a pages -> rows move (convert_to_rows)
+    size_t conv_floats = 0;
 };
 
 namespace {
@@ -162,6 +164,16 @@ int migrate(slam_pf* pf)
             return rc;
     }
     return SLAM_OK;
+}
+
+// Every slam_pf_* call on a sharded session is collective: a rank that fails one alone (an error of its own, not a verdict
+// every rank reaches together) must not leave the others waiting inside it — it gives up for good (comm_abort), the peers get
+// SLAM_ERR_COMM at once instead of after SLAM_COMM_TIMEOUT_S.
+int collective_result(slam_pf* pf, int rc)
+{
+    // (argument checks come before anything collective and are the same on every rank of a sane host: no abort for those)
+    if (rc != SLAM_OK && rc != SLAM_ERR_INVALID_ARG && rc != SLAM_ERR_NOT_READY && pf && pf->comm) (void)comm_abort(pf->comm);
+    return rc;
 }
 
 int finish_exchange(slam_pf* pf)
@@ -255,14 +267,21 @@ bool alloc_page_tables(slam_pf* pf)
 // store (before the pending gather); they are written as pages into the OTHER half — page (other half's first page) + r * nb
 // + b behind identity tables, so the pending gather index means the same thing afterwards — and the half they came from
 // becomes free pages.
+// Sharded: when the exchange of the last frame has already been completed (a map getter between two frames does that), the
+// pending gather index also names rows of the staging tail, n .. n + rows_received - 1: they move with the rest.
+int rows_to_convert(const slam_pf* pf)
+{
+    return pf->n + (pf->comm && pf->has_anc && !pf->exchange_pending ? pf->rows_received : 0);
+}
+
 int convert_to_pages(slam_pf* pf)
 {
     slam_engine* e = pf->e;
     const int mc = pf->map_cur;
     const int page_base = (1 - mc) * pf->cap * pf->nb;
     pf->pt_cur = 0;
-    SLAM_HIP_TRY(e, launch_pages_from_rows(e->stream, pf->map[mc], 5 * (int64_t)pf->Lp, pf->Lp, pf->L, pf->nb, pf->n, pf->pool,
-                                           pf->pt[0], pf->freelist, pf->npages, pf->page_scratch, page_base));
+    SLAM_HIP_TRY(e, launch_pages_from_rows(e->stream, pf->map[mc], 5 * (int64_t)pf->Lp, pf->Lp, pf->L, pf->nb, rows_to_convert(pf),
+                                           pf->pool, pf->pt[0], pf->freelist, pf->npages, pf->page_scratch, page_base));
     pf->paged = true;
     pf->conversions++;
     return SLAM_OK;
@@ -275,25 +294,31 @@ int convert_to_pages(slam_pf* pf)
 int convert_to_rows(slam_pf* pf)
 {
     slam_engine* e = pf->e;
-    const size_t half = 5 * (size_t)pf->Lp * (size_t)pf->cap, used = 5 * (size_t)pf->Lp * (size_t)pf->n;
-    float* tmp = nullptr;
-    if (hipMalloc((void**)&tmp, used * 4) != hipSuccess) {
-        (void)hipGetLastError();
-        pf->auto_stuck = true;
-        return SLAM_OK;
+    const int nrows = rows_to_convert(pf);
+    const size_t used = 5 * (size_t)pf->Lp * (size_t)nrows;
+    if (pf->conv_floats < used) {   // grow-only scratch (an alloc + free per move would serialise the frame every time)
+        if (pf->conv_tmp) {
+            if (pf->comm) {
+                if (int rc = comm_wait_stream(pf->comm)) return rc;
+            } else {
+                SLAM_HIP_TRY(e, hipStreamSynchronize(e->stream));
+            }
+            (void)hipFree(pf->conv_tmp);
+        }
+        pf->conv_tmp = nullptr;
+        pf->conv_floats = 0;
+        if (hipMalloc((void**)&pf->conv_tmp, used * 4) != hipSuccess) {
+            (void)hipGetLastError();
+            pf->conv_tmp = nullptr;
+            pf->auto_stuck = true;
+            return SLAM_OK;
+        }
+        pf->conv_floats = used;
     }
-    int rc = SLAM_OK;
-    auto ok = [&](hipError_t err, const char* what) {
-        if (err != hipSuccess && rc == SLAM_OK) rc = slam_engine_fail_hip(e, err, what);
-        return err == hipSuccess;
-    };
-    (void)half;
-    ok(launch_rows_from_pages(e->stream, pf->pool, pf->pt[pf->pt_cur], pf->nb, nullptr, pf->n, tmp, 5 * (int64_t)pf->Lp, pf->Lp, pf->L),
-       "rows_from_pages") &&
-        ok(hipMemcpyAsync(pf->map[0], tmp, used * 4, hipMemcpyDeviceToDevice, e->stream), "hipMemcpyAsync") &&
-        ok(hipStreamSynchronize(e->stream), "hipStreamSynchronize");
-    (void)hipFree(tmp);
-    if (rc != SLAM_OK) return rc;
+    // stream-ordered: pages -> scratch rows -> the first half of the store (the scratch is read before anything else writes it)
+    SLAM_HIP_TRY(e, launch_rows_from_pages(e->stream, pf->pool, pf->pt[pf->pt_cur], pf->nb, nullptr, nrows, pf->conv_tmp,
+                                           5 * (int64_t)pf->Lp, pf->Lp, pf->L));
+    SLAM_HIP_TRY(e, hipMemcpyAsync(pf->map[0], pf->conv_tmp, used * 4, hipMemcpyDeviceToDevice, e->stream));
     pf->map_cur = 0;
     pf->paged = false;
     pf->conversions++;
@@ -472,6 +497,7 @@ int slam_pf_destroy(slam_pf* pf)
                      (void*)pf->rbuf, (void*)pf->res_dev, (void*)pf->sums_acc, pf->res_all })
         (void)hipFree(p);
     (void)hipFree(pf->sel);
+    (void)hipFree(pf->conv_tmp);
     delete pf;   // h_res is the engine's
     return SLAM_OK;
 }
@@ -791,6 +817,7 @@ int slam_pf_device_view(slam_pf* pf, slam_pf_view* out)
     out->score = pf->has_anc ? pf->score : nullptr;
     out->logw = pf->has_anc ? pf->logw : nullptr;
     out->loglik = pf->has_anc && pf->last_ekf && pf->e->ll_n == pf->n ? pf->e->ll_buf.as<float>() : nullptr;
+    out->count = pf->has_anc ? pf->count : nullptr;
     return SLAM_OK;
 }
 
@@ -811,7 +838,14 @@ int slam_pf_paged_device_view(slam_pf* pf, slam_pf_paged_view* out)
     return SLAM_OK;
 }
 
+static int slam_pf_best_impl(slam_pf* pf, float pose[3], float* logw, int32_t* index);
+
 int slam_pf_best(slam_pf* pf, float pose[3], float* logw, int32_t* index)
+{
+    return collective_result(pf, slam_pf_best_impl(pf, pose, logw, index));
+}
+
+static int slam_pf_best_impl(slam_pf* pf, float pose[3], float* logw, int32_t* index)
 {
     if (!pf || !pose) return SLAM_ERR_INVALID_ARG;
     slam_engine* e = pf->e;
@@ -846,7 +880,14 @@ int slam_pf_best(slam_pf* pf, float pose[3], float* logw, int32_t* index)
     return SLAM_OK;
 }
 
+static int slam_pf_mean_impl(slam_pf* pf, float ref_theta, float pose[3]);
+
 int slam_pf_mean(slam_pf* pf, float ref_theta, float pose[3])
+{
+    return collective_result(pf, slam_pf_mean_impl(pf, ref_theta, pose));
+}
+
+static int slam_pf_mean_impl(slam_pf* pf, float ref_theta, float pose[3])
 {
     if (!pf || !pose) return SLAM_ERR_INVALID_ARG;
     slam_engine* e = pf->e;
@@ -887,7 +928,14 @@ int slam_pf_mean(slam_pf* pf, float ref_theta, float pose[3])
     return SLAM_OK;
 }
 
+static int slam_pf_get_poses_host_impl(slam_pf* pf, float* x, float* y, float* theta);
+
 int slam_pf_get_poses_host(slam_pf* pf, float* x, float* y, float* theta)
+{
+    return collective_result(pf, slam_pf_get_poses_host_impl(pf, x, y, theta));
+}
+
+static int slam_pf_get_poses_host_impl(slam_pf* pf, float* x, float* y, float* theta)
 {
     if (!pf || !x || !y || !theta) return SLAM_ERR_INVALID_ARG;
     const size_t n = (size_t)pf->n;
@@ -905,7 +953,14 @@ int slam_pf_get_poses_host(slam_pf* pf, float* x, float* y, float* theta)
     return SLAM_OK;
 }
 
+static int slam_pf_get_map_host_impl(slam_pf* pf, float* rows);
+
 int slam_pf_get_map_host(slam_pf* pf, float* rows)
+{
+    return collective_result(pf, slam_pf_get_map_host_impl(pf, rows));
+}
+
+static int slam_pf_get_map_host_impl(slam_pf* pf, float* rows)
 {
     if (!pf || !rows || !pf->L) return SLAM_ERR_INVALID_ARG;
     const size_t n = (size_t)pf->n, L = (size_t)pf->L, Lp = (size_t)pf->Lp;
@@ -935,7 +990,14 @@ int slam_pf_get_map_host(slam_pf* pf, float* rows)
     return hipMemcpy2D(rows, L * 4, src, Lp * 4, L * 4, 5 * n, hipMemcpyDeviceToHost) == hipSuccess ? SLAM_OK : SLAM_ERR_HIP;
 }
 
+static int slam_pf_get_map_rows_host_impl(slam_pf* pf, const int32_t* particle, int count, float* rows);
+
 int slam_pf_get_map_rows_host(slam_pf* pf, const int32_t* particle, int count, float* rows)
+{
+    return collective_result(pf, slam_pf_get_map_rows_host_impl(pf, particle, count, rows));
+}
+
+static int slam_pf_get_map_rows_host_impl(slam_pf* pf, const int32_t* particle, int count, float* rows)
 {
     if (!pf || !pf->L || count < 0 || (count > 0 && (!particle || !rows))) return SLAM_ERR_INVALID_ARG;
     for (int k = 0; k < count; ++k)

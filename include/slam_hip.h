@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define SLAM_ABI_VERSION 4
+#define SLAM_ABI_VERSION 5
 
 typedef enum {
     SLAM_OK = 0,
@@ -258,6 +258,10 @@ int slam_ekf_form_counts(slam_engine *e, int64_t counts[2]);
  * (slam_profile_enable: a fused launch is bracketed as SLAM_PROF_EKF).  slam_frame_fusion_count: fused launches of this engine so far. */
 int slam_frame_fusion_set(slam_engine *e, int on);
 int slam_frame_fusion_count(slam_engine *e, int64_t *launches);
+/* Which instantiation the LAST fused front launch of this engine was (tests pin the kernel at the shapes its numbers are
+ * quoted on and say which one they pinned): info[0] = particles per updating wavefront (2 or 4), info[1] = lanes per pose of
+ * its scoring workgroups (4 below 131 072 particles, else 1); both 0 before the first fused launch. */
+int slam_frame_front_last(slam_engine *e, int32_t info[2]);
 /* The in-place update (d_map_in == d_map_out: frames that keep their population, slam_resample_gate_set) also has two
  * kernels with the SAME bits: whole rows in batches of 128 landmarks, and the observed landmarks only, from a list
  * the engine compacts out of the observation table once per table (nlandmarks <= 65536).  form = -1 (initial): the
@@ -526,6 +530,7 @@ typedef struct {
      * score, the log-weight and — when that frame used observations, else NULL — the EKF log-likelihood of every
      * particle; NULL before the first frame */
     const float *score, *logw, *loglik;
+    const int32_t *count;             /* in-bounds beams behind `score` (main.c:512-518 counts them as bestHits_size) */
 } slam_pf_view;
 int slam_pf_device_view(slam_pf *pf, slam_pf_view *out);
 /* current particles with the pending resample gather applied; synchronises */

@@ -28,7 +28,7 @@ def test_header_symbols_are_exported_and_bound():
 def test_abi_version_and_status_strings():
     pkg = load_package()
     lib = pkg.load_library()
-    assert lib.slam_abi_version() == 4
+    assert lib.slam_abi_version() == 5
     assert pkg.status_string(0) == "ok"
     assert "gfx950" in pkg.status_string(-1)
     assert pkg.status_string(-12345) == "unknown status"

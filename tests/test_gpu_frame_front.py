@@ -1,9 +1,10 @@
 """The front of a single-GPU frame on rows as ONE launch (frame_front_kernel: motion sample + scan-match score and the grouped
 out-of-place landmark update, interleaved workgroups) against the two launches it replaces: the same bits — poses, scores'
 consequences (weights -> resample indices -> heaviest particle), maps — frame after frame, for both lane mappings of the
-scorer (4 lanes per pose below 131 072 particles, 1 above) and both group sizes of the update.  The two-launch path is the one
-the rest of the suite pins against the CPU specification (tests/test_gpu_pf.py, test_gpu_configs.py run fused by default
-wherever the shapes fit, so both are checked there as well)."""
+scorer (4 lanes per pose below 131 072 particles, 1 above) and both group sizes of the update.  HIP against HIP, at small sizes:
+the fused kernel itself is pinned against the CPU specification in tests/test_gpu_frame_front_at_size.py, at the shapes its
+numbers are quoted on (the session-vs-oracle tests of test_gpu_pf.py use populations and rows too small for the fused launch,
+and the full-size tests of test_gpu_configs.py call the stage entry point, which never launches it)."""
 import numpy as np
 import pytest
 import torch
