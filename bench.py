@@ -643,7 +643,9 @@ def run_rank(args, ctx, inp):
     forms1 = eng.ekf_form_counts() + eng.ekf_inplace_form_counts()
     forms = tuple(b - a for a, b in zip(forms0, forms1))   # EKF launches of the timed region, by kernel (out of place x2, in place x2)
     fused_n = eng.frame_fusion_count() - fused0             # ... of which went out fused with the motion + score launch
-    paged_in_region = pf.is_paged()
+    layout_in_region = pf.layout()   # "rows", "pages" or "split": what the timed frames ran on
+    paged_in_region = layout_in_region == "pages"
+    split_in_region = layout_in_region == "split"
     elapsed = ctx.max_over_ranks(elapsed)
     migrated = ctx.max_over_ranks(migrated / max(args.steps, 1))
 
@@ -695,10 +697,27 @@ def run_rank(args, ctx, inp):
     score_bytes = (12 + 4 * args.beams + 4) * n              # pose read + one EDT gather per beam + score write
     ekf_bytes = 40 * n * L_obs                               # 20 B read + 20 B written per (particle, OBSERVED landmark)
     no_reuse = None
-    if L and args.mode != "score" and not args.no_sweep and views()[1] is not None:
+    # classes in use (split layout): what the covariance part of a frame costs is proportional to it
+    classes_in_use = None
+    if split_in_region:
+        classes_in_use = int(torch.as_tensor(pf.split_view()["live_count"], device=dev)[0])
+    sweep_rows = views()[1:3]
+    if L and args.mode != "score" and not args.no_sweep and sweep_rows[0] is None and not paged_in_region:
+        # a split session has no rows: the sweep of the ROW kernel (the 20 B + 20 B streaming figure the north star's
+        # read-only fraction is defined on) runs on scratch rows of the same shape, when they fit beside the session
+        free_b, _ = torch.cuda.mem_get_info(dev)
+        if free_b > 2.1 * n * 5 * Lp * 4:
+            ma = torch.zeros((n, 5, Lp), dtype=torch.float32, device=dev)
+            mb = torch.empty((n, 5, Lp), dtype=torch.float32, device=dev)
+            fill_maps(torch, ma, landmarks, L, dev, n)
+            torch.cuda.synchronize()
+            sweep_rows = (ma, mb)
+            del ma, mb
+    if L and args.mode != "score" and not args.no_sweep and sweep_rows[0] is not None:
         eng.profile_enable(eng.PROF_EKF)
         eng.profile_read(eng.PROF_EKF)
-        p, ma, mb, _ = views()
+        p = views()[0]
+        ma, mb = sweep_rows
         base = args.warmup + args.steps
         for k in range(12):
             eng.obs_set_dev(*obs_v[(off + base + k) % len(frames)], L)
@@ -715,6 +734,7 @@ def run_rank(args, ctx, inp):
                         "algorithmic_bytes_per_launch": ekf_bytes,
                         "read_only_frac": 20 * n * L_obs / (t_nr * 1e-3) / 1e9 / HBM_PEAK_GBS}
         del p, ma, mb
+    del sweep_rows
 
     # the engine picks among kernels that give the same bits; name the one that ran
     if paged_in_region:
@@ -735,14 +755,35 @@ def run_rank(args, ctx, inp):
     traffic, traffic_src = None, None
     tfile = ROOT / "profiles" / "traffic.json"
     if tfile.exists():
-        key = (f"{args.mode}:{n}:{args.beams}:{L}:{args.grid}" + (":paged" if paged_in_region else "")
+        key = (f"{args.mode}:{n}:{args.beams}:{L}:{args.grid}" + (":paged" if paged_in_region else "") + (":split" if split_in_region else "")
                + (f":obs{L_obs}" if L_obs != L else "") + (f":ess{args.ess}" if 0 < args.ess < 1 else ""))
         rec = json.loads(tfile.read_text()).get(key, {})
         if rec.get("kernel", kern).split("<")[0] == kern.split(" ")[0]:
             traffic, traffic_src = rec.get("bytes_per_launch"), rec.get("source")
+    # What the launch must move, from THIS run's own figures (checkable without a profiler): an out-of-place update writes
+    # every row it owns in full and reads every distinct ancestor's row once (the offspring share it through registers / L2);
+    # rows hold 20 B per landmark, split rows 8 B plus 24 B per landmark and covariance class in use (read by the particles'
+    # update out of L2, read and rewritten once by cov_update_kernel).  A static PMC record that is far off this model was
+    # taken on another filter state (or another kernel) and is flagged.
+    traffic_model = None
+    if args.mode == "pf" and L and not paged_in_region and distinct_frac is not None and kern.startswith(("frame_front", "ekf_update")):
+        per = 8 if split_in_region else 20
+        written = per * n * Lp
+        read = distinct_frac * per * n * Lp + (24 * Lp * classes_in_use if split_in_region else 0)
+        traffic_model = {"bytes_written": written, "bytes_read": read, "bytes": written + read,
+                         "basis": f"{per} B x n x Lp written + distinct_ancestor_frac x {per} B x n x Lp read"
+                                  + (" + 24 B x Lp x classes in use" if split_in_region else ""),
+                         "distinct_ancestor_frac": distinct_frac, "classes_in_use": classes_in_use}
+        if traffic:
+            traffic_model["record_over_model"] = traffic / (written + read)
+            traffic_model["record_suspect"] = bool(abs(traffic / (written + read) - 1.0) > 0.15)
     if traffic and dur_ms > 0:
         achieved, a_kernel = traffic / (dur_ms * 1e-3) / 1e9, kern
         basis = f"hbm_traffic (PMC record of this workload and kernel, {traffic_src}) / this run's launch time"
+    elif traffic_model and dur_ms > 0:
+        achieved, a_kernel = traffic_model["bytes"] / (dur_ms * 1e-3) / 1e9, kern
+        basis = ("traffic model of this run (no PMC record for this workload and kernel): " + traffic_model["basis"]
+                 + " / this run's launch time")
     elif (kern.startswith("ekf_update") or kern.startswith("frame_front")) and no_reuse and args.mode == "pf":
         achieved, a_kernel = no_reuse["achieved"], no_reuse["kernel"]
         basis = "no_reuse sweep (no PMC record for this workload and kernel): HBM bytes of a launch without shared rows / its launch time"
@@ -772,10 +813,14 @@ def run_rank(args, ctx, inp):
                    "distinct_ancestor_frac": distinct_frac,
                    "resample_ess_frac": args.ess,
                    "preroll_frames": off,
-                   "map_layout": {"requested": args.map_layout, "in_timed_region": "pages (copy-on-write, 32 landmarks)" if paged_in_region else "rows"},
+                   "map_layout": {"requested": args.map_layout,
+                                  "in_timed_region": {"pages": "pages (copy-on-write, 32 landmarks)", "rows": "rows",
+                                                      "split": "split (means per particle, covariances per covariance class)"}[layout_in_region],
+                                  "covariance_classes_in_use": classes_in_use},
                    "frames_resampled": (pf.frames_resampled() if 0 < args.ess < 1 else None)},
         "roofline": {"bound": "hbm", "kernel": kern, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "achieved_basis": basis, "achieved_kernel": a_kernel,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_model": traffic_model,
+                     "achieved_basis": basis, "achieved_kernel": a_kernel,
                      "algorithmic_bytes_per_launch": alg, "logical_rate_gbs": logical,
                      "logical_frac": logical / HBM_PEAK_GBS,
                      "no_reuse": no_reuse,
@@ -789,7 +834,11 @@ def run_rank(args, ctx, inp):
                               "its landmark update (grouped row kernel: HBM writes), interleaved; `avg_launch_ms` is that launch, "
                               "`algorithmic_bytes_per_launch` the update's 40 B per particle and observed landmark; `stage_avg_ms` has "
                               "the two as separate launches (slam_frame_fusion_set(0)); `no_reuse` is the row kernel alone streaming "
-                              "every row from HBM" if kern.startswith("frame_front") else
+                              "every row from HBM"
+                              + ("; SPLIT layout: the update reads and writes the MEANS of a row only (8 B per particle and landmark "
+                                 "each way), the covariance planes exist once per covariance class and are rewritten by "
+                                 "cov_update_kernel (stage `pages`), see `traffic_model`" if split_in_region else "")
+                              if kern.startswith("frame_front") else
                               "paged maps: the update reads the touched pages of the ancestors (shared pages out of L2) and writes "
                               "fresh pages; `logical_rate_gbs` is SURVEY 8d's 40 B per particle and observed landmark / launch time"
                               if kern.startswith("ekf") else
@@ -923,7 +972,7 @@ def extra_legs(args, torch, pkg, eng, dev, inp, kernel_ms):
     e2e = {"what": "configs[1] (65536 x 500, 360 beams, 1024^2 EDT) with the 32 nearest landmarks observed per frame, every "
                    "frame resampled: whole frames on the C session; `*_ms` = median over chunks of 10 frames (one "
                    "synchronisation per chunk; `*_ms_chunks` lists them)", "steps": steps}
-    for layout in ("rows", "pages", "auto"):
+    for layout in ("rows", "split", "pages", "auto"):
         ses = pkg.PfSession(eng, n, L, sigma=SIGMA, meas_var=MEAS_VAR, score_gain=SCORE_GAIN, seed=1234, map_layout=layout)
         g = torch.Generator(device="cpu").manual_seed(1234)
         p0 = true_pose(0)
@@ -949,7 +998,7 @@ def extra_legs(args, torch, pkg, eng, dev, inp, kernel_ms):
         chunk_ms.append(1e3 * (time.perf_counter() - t0) / chunk)
         e2e[f"{layout}_ms"] = float(np.median(chunk_ms))
         e2e[f"{layout}_ms_chunks"] = [round(c, 4) for c in chunk_ms]
-        e2e[f"{layout}_ended_on"] = "pages" if ses.is_paged() else "rows"
+        e2e[f"{layout}_ended_on"] = ses.layout()
         ses.close()
     res["end_to_end_obs32"] = e2e
 
@@ -960,8 +1009,9 @@ def extra_legs(args, torch, pkg, eng, dev, inp, kernel_ms):
     d_scan = torch.from_numpy(np.stack([np.stack([f["bx"], f["by"]]) for f in fr])).to(dev)
     tabs = obs_tables(torch, fr, L, dev)
     old = {}
-    for name, fuse in (("two_launches_cold_every_frame_bracketed", False), ("fused_front_cold_every_frame_bracketed", True)):
-        ses = pkg.PfSession(eng, n, L, sigma=SIGMA, meas_var=MEAS_VAR, score_gain=SCORE_GAIN, seed=1234, map_layout="rows")
+    for name, fuse, lay in (("two_launches_cold_every_frame_bracketed", False, "rows"), ("fused_front_cold_every_frame_bracketed", True, "rows"),
+                            ("default_layout_cold_every_frame_bracketed", True, args.map_layout)):
+        ses = pkg.PfSession(eng, n, L, sigma=SIGMA, meas_var=MEAS_VAR, score_gain=SCORE_GAIN, seed=1234, map_layout=lay)
         g = torch.Generator(device="cpu").manual_seed(1234)
         ses.set_poses(*[(p0[k] + s * torch.randn(n, generator=g)).numpy() for k, s in ((0, 0.05), (1, 0.05), (2, 0.01))])
         m0 = torch.zeros((n, 5, Lp), dtype=torch.float32, device=dev)
@@ -985,12 +1035,18 @@ def extra_legs(args, torch, pkg, eng, dev, inp, kernel_ms):
         ms = 1e3 * (time.perf_counter() - t0) / 20
         eng.profile_enable()
         kms, kn = eng.profile_read(eng.PROF_EKF)
-        old[name] = {"ms_per_step": ms, "particle_updates_per_s": n / (ms * 1e-3), "bracketed_kernel_avg_ms": kernel_ms(kms, kn)}
+        old[name] = {"ms_per_step": ms, "particle_updates_per_s": n / (ms * 1e-3), "bracketed_kernel_avg_ms": kernel_ms(kms, kn),
+                     "map_layout": ses.layout()}
         ses.close()
     eng.frame_fusion_set(True)
     old["what"] = ("configs[1] as BENCH_r01 / BENCH_r02 measured it (--steps 20 --warmup 5 from a cold start, every frame's dominant "
-                   "launch bracketed), with the front as two launches (round 2's frame) and fused")
+                   "launch bracketed): on rows with the front as two launches (round 2's frame) and fused (round 3's), and on this "
+                   "run's --map-layout (the product's default)")
     res["headline_round2_method"] = old
+    # the like-for-like figure for round-on-round comparisons: one method (cold start, 5 + 20 frames, every frame bracketed)
+    res["value_cold_method"] = old["default_layout_cold_every_frame_bracketed"]["particle_updates_per_s"]
+    res["value_cold_method_what"] = ("particle-updates/s of configs[1] measured by rounds 1-2's method (see headline_round2_method); "
+                                     "`value` is the steady-state rate behind a pre-roll with sampled brackets")
     return res
 
 
@@ -1044,8 +1100,10 @@ def parse_args():
                     help="experiment, --mode score: upload the poses grouped by 4-pixel / matching-heading cells")
     ap.add_argument("--ekf-form", type=int, default=-1, choices=[-1, 0, 1, 2],
                     help="out-of-place EKF kernel: -1 the engine chooses (default), 0 one wavefront per particle, 1 / 2 per 4 / 2 particles")
-    ap.add_argument("--map-layout", choices=["auto", "rows", "pages"], default="auto",
-                    help="slam_pf_config.map_layout: auto (default: the session chooses and may change while it runs), rows, pages")
+    ap.add_argument("--map-layout", choices=["auto", "rows", "pages", "split"], default="auto",
+                    help="slam_pf_config.map_layout: auto (default: the session chooses and may change while it runs: split for dense "
+                         "frames on one GPU, pages for sparse ones, rows when sharded or gated), rows, pages, split (means per "
+                         "particle, covariances per covariance class)")
     ap.add_argument("--paged", action="store_true", help="= --map-layout pages")
     ap.add_argument("--force-collectives", action="store_true",
                     help="diagnostics, --gpus 1 only: run the multi-GPU code path (every RCCL collective, the sharded index "

@@ -145,6 +145,8 @@ SIGNATURES = {
     "slam_pf_get_map_host": (_i, [_vp, _vp]),
     "slam_pf_get_map_rows_host": (_i, [_vp, _vp, _i, _vp]),
     "slam_pf_paged_device_view": (_i, [_vp, _vp]),
+    "slam_pf_layout": (_i, [_vp]),
+    "slam_pf_split_device_view": (_i, [_vp, _vp]),
 }
 
 _LIB = None
@@ -271,6 +273,9 @@ class Engine:
 
     def grid_set_dev(self, slot: int, d_edt, meta: GridMeta):
         self._ck(self.lib.slam_grid_set_dev(self.h, slot, _ptr(d_edt), C.byref(meta)), "grid_set_dev")
+        # the engine adopts the buffer without copying it: keep the caller's array alive as long as the slot names it (a
+        # temporary tensor would go back to its allocator and be handed out again under the engine's feet)
+        self.__dict__.setdefault("_adopted", {})[("grid", slot)] = d_edt
 
     def grid_set_meta(self, slot: int, meta: GridMeta):
         self._ck(self.lib.slam_grid_set_meta(self.h, slot, C.byref(meta)), "grid_set_meta")
@@ -284,6 +289,7 @@ class Engine:
     def scan_set_dev(self, d_bx, d_by, nbeams: int):
         self._ck(self.lib.slam_scan_set_dev(self.h, _ptr(d_bx), _ptr(d_by), nbeams), "scan_set_dev")
         self.nbeams = nbeams
+        self.__dict__.setdefault("_adopted", {})["scan"] = (d_bx, d_by)
 
     def score_poses_cs_host(self, slot, x, y, ct, st):
         x, y, ct, st = (_np(a, np.float32) for a in (x, y, ct, st))
@@ -346,6 +352,7 @@ class Engine:
         """Observation table on the device: entry l = observation of landmark l, NaN in zx = not observed."""
         self._ck(self.lib.slam_obs_set_dev(self.h, _ptr(d_zx_by_landmark), _ptr(d_zy_by_landmark), nlandmarks),
                  "obs_set_dev")
+        self.__dict__.setdefault("_adopted", {})["obs"] = (d_zx_by_landmark, d_zy_by_landmark)
 
     def logweight_ekf_dev(self, d_score, gain, n, d_logw, d_max):
         self._ck(self.lib.slam_logweight_ekf_dev(self.h, _ptr(d_score), gain, n, _ptr(d_logw), _ptr(d_max)),
@@ -511,8 +518,9 @@ class PfConfig(C.Structure):
                 ("map_layout", C.c_int32)]
 
 
-MAP_AUTO, MAP_ROWS, MAP_PAGES = 0, 1, 2   # slam_map_layout
-_LAYOUTS = {"auto": MAP_AUTO, "rows": MAP_ROWS, "pages": MAP_PAGES, None: MAP_AUTO}
+MAP_AUTO, MAP_ROWS, MAP_PAGES, MAP_SPLIT = 0, 1, 2, 3   # slam_map_layout
+_LAYOUTS = {"auto": MAP_AUTO, "rows": MAP_ROWS, "pages": MAP_PAGES, "split": MAP_SPLIT, None: MAP_AUTO}
+_LAYOUT_NAMES = {MAP_ROWS: "rows", MAP_PAGES: "pages", MAP_SPLIT: "split"}
 
 
 COMM_ID_BYTES = 128
@@ -524,6 +532,13 @@ class PfView(C.Structure):
     _fields_ = [("pose", C.c_void_p), ("map", C.c_void_p), ("map_spare", C.c_void_p), ("anc", C.c_void_p), ("row_stride", C.c_int64),
                 ("plane_stride", C.c_int32), ("map_rows", C.c_int32), ("score", C.c_void_p), ("logw", C.c_void_p),
                 ("loglik", C.c_void_p), ("count", C.c_void_p)]
+
+
+class PfSplitView(C.Structure):
+    """``slam_pf_split_view``"""
+
+    _fields_ = [("mean", C.c_void_p), ("cov", C.c_void_p), ("cls", C.c_void_p), ("live", C.c_void_p), ("live_count", C.c_void_p),
+                ("plane_stride", C.c_int32), ("rows", C.c_int32)]
 
 
 class PfPagedView(C.Structure):
@@ -653,6 +668,19 @@ class PfSession:
                 "loglik": DeviceArray(v.loglik, (self.n,), "<f4", self) if v.loglik else None,
                 "count": DeviceArray(v.count, (self.n,), "<i4", self) if v.count else None,
                 "plane_stride": v.plane_stride, "row_stride": v.row_stride}
+
+    def layout(self) -> str:
+        """"rows", "pages" or "split": how the landmark maps are kept right now (``slam_pf_layout``)."""
+        return _LAYOUT_NAMES[self.e.lib.slam_pf_layout(self.h)]
+
+    def split_view(self):
+        """``slam_pf_split_device_view``: means, classes, class covariance rows and the list of classes in use."""
+        v = PfSplitView()
+        self.e._ck(self.e.lib.slam_pf_split_device_view(self.h, C.byref(v)), "pf_split_device_view")
+        return {"mean": DeviceArray(v.mean, (v.rows, 2, v.plane_stride), "<f4", self),
+                "cov": DeviceArray(v.cov, (v.rows, 3, v.plane_stride), "<f4", self),
+                "cls": DeviceArray(v.cls, (v.rows,), "<i4", self), "live": DeviceArray(v.live, (v.rows,), "<i4", self),
+                "live_count": DeviceArray(v.live_count, (1,), "<i4", self), "plane_stride": v.plane_stride}
 
     def paged_view(self):
         """``slam_pf_paged_device_view``: the page pool, tables, stamps and free list of a session that is on pages."""

@@ -71,6 +71,42 @@ int check_score_inputs(slam_engine* e, int slot)
     return SLAM_OK;
 }
 
+// The grid as the scorers of MANY poses want it: with the byte-per-cell copy (kernels.h: ScoreGrid::packed) when the grid
+// has one.  The copy is made on the first such call after the grid changed — two small launches and ONE wait for their verdict
+// (does the 256-entry table give every cell back bit for bit?), then nothing until the grid changes again.  Few poses (the
+// one-wavefront-per-pose kernel, the lattice) keep the float grid.  SLAM_SCORE_PACKED=0: never (measurements).
+int many_pose_grid(slam_engine* e, int slot, int nposes, ScoreGrid* out)
+{
+    GridSlot& g = e->grid[slot];
+    *out = score_grid(g);
+    static const bool enabled = !(getenv("SLAM_SCORE_PACKED") && atoi(getenv("SLAM_SCORE_PACKED")) == 0);
+    static const int wave_max = getenv("SLAM_SCORE_WAVE_MAX") ? atoi(getenv("SLAM_SCORE_WAVE_MAX")) : 3072;   // score_body.h: kWaveMaxPoses
+    if (!enabled || nposes < wave_max || g.meta.rows < 8 || g.meta.cols < 16) return SLAM_OK;
+    const int strip_bytes = 16 * ((g.meta.rows + 7) / 8 * 8);
+    if (strip_bytes >= (1 << 24)) return SLAM_OK;   // 24-bit multiply in the scorer's cell offset
+    if (g.packed_state == 0) {
+        const size_t bytes = edt_packed_bytes(g.meta.rows, g.meta.cols);
+        if (g.packed_buf.cap < bytes || g.table_buf.cap < 1024 + 8) {
+            HIP_TRY(hipStreamSynchronize(e->stream));   // an earlier launch may still read the old copy
+            HIP_TRY(g.packed_buf.ensure(bytes));
+            HIP_TRY(g.table_buf.ensure(1024 + 8));
+        }
+        uint32_t* flag = reinterpret_cast<uint32_t*>(g.table_buf.as<float>() + 256);
+        HIP_TRY(launch_edt_pack(e->stream, g.d_edt, g.meta.ld, g.meta.rows, g.meta.cols, g.packed_buf.as<uint8_t>(),
+                                g.table_buf.as<float>(), flag));
+        uint32_t verdict[2] = { 0, 1 };
+        HIP_TRY(hipMemcpyAsync(verdict, flag, sizeof verdict, hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        g.packed_state = verdict[1] == 0 ? 1 : 2;
+    }
+    if (g.packed_state == 1) {
+        out->packed = g.packed_buf.as<uint8_t>();
+        out->table = g.table_buf.as<float>();
+        out->strip_bytes = strip_bytes;
+    }
+    return SLAM_OK;
+}
+
 // host-side Philox4x32-10 for the comb offset
 void philox_host(uint32_t c[4], uint32_t k0, uint32_t k1)
 {
@@ -355,6 +391,8 @@ int slam_edt_dev(slam_engine* e, const int32_t* d_occ, int ld, int rows, int col
     if (!d_occ || !d_out || rows < 0 || cols < 0 || ld < cols || !(cap >= 0.0f)) return SLAM_ERR_INVALID_ARG;
     if (ceilf(cap) > (float)EDT_MAX_RADIUS) return SLAM_ERR_CAPACITY;
     HIP_TRY(launch_edt(e->stream, d_occ, ld, rows, cols, cap, d_out, e->prof_next(SLAM_PROF_EDT)));
+    for (GridSlot& g : e->grid)   // an adopted grid rebuilt in place: its packed copy is stale
+        if (g.ready && g.d_edt == d_out) g.packed_state = 0;
     return SLAM_OK;
 }
 
@@ -397,6 +435,7 @@ int slam_grid_upload_host(slam_engine* e, int slot, const int32_t* occ, const sl
     g.meta = *meta;
     g.d_edt = g.edt_buf.as<float>();
     g.ready = true;
+    g.packed_state = 0;
     if (edt_out && meta->rows > 0 && meta->cols > 0) {
         HIP_TRY(hipMemcpy2DAsync(edt_out, (size_t)meta->ld * sizeof(float), g.edt_buf.p,
                                  (size_t)meta->ld * sizeof(float), (size_t)meta->cols * sizeof(float),
@@ -414,6 +453,7 @@ int slam_grid_set_dev(slam_engine* e, int slot, const float* d_edt, const slam_g
     g.meta = *meta;
     g.d_edt = d_edt;
     g.ready = true;
+    g.packed_state = 0;   // the scorers' packed copy is made from the new contents on their next call
     return SLAM_OK;
 }
 
@@ -468,7 +508,9 @@ int slam_score_poses_cs_dev(slam_engine* e, int slot, const float* d_x, const fl
     if (nposes < 0 || (nposes > 0 && (!d_x || !d_y || !d_ct || !d_st || !d_score || !d_count)))
         return SLAM_ERR_INVALID_ARG;
     if (int rc = check_score_inputs(e, slot)) return rc;
-    HIP_TRY(launch_score_poses(e->stream, score_grid(e->grid[slot]), e->d_bx, e->d_by, e->nbeams, d_x, d_y, d_ct, d_st,
+    ScoreGrid sg;
+    if (int rc = many_pose_grid(e, slot, nposes, &sg)) return rc;
+    HIP_TRY(launch_score_poses(e->stream, sg, e->d_bx, e->d_by, e->nbeams, d_x, d_y, d_ct, d_st,
                                nposes, d_score, d_count, e->prof_next(SLAM_PROF_SCORE)));
     return SLAM_OK;
 }
@@ -479,7 +521,9 @@ int slam_score_poses_dev(slam_engine* e, int slot, const float* d_x, const float
     ENTER(e);
     if (nposes < 0 || (nposes > 0 && (!d_x || !d_y || !d_theta || !d_score || !d_count))) return SLAM_ERR_INVALID_ARG;
     if (int rc = check_score_inputs(e, slot)) return rc;
-    HIP_TRY(launch_score_poses(e->stream, score_grid(e->grid[slot]), e->d_bx, e->d_by, e->nbeams, d_x, d_y, d_theta,
+    ScoreGrid sg;
+    if (int rc = many_pose_grid(e, slot, nposes, &sg)) return rc;
+    HIP_TRY(launch_score_poses(e->stream, sg, e->d_bx, e->d_by, e->nbeams, d_x, d_y, d_theta,
                                nullptr, nposes, d_score, d_count, e->prof_next(SLAM_PROF_SCORE)));
     return SLAM_OK;
 }
@@ -495,7 +539,9 @@ static int score_host_common(slam_engine* e, int slot, const float* x, const flo
     for (int k = 0; k < 6; ++k) HIP_TRY(e->host_io[k].ensure(bytes));
     for (int k = 0; k < 4; ++k)
         if (src[k]) HIP_TRY(hipMemcpyAsync(e->host_io[k].p, src[k], bytes, hipMemcpyHostToDevice, e->stream));
-    HIP_TRY(launch_score_poses(e->stream, score_grid(e->grid[slot]), e->d_bx, e->d_by, e->nbeams,
+    ScoreGrid sg;
+    if (int rc = many_pose_grid(e, slot, nposes, &sg)) return rc;
+    HIP_TRY(launch_score_poses(e->stream, sg, e->d_bx, e->d_by, e->nbeams,
                                e->host_io[0].as<float>(), e->host_io[1].as<float>(), e->host_io[2].as<float>(),
                                b ? e->host_io[3].as<float>() : nullptr, nposes, e->host_io[4].as<float>(),
                                e->host_io[5].as<int32_t>()));
@@ -662,7 +708,9 @@ int slam_motion_score_dev(slam_engine* e, int slot, const float* d_src_x, const 
     if (d_src_x == d_x || d_src_y == d_y || d_src_th == d_th) return SLAM_ERR_INVALID_ARG;   // several lanes re-read src
     if (int rc = check_score_inputs(e, slot)) return rc;
     MotionIO io{ d_src_x, d_src_y, d_src_th, d_anc, d_x, d_y, d_th };
-    HIP_TRY(launch_motion_score(e->stream, score_grid(e->grid[slot]), e->d_bx, e->d_by, e->nbeams, io, n, first_id, dp,
+    ScoreGrid sg;
+    if (int rc = many_pose_grid(e, slot, n, &sg)) return rc;
+    HIP_TRY(launch_motion_score(e->stream, sg, e->d_bx, e->d_by, e->nbeams, io, n, first_id, dp,
                                 sigma, seed, frame, d_score, d_count, e->prof_next(SLAM_PROF_SCORE)));
     return SLAM_OK;
 }
@@ -793,7 +841,7 @@ int slam_frame_front_dev(slam_engine* e, int slot, const float* d_src_x, const f
                          const int32_t* d_anc, float* d_x, float* d_y, float* d_th, int n, int64_t first_id, const float dp[3],
                          const float sigma[3], uint64_t seed, uint32_t frame, float* d_score, int32_t* d_count,
                          const float* d_map_in, float* d_map_out, int64_t row_stride, int plane_stride, int nlandmarks,
-                         float meas_var, bool* launched)
+                         float meas_var, bool* launched, const slam::SplitIO* split)
 {
     ENTER(e);
     *launched = false;
@@ -805,7 +853,7 @@ int slam_frame_front_dev(slam_engine* e, int slot, const float* d_src_x, const f
         !d_count || !d_anc || !d_map_in || !d_map_out || d_map_in == d_map_out)
         return SLAM_OK;   // the two calls will say what is wrong
     if (d_src_x == d_x || d_src_y == d_y || d_src_th == d_th) return SLAM_ERR_INVALID_ARG;
-    if (nlandmarks <= 128 || plane_stride < nlandmarks || row_stride < 5 * (int64_t)plane_stride || !(meas_var > 0.0f))
+    if (nlandmarks <= 128 || plane_stride < nlandmarks || row_stride < (split ? 2 : 5) * (int64_t)plane_stride || !(meas_var > 0.0f))
         return SLAM_OK;
     if (int rc = check_score_inputs(e, slot)) return rc;
     if (e->obs_nlandmarks < 0 || e->obs_nlandmarks != nlandmarks) return SLAM_ERR_NOT_READY;
@@ -829,10 +877,20 @@ int slam_frame_front_dev(slam_engine* e, int slot, const float* d_src_x, const f
     a.loglik = e->ll_buf.as<float>();
     a.loglik_user = nullptr;
     a.xcd_chunk = 0;
+    if (split) {
+        a.cov = split->cov;
+        a.cov_stride = split->cov_stride;
+        a.cls_in = split->cls_in;
+        a.cls_out = split->cls_out;
+        a.cstamp = split->cstamp;
+        a.stamp_now = split->stamp_now;
+    }
     MotionIO io{ d_src_x, d_src_y, d_src_th, d_anc, d_x, d_y, d_th };
     int lanes = 0;
     // one bracket for the whole launch: it counts as the frame's landmark update (the dominant stage)
-    HIP_TRY(launch_frame_front(e->stream, score_grid(e->grid[slot]), e->d_bx, e->d_by, e->nbeams, io, first_id, dp, sigma, seed,
+    ScoreGrid sg;
+    if (int rc = many_pose_grid(e, slot, n, &sg)) return rc;
+    HIP_TRY(launch_frame_front(e->stream, sg, e->d_bx, e->d_by, e->nbeams, io, first_id, dp, sigma, seed,
                                frame, d_score, d_count, a, group, e->prof_next(SLAM_PROF_EKF), launched, &lanes));
     if (*launched) {
         e->front_last[0] = group;
@@ -841,6 +899,47 @@ int slam_frame_front_dev(slam_engine* e, int slot, const float* d_src_x, const f
         e->ekf_form_launches[1]++;
         e->front_launches++;
     }
+    return SLAM_OK;
+}
+
+int slam_ekf_split_dev(slam_engine* e, const float* d_mean_in, float* d_mean_out, int64_t row_stride, int plane_stride,
+                       int nlandmarks, const float* d_x, const float* d_y, const float* d_th, const int32_t* d_anc, int n,
+                       float meas_var, const slam::SplitIO* split)
+{
+    ENTER(e);
+    if (n <= 0 || nlandmarks <= 0 || plane_stride < nlandmarks || row_stride < 2 * (int64_t)plane_stride || !(meas_var > 0.0f) ||
+        !d_mean_in || !d_mean_out || d_mean_in == d_mean_out || !d_x || !d_y || !d_th || !split || !split->cov || !split->cls_in ||
+        !split->cls_out || !split->cstamp)
+        return SLAM_ERR_INVALID_ARG;
+    if (e->obs_nlandmarks < 0 || e->obs_nlandmarks != nlandmarks) return SLAM_ERR_NOT_READY;
+    HIP_TRY(e->ll_buf.ensure(sizeof(float) * (size_t)n));
+    EkfArgs a;
+    a.map_in = d_mean_in;
+    a.map_out = d_mean_out;
+    a.row_stride = row_stride;
+    a.plane_stride = plane_stride;
+    a.nlandmarks = nlandmarks;
+    a.x = d_x;
+    a.y = d_y;
+    a.th = d_th;
+    a.anc = d_anc;
+    a.n = n;
+    a.obs_zx = e->d_obs_zx;
+    a.obs_zy = e->d_obs_zy;
+    a.meas_var = meas_var;
+    a.loglik = e->ll_buf.as<float>();
+    a.loglik_user = nullptr;
+    a.xcd_chunk = 0;
+    a.cov = split->cov;
+    a.cov_stride = split->cov_stride;
+    a.cls_in = split->cls_in;
+    a.cls_out = split->cls_out;
+    a.cstamp = split->cstamp;
+    a.stamp_now = split->stamp_now;
+    const int group = e->ekf_group_size(n, d_anc != nullptr, plane_stride, false);
+    HIP_TRY(launch_ekf_update(e->stream, a, e->prof_next(SLAM_PROF_EKF), group == 4 ? 4 : 2));
+    e->ekf_form_launches[1]++;
+    e->ll_n = n;
     return SLAM_OK;
 }
 

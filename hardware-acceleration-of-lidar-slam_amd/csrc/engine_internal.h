@@ -42,6 +42,10 @@ struct GridSlot {
     slam_grid_meta meta{};
     const float* d_edt = nullptr;   // owned (edt_buf) or adopted
     DevBuf occ_buf, edt_buf;
+    // the byte-per-cell copy the many-pose scorers gather from (kernels.h: ScoreGrid::packed), made on the first such call
+    // after the grid changed: 0 = not made yet, 1 = in use, 2 = this grid has no such copy (values the table cannot give back)
+    int packed_state = 0;
+    DevBuf packed_buf, table_buf;   // table_buf: 256 floats + the two flag words of launch_edt_pack
 };
 
 constexpr int kLattice = 27;
@@ -235,7 +239,12 @@ extern "C" int slam_frame_front_dev(slam_engine* e, int slot, const float* d_src
                          const int32_t* d_anc, float* d_x, float* d_y, float* d_th, int n, int64_t first_id, const float dp[3],
                          const float sigma[3], uint64_t seed, uint32_t frame, float* d_score, int32_t* d_count,
                          const float* d_map_in, float* d_map_out, int64_t row_stride, int plane_stride, int nlandmarks,
-                         float meas_var, bool* launched);
+                         float meas_var, bool* launched, const slam::SplitIO* split = nullptr);
+// the out-of-place landmark update on the SPLIT layout (kernels.h: EkfArgs): d_mean_in / d_mean_out are rows of two planes
+// (row_stride >= 2 * plane_stride), the covariances come per class through `split`; otherwise slam_ekf_update_dev
+extern "C" int slam_ekf_split_dev(slam_engine* e, const float* d_mean_in, float* d_mean_out, int64_t row_stride, int plane_stride,
+                       int nlandmarks, const float* d_x, const float* d_y, const float* d_th, const int32_t* d_anc, int n,
+                       float meas_var, const slam::SplitIO* split);
 int slam_engine_fail_hip(slam_engine* e, hipError_t err, const char* what);
 slam::ScoreGrid slam_engine_score_grid(const slam_engine* e, int slot);
 // FastMatch on grid `slot` with the beam count read from device memory (d_nbeams, at most nbeams_max) and the

@@ -21,7 +21,21 @@ struct ScoreGrid {
     int rows, cols, ld;
     float ipix;         // 1 / pixel, computed on the host with one float division (main.c:383)
     float min_x, min_y;
+    // Optional packed copy of the same grid for the many-pose scorers (launch_edt_pack): one BYTE per cell, stored in
+    // vertical strips of 16 columns — cell (ix, iy) at (ix >> 4) * strip_bytes + iy * 16 + (ix & 15) — so that a 128-byte
+    // line holds a 16 x 8 patch of cells, and a 256-entry table that turns a byte back into the cell's float, bit for bit.
+    const uint8_t* packed = nullptr;
+    const float* table = nullptr;
+    int strip_bytes = 0;   // 16 * (rows rounded up to 8)
 };
+// The capped EDT (main.c:223-269, Appendix A.4) holds few distinct values: 0 on an occupied cell, sqrtf(d2) of a small
+// integer d2 below the cap, and the cap itself.  launch_edt_pack writes code(cell) = d2 (255: the grid's largest value) into
+// `packed`, table[code] = the float it stands for, and flag[1] = 1 if some cell of the rows x cols rectangle is not table[its
+// code] bit for bit (a grid that did not come from the EDT kernels, or a cap above 15.9 cells): the caller then keeps the
+// float grid.  flag: two device words {largest value's bits (scratch), bad}, zeroed by the launcher.
+size_t edt_packed_bytes(int rows, int cols);
+hipError_t launch_edt_pack(hipStream_t stream, const float* edt, int ld, int rows, int cols, uint8_t* packed, float* table,
+                           uint32_t* flag);
 hipError_t launch_score_poses(hipStream_t stream, const ScoreGrid& g, const float* bx, const float* by, int nbeams,
                               const float* x, const float* y, const float* th_or_ct, const float* st_or_null,
                               int nposes, float* score, int32_t* count, const EventPair* ev = nullptr);
@@ -99,6 +113,15 @@ struct EkfArgs {
     int32_t* cls_out = nullptr;       // class of every particle of this frame
     uint32_t* cstamp = nullptr;       // [classes]: stamp_now = "a particle of this frame belongs to the class"
     uint32_t stamp_now = 0;
+};
+// the split layout's part of EkfArgs, as the session hands it to the engine's stage functions
+struct SplitIO {
+    const float* cov;
+    int64_t cov_stride;
+    const int32_t* cls_in;
+    int32_t* cls_out;
+    uint32_t* cstamp;
+    uint32_t stamp_now;
 };
 // group_size: 0 = one wavefront per particle; 2 / 4 / 8 = the grouped out-of-place form (that many neighbouring particles
 // per wavefront share their source rows in registers) — a speed choice only, every form gives the same bits

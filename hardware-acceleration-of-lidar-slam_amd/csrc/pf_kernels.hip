@@ -720,7 +720,7 @@ struct FrontArgs {
     int score_span;      // the scoring octets lie among the first score_span octets of the grid
 };
 
-template <int NB, int G, int LPP, int DEPTH, bool SPLIT = false>
+template <int NB, int G, int LPP, int DEPTH, bool SPLIT = false, bool PACKED = false>
 __global__ __launch_bounds__(kEkfWaves * 64) EKF_GROUP_ATTR void frame_front_kernel(FrontArgs f)
 {
     static_assert(kScoreBlock == kEkfWaves * 64, "both kinds of workgroup have 256 threads");
@@ -736,8 +736,8 @@ __global__ __launch_bounds__(kEkfWaves * 64) EKF_GROUP_ATTR void frame_front_ker
     if (upto > before) {   // a scoring octet (wave-uniform, workgroup-uniform)
         const int sb = before * 8 + xcd;
         if (sb >= f.score_blocks) return;
-        score_poses_body<false, LPP, DEPTH, true>(f.g, f.bx, f.by, f.nbeams, f.mio.x, f.mio.y, f.mio.th, nullptr, f.a.n, f.score,
-                                                  f.count, f.mio, f.mpar, sb, s_pair);
+        score_poses_body<false, LPP, DEPTH, true, PACKED>(f.g, f.bx, f.by, f.nbeams, f.mio.x, f.mio.y, f.mio.th, nullptr, f.a.n,
+                                                          f.score, f.count, f.mio, f.mpar, sb, s_pair);
     } else if constexpr (SPLIT) {
         ekf_split_body<NB, G, true>(f.a, xcd * f.ekf_octets + (o - before), s_acc, f.mio, f.mpar);
     } else {
@@ -1979,23 +1979,30 @@ hipError_t launch_frame_front(hipStream_t stream, const ScoreGrid& g, const floa
     static const int span_pct = getenv("SLAM_FRONT_SPAN") ? atoi(getenv("SLAM_FRONT_SPAN")) : 100;
     const int64_t span = (int64_t)(f.score_octets + f.ekf_octets) * (span_pct < 1 ? 1 : span_pct > 100 ? 100 : span_pct) / 100;
     f.score_span = (int)(span > f.score_octets ? span : f.score_octets);
-    const size_t lds = sizeof(float2) * (size_t)(nbeams + (quad ? 4 * kQuadDepth : kLaneDepth));
+    const size_t lds = sizeof(float2) * (size_t)(nbeams + (quad ? 4 * kQuadDepth : kLaneDepth)) + (g.packed ? 1024 : 0);
     if (ev) (void)hipEventRecord(ev->start, stream);
-    if (f.a.cov) {   // split layout
-        if (quad) {
-            if (G == 2) frame_front_kernel<EKF_GROUP_NB, 2, 4, kQuadDepth, true><<<grid, kEkfWaves * 64, lds, stream>>>(f);
-            else frame_front_kernel<EKF_GROUP_NB, 4, 4, kQuadDepth, true><<<grid, kEkfWaves * 64, lds, stream>>>(f);
-        } else {
-            if (G == 2) frame_front_kernel<EKF_GROUP_NB, 2, 1, kLaneDepth, true><<<grid, kEkfWaves * 64, lds, stream>>>(f);
-            else frame_front_kernel<EKF_GROUP_NB, 4, 1, kLaneDepth, true><<<grid, kEkfWaves * 64, lds, stream>>>(f);
-        }
-    } else if (quad) {
-        if (G == 2) frame_front_kernel<EKF_GROUP_NB, 2, 4, kQuadDepth><<<grid, kEkfWaves * 64, lds, stream>>>(f);
-        else frame_front_kernel<EKF_GROUP_NB, 4, 4, kQuadDepth><<<grid, kEkfWaves * 64, lds, stream>>>(f);
+    // the instantiation: particles per updating wavefront x scorer's lane mapping x map layout x grid copy the scorer reads
+#define SLAM_FRONT(G_, LPP_, DEPTH_, SP_, PK_) \
+    frame_front_kernel<EKF_GROUP_NB, G_, LPP_, DEPTH_, SP_, PK_><<<grid, kEkfWaves * 64, lds, stream>>>(f)
+#define SLAM_FRONT_GL(SP_, PK_)                          \
+    do {                                                 \
+        if (quad) {                                      \
+            if (G == 2) SLAM_FRONT(2, 4, kQuadDepth, SP_, PK_); \
+            else SLAM_FRONT(4, 4, kQuadDepth, SP_, PK_);        \
+        } else {                                         \
+            if (G == 2) SLAM_FRONT(2, 1, kLaneDepth, SP_, PK_); \
+            else SLAM_FRONT(4, 1, kLaneDepth, SP_, PK_);        \
+        }                                                \
+    } while (0)
+    if (f.a.cov) {
+        if (f.g.packed) SLAM_FRONT_GL(true, true);
+        else SLAM_FRONT_GL(true, false);
     } else {
-        if (G == 2) frame_front_kernel<EKF_GROUP_NB, 2, 1, kLaneDepth><<<grid, kEkfWaves * 64, lds, stream>>>(f);
-        else frame_front_kernel<EKF_GROUP_NB, 4, 1, kLaneDepth><<<grid, kEkfWaves * 64, lds, stream>>>(f);
+        if (f.g.packed) SLAM_FRONT_GL(false, true);
+        else SLAM_FRONT_GL(false, false);
     }
+#undef SLAM_FRONT_GL
+#undef SLAM_FRONT
     if (ev) (void)hipEventRecord(ev->stop, stream);
     *launched = true;
     if (lanes_per_pose) *lanes_per_pose = quad ? 4 : 1;

@@ -74,6 +74,21 @@ struct slam_pf {
     uint32_t stamp_now = 0;
     int32_t* page_scratch = nullptr;   // the free list's bookkeeping (pool_state_words()) | count | tpage[nb] | tindex[nb] | tmask[nb] | tbase[nb + 1] |
                                        // the frame's observation list id[Lp] | zx[Lp] | zy[Lp] | round[Lp] | {count, highest round}
+    // ---- split layout (SLAM_MAP_SPLIT, and what SLAM_MAP_AUTO keeps a single-GPU session on while its frames observe most
+    // landmarks): means per particle, covariances per covariance class (split_kernels.hip); carved out of the same store
+    bool split = false;
+    bool dense_split = false;       // AUTO's layout for dense frames is split (else rows)
+    float* mean[2] = { nullptr, nullptr };   // [cap][2][Lp]: mean[0] and cov share one half of the store, mean[1] starts the other
+    float* cov = nullptr;           // [cap][3][Lp], updated in place once per class and frame
+    int sp_base = 0;                // the half of the store that holds mean[0] and cov
+    int sp_cur = 0;                 // mean / class buffer of the current particles
+    int32_t* cls[2] = { nullptr, nullptr };    // [cap]
+    int32_t* live[2] = { nullptr, nullptr };   // [cap] the classes in use, current list and next
+    int32_t* cov_cnt = nullptr;     // [3] list lengths, rotating (see cov_update_kernel)
+    uint32_t* cstamp = nullptr;     // [cap]
+    uint32_t cstamp_now = 0, cls_epoch = 0;
+    int live_cur = 0, cov_phase = 0;
+    void* split_scratch = nullptr;  // flags, prefix sums of a rows -> split move
     bool gated = false;             // cfg.resample_ess_frac in (0, 1): a frame resamples only when its ESS is low
     int64_t frames_resampled = 0;   // (as far as the host has looked: one frame behind)
     // SLAM_MAP_AUTO: the session watches how many landmarks the frames observe ({observed, L, seq} in words 24..26 of h_res,
@@ -325,6 +340,97 @@ int convert_to_rows(slam_pf* pf)
     return SLAM_OK;
 }
 
+// ---- split layout: tables, placement in the store, moves
+void free_split_tables(slam_pf* pf)
+{
+    for (void** p : { (void**)&pf->cls[0], (void**)&pf->cls[1], (void**)&pf->live[0], (void**)&pf->live[1], (void**)&pf->cov_cnt,
+                      (void**)&pf->cstamp, &pf->split_scratch }) {
+        if (*p) (void)hipFree(*p);
+        *p = nullptr;
+    }
+}
+
+bool alloc_split_tables(slam_pf* pf)
+{
+    const size_t cap = (size_t)pf->cap;
+    bool ok = true;
+    for (int b = 0; b < 2; ++b)
+        ok = ok && dev_alloc((void**)&pf->cls[b], cap * 4) == hipSuccess && dev_alloc((void**)&pf->live[b], cap * 4) == hipSuccess;
+    ok = ok && dev_alloc((void**)&pf->cov_cnt, 16) == hipSuccess && hipMemset(pf->cov_cnt, 0, 16) == hipSuccess &&
+         dev_alloc((void**)&pf->cstamp, cap * 4) == hipSuccess && hipMemset(pf->cstamp, 0, cap * 4) == hipSuccess &&
+         dev_alloc(&pf->split_scratch, split_scratch_words(pf->n) * 4) == hipSuccess;
+    if (!ok) {
+        (void)hipGetLastError();
+        free_split_tables(pf);
+    }
+    return ok;
+}
+
+// mean[0] and cov take the half `base` of the store (2 + 3 of its 5 units), mean[1] the start of the other half
+void place_split(slam_pf* pf, int base)
+{
+    const size_t half = 5 * (size_t)pf->Lp * (size_t)pf->cap;
+    pf->sp_base = base;
+    pf->mean[0] = pf->store + (size_t)base * half;
+    pf->cov = pf->mean[0] + 2 * (size_t)pf->Lp * (size_t)pf->cap;
+    pf->mean[1] = pf->store + (size_t)(1 - base) * half;
+}
+
+int32_t* split_h_live(slam_pf* pf) { return reinterpret_cast<int32_t*>(pf->d_hres) + 22; }   // {classes in use, epoch}
+
+// a new set of classes is about to be made (set_map, reset, rows -> split): lists and counters start afresh
+void split_new_epoch(slam_pf* pf)
+{
+    pf->cls_epoch++;
+    pf->cstamp_now++;
+    pf->live_cur = 0;
+    pf->cov_phase = 0;
+}
+
+// rows (as given, any strides) -> means + classes + class rows in the buffers of the current placement
+int split_from_rows(slam_pf* pf, const float* d_rows, int64_t row_stride, int plane_stride)
+{
+    slam_engine* e = pf->e;
+    split_new_epoch(pf);
+    SLAM_HIP_TRY(e, launch_split_from_rows(e->stream, d_rows, row_stride, plane_stride, pf->L, pf->n, pf->Lp, pf->mean[pf->sp_cur], pf->cov,
+                                           pf->cls[pf->sp_cur], pf->live[0], pf->cov_cnt, 0, pf->cstamp, pf->cstamp_now,
+                                           split_h_live(pf), pf->cls_epoch, pf->split_scratch));
+    return SLAM_OK;
+}
+
+// rows -> split while the session runs: stream-ordered, no allocation.  The rows sit in one half of the store; the means and
+// the class rows go into the OTHER half, and the half the rows came from becomes the second mean buffer.
+int convert_rows_to_split(slam_pf* pf)
+{
+    const int mc = pf->map_cur;
+    place_split(pf, 1 - mc);
+    pf->sp_cur = 0;
+    if (int rc = split_from_rows(pf, pf->map[mc], 5 * (int64_t)pf->Lp, pf->Lp)) return rc;
+    pf->split = true;
+    pf->conversions++;
+    return SLAM_OK;
+}
+
+// split -> rows: into the half of the store that does not hold mean[0] and cov (the current means move to mean[0] first when
+// they sit in mean[1], which starts that half)
+int convert_split_to_rows(slam_pf* pf)
+{
+    slam_engine* e = pf->e;
+    const size_t n = (size_t)pf->n, Lp = (size_t)pf->Lp;
+    if (pf->sp_cur == 1) {
+        SLAM_HIP_TRY(e, hipMemcpyAsync(pf->mean[0], pf->mean[1], 2 * Lp * n * 4, hipMemcpyDeviceToDevice, e->stream));
+        SLAM_HIP_TRY(e, hipMemcpyAsync(pf->cls[0], pf->cls[1], n * 4, hipMemcpyDeviceToDevice, e->stream));
+        pf->sp_cur = 0;
+    }
+    const int target = 1 - pf->sp_base;
+    SLAM_HIP_TRY(e, launch_rows_from_split(e->stream, pf->mean[0], pf->cov, pf->cls[0], pf->Lp, nullptr, pf->n, pf->map[target],
+                                           5 * (int64_t)Lp, pf->Lp, pf->L));
+    pf->map_cur = target;
+    pf->split = false;
+    pf->conversions++;
+    return SLAM_OK;
+}
+
 // SLAM_MAP_AUTO, at the start of a frame: look at the counts that have arrived since the last look (no waiting) and move
 // when the last three agree.  Pages pay when a frame observes at most a quarter of the landmarks (a resampling frame on
 // rows rewrites every row in full); rows pay when it observes more than half (every page is touched anyway and the row
@@ -349,16 +455,27 @@ int auto_layout(slam_pf* pf)
     pf->obs_seq_seen = seq;
     pf->votes_pages = h[3];   // samples in a row (counted on the device, so none is missed however far the host runs ahead)
     pf->votes_rows = h[4];
-    if (!pf->paged && pf->votes_pages >= 3) return convert_to_pages(pf);
-    if (pf->paged && pf->votes_rows >= 3) return convert_to_rows(pf);
+    if (!pf->paged && pf->votes_pages >= 3) {
+        if (pf->split)
+            if (int rc = convert_split_to_rows(pf)) return rc;
+        return convert_to_pages(pf);
+    }
+    if (pf->paged && pf->votes_rows >= 3) {
+        if (int rc = convert_to_rows(pf)) return rc;
+        if (!pf->paged && pf->dense_split) return convert_rows_to_split(pf);
+    }
     return SLAM_OK;
 }
 
 int create_common(slam_engine* e, const slam_pf_config* cfg, slam_comm* comm, int recv_capacity, slam_pf** out)
 {
     if (!e || !cfg || !out || cfg->n_particles <= 0 || cfg->n_landmarks < 0 || !(cfg->meas_var > 0.0f) ||
-        cfg->map_layout < SLAM_MAP_AUTO || cfg->map_layout > SLAM_MAP_PAGES)
+        cfg->map_layout < SLAM_MAP_AUTO || cfg->map_layout > SLAM_MAP_SPLIT)
         return SLAM_ERR_INVALID_ARG;
+    if (comm && cfg->map_layout == SLAM_MAP_SPLIT) {
+        snprintf(e->err, sizeof e->err, "SLAM_MAP_SPLIT: covariance classes are local to a GPU; sharded sessions keep rows or pages");
+        return SLAM_ERR_INVALID_ARG;
+    }
     *out = nullptr;
     if (e->live_sessions > 0) {   // the stages keep per-population state in the engine (gate, carried weights, exchange plan)
         snprintf(e->err, sizeof e->err, "this engine already runs a particle-filter session: one session per engine");
@@ -404,7 +521,17 @@ int create_common(slam_engine* e, const slam_pf_config* cfg, slam_comm* comm, in
         pf->npages = np > 0x7fffffff - 8192 ? 0 : (int)np;
         if (pf->nb < 2) pf->auto_stuck = true;   // one page per particle: nothing to gain from pages
     }
+    pf->gated = cfg->resample_ess_frac > 0.0f && cfg->resample_ess_frac < 1.0f;
     if (L) ok = alloc_store(pf);
+    // the split layout: asked for, or what AUTO keeps a single-GPU session that resamples every frame on while its frames
+    // observe most landmarks (a sharded session's classes would have to travel; a gated one updates in place, which rows do)
+    if (L && ok && !comm && (pf->layout_cfg == SLAM_MAP_SPLIT || (pf->layout_cfg == SLAM_MAP_AUTO && !pf->gated))) {
+        const bool have = alloc_split_tables(pf);
+        if (!have && pf->layout_cfg == SLAM_MAP_SPLIT) ok = false;
+        pf->dense_split = have && pf->layout_cfg == SLAM_MAP_AUTO;
+        pf->split = have;
+        if (have) place_split(pf, 0);
+    }
     if (L && ok && (pf->paged || (pf->layout_cfg == SLAM_MAP_AUTO && !pf->auto_stuck))) {
         ok = alloc_page_tables(pf);
         if (!ok && !pf->paged) {   // AUTO can live without them: it stays on rows
@@ -443,7 +570,6 @@ int create_common(slam_engine* e, const slam_pf_config* cfg, slam_comm* comm, in
             slam_pf_destroy(pf);
             return rc;
         }
-    pf->gated = cfg->resample_ess_frac > 0.0f && cfg->resample_ess_frac < 1.0f;
     if (int rc = slam_resample_gate_set(e, pf->gated ? cfg->resample_ess_frac : 0.0f)) {
         slam_pf_destroy(pf);
         return rc;
@@ -492,6 +618,7 @@ int slam_pf_destroy(slam_pf* pf)
     }
     if (pf->store) (void)hipFree(pf->store);
     free_page_tables(pf);
+    free_split_tables(pf);
     for (void* p : { (void*)pf->score, (void*)pf->logw, (void*)pf->count, (void*)pf->first, (void*)pf->pose_all, (void*)pf->pose_stage, (void*)pf->first_all,
                      (void*)pf->d_max, (void*)pf->d_sum, (void*)pf->totals, (void*)pf->d_plan, (void*)pf->sbuf,
                      (void*)pf->rbuf, (void*)pf->res_dev, (void*)pf->sums_acc, pf->res_all })
@@ -512,7 +639,12 @@ int slam_pf_reset(slam_pf* pf, const float pose[3])
     if (int rc = drop_resample(pf)) return rc;
     if (int rc = slam_engine_sync(pf->e)) return rc;
     if (hipMemcpy(pf->pose[pf->cur], h.data(), 3 * n * 4, hipMemcpyHostToDevice) != hipSuccess) return SLAM_ERR_HIP;
-    if (pf->paged) {   // every particle names ONE shared page of landmarks not seen yet
+    if (pf->split) {   // every landmark of every particle "not seen yet": one class
+        split_new_epoch(pf);
+        SLAM_HIP_TRY(pf->e, launch_split_reset(pf->e->stream, pf->mean[pf->sp_cur], pf->cov, pf->cls[pf->sp_cur], pf->Lp, pf->n, pf->live[0],
+                                               pf->cov_cnt, 0, pf->cstamp, pf->cstamp_now, split_h_live(pf), pf->cls_epoch));
+        if (int rc = slam_engine_sync(pf->e)) return rc;
+    } else if (pf->paged) {   // every particle names ONE shared page of landmarks not seen yet
         SLAM_HIP_TRY(pf->e, launch_pages_reset(pf->e->stream, pf->pool, pf->pt[pf->pt_cur], (int64_t)pf->n * pf->nb, pf->freelist,
                                                pf->npages, pf->page_scratch));
         if (int rc = slam_engine_sync(pf->e)) return rc;
@@ -554,13 +686,14 @@ int slam_pf_set_map_host(slam_pf* pf, const float* rows)
     if (int rc = slam_engine_sync(pf->e)) return rc;
     if (pf->has_anc) return SLAM_ERR_NOT_READY;   // set poses / reset first: a gather is pending
     // host [n][5][L] -> device [n][5][Lp]: 5n planes of L floats each
-    float* dense = pf->paged ? nullptr : pf->map[pf->map_cur];
-    if (pf->paged && hipMalloc((void**)&dense, 5 * (size_t)pf->Lp * pf->n * 4) != hipSuccess) return SLAM_ERR_HIP;
+    const bool indirect = pf->paged || pf->split;   // no rows to copy into: a scratch copy goes through slam_pf_set_map_dev
+    float* dense = indirect ? nullptr : pf->map[pf->map_cur];
+    if (indirect && hipMalloc((void**)&dense, 5 * (size_t)pf->Lp * pf->n * 4) != hipSuccess) return SLAM_ERR_HIP;
     int rc = SLAM_OK;
     if (hipMemcpy2D(dense, (size_t)pf->Lp * 4, rows, (size_t)pf->L * 4, (size_t)pf->L * 4, 5 * (size_t)pf->n,
                     hipMemcpyHostToDevice) != hipSuccess)
         rc = SLAM_ERR_HIP;
-    if (pf->paged) {
+    if (indirect) {
         if (rc == SLAM_OK) rc = slam_pf_set_map_dev(pf, dense, 5 * (int64_t)pf->Lp, pf->Lp);
         if (rc == SLAM_OK) rc = slam_engine_sync(pf->e);
         (void)hipFree(dense);
@@ -574,6 +707,7 @@ int slam_pf_set_map_dev(slam_pf* pf, const float* d_rows, int64_t row_stride, in
     if (pf->has_anc) return SLAM_ERR_NOT_READY;   // set poses / reset first: a gather is pending
     slam_engine* e = pf->e;
     SLAM_HIP_TRY(e, hipSetDevice(e->device));
+    if (pf->split) return split_from_rows(pf, d_rows, row_stride, plane_stride);
     if (pf->paged) {
         SLAM_HIP_TRY(e, launch_pages_from_rows(e->stream, d_rows, row_stride, plane_stride, pf->L, pf->nb, pf->n, pf->pool,
                                                pf->pt[pf->pt_cur], pf->freelist, pf->npages, pf->page_scratch));
@@ -628,10 +762,24 @@ static int pf_step_impl(slam_pf* pf, int slot, const float dp[3], int use_observ
     // observed, long rows, enough particles): motion sample + scan-match score and the out-of-place landmark update side by
     // side, the scorer's gathers in the shadow of the update's row stores (slam_frame_front_dev; the same bits)
     bool fused = false;
+    SplitIO sio{};
+    if (pf->split) {   // the classes follow their particles through the update; it stamps the ones still in use
+        sio.cov = pf->cov;
+        sio.cov_stride = 3 * (int64_t)pf->Lp;
+        sio.cls_in = pf->cls[pf->sp_cur];
+        sio.cls_out = pf->cls[1 - pf->sp_cur];
+        sio.cstamp = pf->cstamp;
+        sio.stamp_now = pf->cstamp_now + 1;
+    }
     if (!comm && !pf->paged && !pf->gated && anc && L > 0 && use_observations && e->obs_nlandmarks == L) {
-        rc = slam_frame_front_dev(e, slot, src, src + sn, src + 2 * sn, anc, dst, dst + sn, dst + 2 * sn, n, first_id, dp,
-                                  pf->cfg.sigma, pf->cfg.seed, pf->frame, pf->score, pf->count, pf->map[pf->map_cur],
-                                  pf->map[1 - pf->map_cur], 5 * (int64_t)pf->Lp, pf->Lp, L, pf->cfg.meas_var, &fused);
+        if (pf->split)
+            rc = slam_frame_front_dev(e, slot, src, src + sn, src + 2 * sn, anc, dst, dst + sn, dst + 2 * sn, n, first_id, dp,
+                                      pf->cfg.sigma, pf->cfg.seed, pf->frame, pf->score, pf->count, pf->mean[pf->sp_cur],
+                                      pf->mean[1 - pf->sp_cur], 2 * (int64_t)pf->Lp, pf->Lp, L, pf->cfg.meas_var, &fused, &sio);
+        else
+            rc = slam_frame_front_dev(e, slot, src, src + sn, src + 2 * sn, anc, dst, dst + sn, dst + 2 * sn, n, first_id, dp,
+                                      pf->cfg.sigma, pf->cfg.seed, pf->frame, pf->score, pf->count, pf->map[pf->map_cur],
+                                      pf->map[1 - pf->map_cur], 5 * (int64_t)pf->Lp, pf->Lp, L, pf->cfg.meas_var, &fused);
         if (rc != SLAM_OK) return rc;
     }
     // 1 + 2. motion (+ the fused gather of the previous resample) and scan-match score, one launch.  Sharded: the
@@ -670,7 +818,55 @@ static int pf_step_impl(slam_pf* pf, int slot, const float dp[3], int use_observ
     const bool ekf = L > 0 && use_observations;
     const int mc = pf->map_cur, mn = 1 - mc;
     float* d_max = comm ? pf->d_max : nullptr;
-    if (pf->paged) {
+    if (pf->split && L > 0) {
+        const int sc = pf->sp_cur;
+        if (ekf) {
+            if (e->obs_nlandmarks != L) return SLAM_ERR_NOT_READY;
+            if (sample_obs) SLAM_HIP_TRY(e, launch_obs_count(e->stream, e->d_obs_zx, e->d_obs_zy, L, d_hobs, ++pf->obs_seq_issued, pf->votes));
+            // the particles' update (a frame that kept its population runs it out of place all the same: its gather index is
+            // the identity) ...
+            if (!fused)
+                if ((rc = slam_ekf_split_dev(e, pf->mean[sc], pf->mean[1 - sc], 2 * (int64_t)pf->Lp, pf->Lp, L, dst, dst + sn, dst + 2 * sn,
+                                             anc, n, pf->cfg.meas_var, &sio)) != SLAM_OK)
+                    return rc;
+            pf->cstamp_now++;
+            pf->sp_cur = 1 - sc;
+            // ... then the classes' update, in place, once per class still in use.  The launch is as wide as the host knows the
+            // list to be at most: its length as of some earlier frame (mapped memory, read without waiting; the list only
+            // shrinks), the population before anything of this epoch has arrived.
+            const uint64_t hl = __atomic_load_n(reinterpret_cast<const uint64_t*>(reinterpret_cast<const int32_t*>(pf->h_res) + 22), __ATOMIC_ACQUIRE);
+            const int32_t seen = (int32_t)(uint32_t)hl;   // {count, epoch} in one word
+            const int bound = (uint32_t)(hl >> 32) == pf->cls_epoch && seen > 0 && seen < n ? seen : n;
+            CovArgs ca;
+            ca.cov = pf->cov;
+            ca.cov_stride = 3 * (int64_t)pf->Lp;
+            ca.plane_stride = pf->Lp;
+            ca.nlandmarks = L;
+            ca.obs_zx = e->d_obs_zx;
+            ca.obs_zy = e->d_obs_zy;
+            ca.meas_var = pf->cfg.meas_var;
+            ca.live_in = pf->live[pf->live_cur];
+            ca.live_out = pf->live[1 - pf->live_cur];
+            ca.cnt = pf->cov_cnt;
+            ca.phase = pf->cov_phase;
+            ca.cstamp = pf->cstamp;
+            ca.stamp_now = pf->cstamp_now;
+            ca.h_live = split_h_live(pf);
+            ca.epoch = pf->cls_epoch;
+            SLAM_HIP_TRY(e, launch_cov_update(e->stream, ca, bound, e->prof_next(SLAM_PROF_PAGES)));
+            pf->live_cur = 1 - pf->live_cur;
+            pf->cov_phase = (pf->cov_phase + 1) % 3;
+            rc = slam_logweight_ekf_dev(e, pf->score, pf->cfg.score_gain, n, pf->logw, d_max);
+        } else {
+            if (anc) {   // means and classes follow their particles
+                const ProfScope prof(e, SLAM_PROF_PAGES);
+                SLAM_HIP_TRY(e, launch_split_gather(e->stream, pf->mean[sc], pf->mean[1 - sc], pf->cls[sc], pf->cls[1 - sc], pf->Lp, anc, n,
+                                                    pf->cstamp, ++pf->cstamp_now));
+                pf->sp_cur = 1 - sc;
+            }
+            rc = slam_logweight_dev(e, pf->score, nullptr, pf->cfg.score_gain, n, pf->logw, d_max);
+        }
+    } else if (pf->paged) {
         const int pc = pf->pt_cur;
         if (ekf) {
             // touched pages of this frame's observation table, the update into fresh pages, the next frame's free list
@@ -808,8 +1004,9 @@ int slam_pf_device_view(slam_pf* pf, slam_pf_view* out)
 {
     if (!pf || !out) return SLAM_ERR_INVALID_ARG;
     out->pose = pf->pose[pf->cur];
-    out->map = pf->L && !pf->paged ? pf->map[pf->map_cur] : nullptr;   // paged maps have no rows to look at: slam_pf_set_map_dev
-    out->map_spare = pf->L && !pf->paged ? pf->map[1 - pf->map_cur] : nullptr;
+    const bool rows = pf->L && !pf->paged && !pf->split;   // pages and split maps have no rows to look at: slam_pf_set_map_dev
+    out->map = rows ? pf->map[pf->map_cur] : nullptr;
+    out->map_spare = rows ? pf->map[1 - pf->map_cur] : nullptr;
     out->anc = pf->has_anc ? pf->anc[pf->cur] : nullptr;
     out->row_stride = 5 * (int64_t)pf->Lp;
     out->plane_stride = pf->Lp;
@@ -818,6 +1015,26 @@ int slam_pf_device_view(slam_pf* pf, slam_pf_view* out)
     out->logw = pf->has_anc ? pf->logw : nullptr;
     out->loglik = pf->has_anc && pf->last_ekf && pf->e->ll_n == pf->n ? pf->e->ll_buf.as<float>() : nullptr;
     out->count = pf->has_anc ? pf->count : nullptr;
+    return SLAM_OK;
+}
+
+int slam_pf_layout(const slam_pf* pf)
+{
+    if (!pf || !pf->L) return SLAM_MAP_ROWS;
+    return pf->paged ? SLAM_MAP_PAGES : pf->split ? SLAM_MAP_SPLIT : SLAM_MAP_ROWS;
+}
+
+int slam_pf_split_device_view(slam_pf* pf, slam_pf_split_view* out)
+{
+    if (!pf || !out) return SLAM_ERR_INVALID_ARG;
+    if (!pf->split || !pf->L) return SLAM_ERR_NOT_READY;
+    out->mean = pf->mean[pf->sp_cur];
+    out->cov = pf->cov;
+    out->cls = pf->cls[pf->sp_cur];
+    out->live = pf->live[pf->live_cur];
+    out->live_count = pf->cov_cnt + pf->cov_phase;
+    out->plane_stride = pf->Lp;
+    out->rows = pf->cap;
     return SLAM_OK;
 }
 
@@ -966,12 +1183,15 @@ static int slam_pf_get_map_host_impl(slam_pf* pf, float* rows)
     const size_t n = (size_t)pf->n, L = (size_t)pf->L, Lp = (size_t)pf->Lp;
     if (pf->comm)
         if (int rc = finish_exchange(pf)) return rc;   // collective: remote ancestors' rows into the staging tail
-    if (pf->paged) {   // pages -> rows in a scratch buffer (the pending gather applied on the way), then the copy
+    if (pf->paged || pf->split) {   // -> rows in a scratch buffer (the pending gather applied on the way), then the copy
         float* dense = nullptr;
         if (hipMalloc((void**)&dense, 5 * Lp * n * 4) != hipSuccess) return SLAM_ERR_HIP;
         int rc = SLAM_OK;
-        if (launch_rows_from_pages(pf->e->stream, pf->pool, pf->pt[pf->pt_cur], pf->nb, pf->has_anc ? pf->anc[pf->cur] : nullptr,
-                                   pf->n, dense, 5 * (int64_t)Lp, pf->Lp, pf->L) != hipSuccess)
+        const int32_t* idx = pf->has_anc ? pf->anc[pf->cur] : nullptr;
+        if ((pf->split ? launch_rows_from_split(pf->e->stream, pf->mean[pf->sp_cur], pf->cov, pf->cls[pf->sp_cur], pf->Lp, idx, pf->n, dense,
+                                                5 * (int64_t)Lp, pf->Lp, pf->L)
+                       : launch_rows_from_pages(pf->e->stream, pf->pool, pf->pt[pf->pt_cur], pf->nb, idx, pf->n, dense, 5 * (int64_t)Lp,
+                                                pf->Lp, pf->L)) != hipSuccess)
             rc = SLAM_ERR_HIP;
         if (rc == SLAM_OK) rc = slam_engine_sync(pf->e);
         if (rc == SLAM_OK && hipMemcpy2D(rows, L * 4, dense, Lp * 4, L * 4, 5 * n, hipMemcpyDeviceToHost) != hipSuccess)
@@ -1026,7 +1246,10 @@ static int slam_pf_get_map_rows_host_impl(slam_pf* pf, const int32_t* particle, 
     };
     if (ok(hipMemcpyAsync(sel, particle, sizeof(int32_t) * (size_t)count, hipMemcpyHostToDevice, e->stream), "copy of the particle list") &&
         ok(launch_compose_index(e->stream, sel, pf->has_anc ? pf->anc[pf->cur] : nullptr, count, src), "compose_index")) {
-        if (pf->paged)
+        if (pf->split)
+            ok(launch_rows_from_split(e->stream, pf->mean[pf->sp_cur], pf->cov, pf->cls[pf->sp_cur], pf->Lp, src, count, dense,
+                                      5 * (int64_t)Lp, pf->Lp, pf->L), "rows_from_split");
+        else if (pf->paged)
             ok(launch_rows_from_pages(e->stream, pf->pool, pf->pt[pf->pt_cur], pf->nb, src, count, dense, 5 * (int64_t)Lp, pf->Lp, pf->L),
                "rows_from_pages");
         else

@@ -33,6 +33,14 @@ constexpr int kScoreBlock = 256;
 //  - the cell offset as one 24-bit multiply-add (v_mad_u32_u24 is full rate, v_mul_lo_u32 is not);
 //  - the EDT as a buffer resource: an out-of-bounds beam gets offset 0xffffffff and the hardware's range check
 //    returns +0.0f, which leaves the running sum's bits unchanged — no select on the loaded value, no 64-bit address.
+// PACKED (round 4): the gathers go to a one-byte-per-cell copy of the grid laid out in 16-column strips (kernels.h:
+// ScoreGrid::packed), a byte is turned back into the cell's float through a 256-entry table in LDS (the same bits: the
+// capped EDT only holds 0, sqrtf of small integers and the cap, main.c:223-269).  Why: the scorer is bound by the texture
+// addresser, which works through the DISTINCT 128-byte lines of a wave gather one per cycle (~59 of them for the 64 lanes of
+// a settled population on a row-major float grid, profiles/r02_pmc_score.md: the poses of a wavefront spread over ~30 rows,
+// and every row is another line).  In the packed copy a line is a 16 x 8 patch of cells, so the same neighbourhood lies in
+// a fraction of the lines.  An out-of-bounds beam still gets offset 0xffffffff: the range check returns byte 0 = the code of
+// an occupied cell = +0.0f.  The decode costs one LDS read per beam, issued one beam pair ahead of the sum that consumes it.
 constexpr int kQuadDepth = 8;    // gathers in flight per lane, 4 lanes per pose (measured: 43 -> 39 us at 64k poses x 360
                                  // beams, 84 -> 47 us at 16k x 1079)
 constexpr int kLaneDepth = 16;   // gathers in flight per lane, 1 lane per pose
@@ -47,7 +55,7 @@ __device__ __forceinline__ float quad_bcast(float v)
 // (px,py,p2) by the pose's first lane and scored in the same launch (saves a launch and a pose round trip).
 // `block`: which 256-thread slice of the poses this workgroup takes (blockIdx.x of score_poses_kernel; the fused front kernel
 // of a frame, pf_kernels.hip, hands its scoring workgroups their slice); s_pair: nb_pad / 2 float4 of LDS.
-template <bool HAS_CS, int LPP, int DEPTH, bool MOTION>
+template <bool HAS_CS, int LPP, int DEPTH, bool MOTION, bool PACKED = false>
 __device__ __forceinline__ void score_poses_body(const ScoreGrid& g, const float* __restrict__ bx, const float* __restrict__ by,
                                                  int nbeams, float* __restrict__ px, float* __restrict__ py,
                                                  float* __restrict__ p2, const float* __restrict__ p3, int nposes,
@@ -69,6 +77,12 @@ __device__ __forceinline__ void score_poses_body(const ScoreGrid& g, const float
             s_pair[p] = make_float4(b0 < nbeams ? bx[b0] * g.ipix : nanv, b1 < nbeams ? bx[b1] * g.ipix : nanv,
                                     b0 < nbeams ? by[b0] * g.ipix : nanv, b1 < nbeams ? by[b1] * g.ipix : nanv);
         }
+    }
+    // PACKED: the decode table behind the beams (the launcher adds its 1 KB to the dynamic LDS size)
+    float* s_table = reinterpret_cast<float*>(s_pair + nb_pad / 2);
+    if constexpr (PACKED) {
+        static_assert(kScoreBlock == 256, "one table entry per thread");
+        s_table[threadIdx.x] = g.table[threadIdx.x];
     }
     __syncthreads();
 
@@ -107,8 +121,10 @@ __device__ __forceinline__ void score_poses_body(const ScoreGrid& g, const float
     const unsigned lim_x = (unsigned)(g.cols > 2 ? g.cols - 2 : 0);
     const unsigned lim_y = (unsigned)(g.rows > 2 ? g.rows - 2 : 0);
     const unsigned ld4 = (unsigned)g.ld * 4u;   // < 2^24 (the engine refuses wider grids), rows < 2^24: 24-bit multiply
+    const unsigned strip = (unsigned)g.strip_bytes;   // PACKED: bytes of one 16-column strip (< 2^24)
     const __amdgpu_buffer_rsrc_t edt =
-        __builtin_amdgcn_make_buffer_rsrc((void*)g.edt, 0, (int)((unsigned)g.rows * ld4), 0x00020000);
+        PACKED ? __builtin_amdgcn_make_buffer_rsrc((void*)g.packed, 0, (int)(((unsigned)g.cols + 15u) / 16u * strip), 0x00020000)
+               : __builtin_amdgcn_make_buffer_rsrc((void*)g.edt, 0, (int)((unsigned)g.rows * ld4), 0x00020000);
 
     typedef float v2f __attribute__((ext_vector_type(2)));
     const v2f c2 = {ct, ct}, s2 = {st, st}, ns2 = {nst, nst}, ox2 = {off_x, off_x}, oy2 = {off_y, off_y};
@@ -116,7 +132,8 @@ __device__ __forceinline__ void score_poses_body(const ScoreGrid& g, const float
     int n_in = 0;
     typedef int v2i __attribute__((ext_vector_type(2)));
     const v2i sign2 = {(int)0x80000000, (int)0x80000000}, half2 = {0x3effffff, 0x3effffff};   // 0.5 - 1 ulp
-    auto beam2 = [&](int m) {   // beams sub + LPP*2m and sub + LPP*(2m+1)
+    typedef unsigned v2u __attribute__((ext_vector_type(2)));
+    auto beam2 = [&](int m) {   // beams sub + LPP*2m and sub + LPP*(2m+1); PACKED: the two cells' codes (bit patterns)
         const float4 q = s_pair[sub + LPP * m];
         const v2f X = {q.x, q.y}, Y = {q.z, q.w};
         v2f fx = ((X * c2) + (Y * s2)) + ox2;
@@ -134,11 +151,20 @@ __device__ __forceinline__ void score_poses_body(const ScoreGrid& g, const float
             asm("v_cvt_i32_f32 %0, %1" : "=v"(ix) : "v"(fx[e]));
             asm("v_cvt_i32_f32 %0, %1" : "=v"(iy) : "v"(fy[e]));
             const bool in = (unsigned)(ix - 1) < lim_x && (unsigned)(iy - 1) < lim_y;
-            const unsigned off = in ? __umul24((unsigned)iy, ld4) + ((unsigned)ix << 2) : 0xffffffffu;
-            h[e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(edt, (int)off, 0, 0));   // out of range: +0.0f
+            if constexpr (PACKED) {
+                const unsigned off = in ? __umul24((unsigned)ix >> 4, strip) + (((unsigned)iy << 4) | ((unsigned)ix & 15u)) : 0xffffffffu;
+                h[e] = __uint_as_float((unsigned)__builtin_amdgcn_raw_buffer_load_b8(edt, (int)off, 0, 0));   // out of range: code 0
+            } else {
+                const unsigned off = in ? __umul24((unsigned)iy, ld4) + ((unsigned)ix << 2) : 0xffffffffu;
+                h[e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(edt, (int)off, 0, 0));   // out of range: +0.0f
+            }
             n_in += in ? 1 : 0;
         }
         return h;
+    };
+    auto decode = [&](v2f c) {   // PACKED: code -> float through the LDS table
+        const v2u k = __builtin_bit_cast(v2u, c);
+        return (v2f){s_table[k[0]], s_table[k[1]]};
     };
     auto add_hit = [&](float h) {
         if constexpr (LPP == 4) {   // beams 4j, 4j+1, 4j+2, 4j+3 in order, identically in all four lanes of the quad
@@ -154,19 +180,45 @@ __device__ __forceinline__ void score_poses_body(const ScoreGrid& g, const float
     v2f hq[kPairs];
 #pragma unroll
     for (int m = 0; m < kPairs; ++m) hq[m] = beam2(m);
-    for (int r = 1; r < nb_pad / kRound; ++r) {
+    if constexpr (PACKED) {
+        // three stages: gathers DEPTH beams ahead, the LDS decode one pair ahead, the ordered sum.  (The sum starts by adding
+        // the two zeros of `hprev`: +0 + +0 = +0, the bits of the reference's sum.)
+        v2f hprev = {0.0f, 0.0f};
+        for (int r = 1; r < nb_pad / kRound; ++r) {
+#pragma unroll
+            for (int m = 0; m < kPairs; ++m) {
+                const v2f c = hq[m];
+                hq[m] = beam2(r * kPairs + m);
+                const v2f h = decode(c);
+                add_hit(hprev[0]);
+                add_hit(hprev[1]);
+                hprev = h;
+            }
+        }
 #pragma unroll
         for (int m = 0; m < kPairs; ++m) {
-            const v2f h = hq[m];
-            hq[m] = beam2(r * kPairs + m);
-            add_hit(h[0]);
-            add_hit(h[1]);
+            const v2f h = decode(hq[m]);
+            add_hit(hprev[0]);
+            add_hit(hprev[1]);
+            hprev = h;
         }
-    }
+        add_hit(hprev[0]);
+        add_hit(hprev[1]);
+    } else {
+        for (int r = 1; r < nb_pad / kRound; ++r) {
 #pragma unroll
-    for (int m = 0; m < kPairs; ++m) {
-        add_hit(hq[m][0]);
-        add_hit(hq[m][1]);
+            for (int m = 0; m < kPairs; ++m) {
+                const v2f h = hq[m];
+                hq[m] = beam2(r * kPairs + m);
+                add_hit(h[0]);
+                add_hit(h[1]);
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < kPairs; ++m) {
+            add_hit(hq[m][0]);
+            add_hit(hq[m][1]);
+        }
     }
     if (LPP == 4) {
         n_in += __builtin_amdgcn_mov_dpp(n_in, 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]

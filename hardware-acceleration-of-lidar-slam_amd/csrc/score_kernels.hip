@@ -28,7 +28,7 @@ namespace slam {
 
 namespace {
 
-template <bool HAS_CS, int LPP, int DEPTH, bool MOTION>
+template <bool HAS_CS, int LPP, int DEPTH, bool MOTION, bool PACKED>
 __global__ __launch_bounds__(kScoreBlock) void score_poses_kernel(ScoreGrid g, const float* __restrict__ bx,
                                                                    const float* __restrict__ by, int nbeams,
                                                                    float* __restrict__ px, float* __restrict__ py,
@@ -39,8 +39,8 @@ __global__ __launch_bounds__(kScoreBlock) void score_poses_kernel(ScoreGrid g, c
                                                                    MotionParams mpar)
 {
     extern __shared__ float4 s_pair[];
-    score_poses_body<HAS_CS, LPP, DEPTH, MOTION>(g, bx, by, nbeams, px, py, p2, p3, nposes, score, count, mio, mpar, (int)blockIdx.x,
-                                                 s_pair);
+    score_poses_body<HAS_CS, LPP, DEPTH, MOTION, PACKED>(g, bx, by, nbeams, px, py, p2, p3, nposes, score, count, mio, mpar,
+                                                         (int)blockIdx.x, s_pair);
 }
 
 // Small batches (< ~8k poses): ONE WAVEFRONT PER POSE.  The 64 lanes gather 64 beams at a time (8 x 64 in flight),
@@ -309,17 +309,24 @@ hipError_t launch_score_any(hipStream_t stream, const ScoreGrid& g, const float*
     const bool quad = nposes < quad_max;
     const long threads = quad ? 4L * nposes : nposes;
     const int blocks = (int)((threads + kScoreBlock - 1) / kScoreBlock);
-    const size_t lds = sizeof(float2) * (size_t)(nbeams + (quad ? 4 * kQuadDepth : kLaneDepth));
+    const bool packed = g.packed != nullptr;   // the byte-per-cell copy of the grid (launch_edt_pack) + 1 KB of LDS for its table
+    const size_t lds = sizeof(float2) * (size_t)(nbeams + (quad ? 4 * kQuadDepth : kLaneDepth)) + (packed ? 1024 : 0);
     if (ev) (void)hipEventRecord(ev->start, stream);
-#define SLAM_LAUNCH_SCORE(CS, LPP, DEPTH)                                                                              \
-    score_poses_kernel<CS, LPP, DEPTH, MOTION><<<blocks, kScoreBlock, lds, stream>>>(g, bx, by, nbeams, x, y, th_or_ct, \
-                                                                                      st_or_null, nposes, score, count, \
-                                                                                      mio, mpar)
+#define SLAM_LAUNCH_SCORE(CS, LPP, DEPTH, PK)                                                                              \
+    score_poses_kernel<CS, LPP, DEPTH, MOTION, PK><<<blocks, kScoreBlock, lds, stream>>>(g, bx, by, nbeams, x, y, th_or_ct, \
+                                                                                          st_or_null, nposes, score, count, \
+                                                                                          mio, mpar)
+#define SLAM_LAUNCH_SCORE2(CS, LPP, DEPTH)                 \
+    do {                                                   \
+        if (packed) SLAM_LAUNCH_SCORE(CS, LPP, DEPTH, true); \
+        else SLAM_LAUNCH_SCORE(CS, LPP, DEPTH, false);       \
+    } while (0)
     if (st_or_null && !MOTION) {
-        if (quad) SLAM_LAUNCH_SCORE(true, 4, kQuadDepth); else SLAM_LAUNCH_SCORE(true, 1, kLaneDepth);
+        if (quad) SLAM_LAUNCH_SCORE2(true, 4, kQuadDepth); else SLAM_LAUNCH_SCORE2(true, 1, kLaneDepth);
     } else {
-        if (quad) SLAM_LAUNCH_SCORE(false, 4, kQuadDepth); else SLAM_LAUNCH_SCORE(false, 1, kLaneDepth);
+        if (quad) SLAM_LAUNCH_SCORE2(false, 4, kQuadDepth); else SLAM_LAUNCH_SCORE2(false, 1, kLaneDepth);
     }
+#undef SLAM_LAUNCH_SCORE2
 #undef SLAM_LAUNCH_SCORE
     if (ev) (void)hipEventRecord(ev->stop, stream);
     return hipGetLastError();
@@ -342,6 +349,64 @@ hipError_t launch_motion_score(hipStream_t stream, const ScoreGrid& g, const flo
 {
     return launch_score_any<true>(stream, g, bx, by, nbeams, io.x, io.y, io.th, nullptr, nposes, score, count, io,
                                   make_motion_params(first_id, dp, sigma, seed, frame), ev);
+}
+
+// ---- the packed copy of a grid (kernels.h: ScoreGrid::packed).  Two passes: the grid's largest value (the cap, wherever a cell
+// is farther than that from every occupied one), then code, table and the check that the table gives every cell back.
+namespace {
+__global__ __launch_bounds__(256) void edt_max_kernel(const float* __restrict__ edt, int ld, int rows, int cols, uint32_t* __restrict__ flag)
+{
+    uint32_t m = 0;   // the values are >= 0: their bit patterns order like the floats
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (int64_t)rows * cols; i += (int64_t)gridDim.x * 256) {
+        const float v = edt[(i / cols) * ld + i % cols];
+        const uint32_t u = __float_as_uint(v);
+        m = u > m ? u : m;   // a negative or NaN value ends up as a huge pattern: it fails the check of the second pass
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t t = (uint32_t)__shfl_xor((int)m, o);
+        m = t > m ? t : m;
+    }
+    if ((threadIdx.x & 63) == 0) atomicMax(&flag[0], m);
+}
+
+__global__ __launch_bounds__(256) void edt_pack_kernel(const float* __restrict__ edt, int ld, int rows, int cols, int strip_bytes,
+                                                       uint8_t* __restrict__ packed, float* __restrict__ table, uint32_t* __restrict__ flag)
+{
+    const float top = __uint_as_float(flag[0]);
+    if (blockIdx.x == 0) table[threadIdx.x] = threadIdx.x == 255 ? top : sqrtf((float)threadIdx.x);
+    const int rows8 = strip_bytes / 16;
+    const int64_t cells = (int64_t)((cols + 15) / 16) * strip_bytes;   // every byte of the copy, padding included
+    bool bad = false;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < cells; i += (int64_t)gridDim.x * 256) {
+        const int ix = (int)(i / strip_bytes) * 16 + (int)(i & 15), iy = (int)((i % strip_bytes) >> 4);
+        unsigned code = 0;
+        if (ix < cols && iy < rows && iy < rows8) {
+            const float v = edt[(int64_t)iy * ld + ix];
+            const float d2 = rintf(v * v);
+            code = __float_as_uint(v) == __float_as_uint(top) ? 255u : (d2 >= 0.0f && d2 < 255.0f ? (unsigned)d2 : 254u);
+            const float back = code == 255u ? top : sqrtf((float)code);
+            bad = bad || __float_as_uint(back) != __float_as_uint(v);
+        }
+        packed[i] = (uint8_t)code;
+    }
+    if (__ballot(bad) != 0 && (threadIdx.x & 63) == 0) flag[1] = 1;
+}
+}  // namespace
+
+size_t edt_packed_bytes(int rows, int cols) { return (size_t)((cols + 15) / 16) * 16 * (size_t)((rows + 7) / 8 * 8); }
+
+hipError_t launch_edt_pack(hipStream_t stream, const float* edt, int ld, int rows, int cols, uint8_t* packed, float* table,
+                           uint32_t* flag)
+{
+    hipError_t err = hipMemsetAsync(flag, 0, 8, stream);
+    if (err != hipSuccess) return err;
+    if (rows <= 0 || cols <= 0) return hipSuccess;
+    const int64_t cells = (int64_t)rows * cols;
+    const int blocks = (int)((cells + 255) / 256 < 2048 ? (cells + 255) / 256 : 2048);
+    edt_max_kernel<<<blocks, 256, 0, stream>>>(edt, ld, rows, cols, flag);
+    edt_pack_kernel<<<blocks, 256, 0, stream>>>(edt, ld, rows, cols, 16 * ((rows + 7) / 8 * 8), packed, table, flag);
+    return hipGetLastError();
 }
 
 hipError_t launch_pose_hits(hipStream_t stream, const ScoreGrid& g, const float* bx, const float* by, int nbeams,

@@ -31,6 +31,13 @@ namespace {
 
 inline int blocks256(int64_t n) { return (int)((n + 255) / 256); }
 
+// {classes in use, epoch} to mapped host memory as ONE 8-byte store (8-byte aligned), so that the host never pairs the count of
+// one epoch with the number of another
+__device__ __forceinline__ void publish_live(int32_t* h_live, int count, uint32_t epoch)
+{
+    *reinterpret_cast<volatile unsigned long long*>(h_live) = (unsigned long long)(uint32_t)count | ((unsigned long long)epoch << 32);
+}
+
 // ---- the classes' update: workgroup (k, y) takes landmarks [256 y, 256 y + 256) of class live[k]
 __global__ __launch_bounds__(256) void cov_update_kernel(CovArgs a)
 {
@@ -38,10 +45,7 @@ __global__ __launch_bounds__(256) void cov_update_kernel(CovArgs a)
     const int nlive = a.cnt[a.phase];
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
         a.cnt[(a.phase + 2) % 3] = 0;   // the list after next: nobody reads or writes it during this launch
-        if (a.h_live) {
-            a.h_live[0] = nlive;
-            a.h_live[1] = (int32_t)a.epoch;
-        }
+        if (a.h_live) publish_live(a.h_live, nlive, a.epoch);
     }
     if (k >= nlive) return;
     const int c = a.live_in[k];
@@ -128,10 +132,7 @@ __global__ __launch_bounds__(256) void split_from_rows_kernel(const float* __res
             cnt[phase] = c + 1;
             cnt[(phase + 1) % 3] = 0;
             cnt[(phase + 2) % 3] = 0;
-            if (h_live) {
-                h_live[0] = c + 1;
-                h_live[1] = (int32_t)epoch;
-            }
+            if (h_live) publish_live(h_live, c + 1, epoch);
         }
     }
 }
@@ -192,10 +193,7 @@ __global__ __launch_bounds__(256) void split_reset_kernel(float* __restrict__ me
         cnt[phase] = 1;
         cnt[(phase + 1) % 3] = 0;
         cnt[(phase + 2) % 3] = 0;
-        if (h_live) {
-            h_live[0] = 1;
-            h_live[1] = (int32_t)epoch;
-        }
+        if (h_live) publish_live(h_live, 1, epoch);
     }
 }
 

@@ -418,8 +418,19 @@ typedef struct {
  * observes most landmarks) or COPY-ON-WRITE PAGES behind a page table per particle (a resampling frame copies table
  * entries and rewrites only the pages that hold an observed landmark: the fastest form when a frame observes few of
  * many).  Both give the same bits.  SLAM_MAP_AUTO lets the session choose and change its mind while it runs. */
-typedef enum { SLAM_MAP_AUTO = 0, SLAM_MAP_ROWS = 1, SLAM_MAP_PAGES = 2 } slam_map_layout;
-/* SLAM_MAP_AUTO starts on rows and watches how many landmarks the frames observe (a count the update kernels leave in
+typedef enum { SLAM_MAP_AUTO = 0, SLAM_MAP_ROWS = 1, SLAM_MAP_PAGES = 2, SLAM_MAP_SPLIT = 3 } slam_map_layout;
+/* SLAM_MAP_SPLIT (round 4): MEANS per particle, COVARIANCES per covariance class.  The landmark update is carried out in the
+ * world frame (see slam_ekf_update_dev): the posterior covariance of a landmark depends on its prior covariance, on meas_var
+ * and on whether the frame observes it — never on the particle's pose or on the measurement.  Particles whose covariances are
+ * equal therefore stay equal for ever (the offspring of an ancestor; a population whose maps were initialised alike), and
+ * they share ONE row of covariance planes, updated once per frame, while every particle keeps its own two planes of means:
+ * a resampling frame that observes every landmark reads 8 and writes 8 bytes per (particle, landmark) instead of 20 and 20.
+ * Classes are found when maps come in (slam_pf_set_map_*: neighbouring particles with bit-identical covariance planes share a
+ * class) and die with their last particle.  The same bits as rows and pages; one GPU only (SLAM_ERR_INVALID_ARG for a sharded
+ * session).  slam_pf_device_view gives map = NULL while a session is split, like pages. */
+/* SLAM_MAP_AUTO keeps a single-GPU session that resamples every frame on the SPLIT layout instead of rows (sharded and gated
+ * sessions: rows), and otherwise works as described here, "rows" meaning that dense layout.
+ * SLAM_MAP_AUTO starts on rows and watches how many landmarks the frames observe (a count the update kernels leave in
  * mapped host memory: every frame at the start and while they speak against the current layout, every 8th frame otherwise;
  * read without waiting, except in a session's first four frames, which wait for the count of the frame before so that the
  * layout is settled by then): three counts in a row of at most
@@ -494,6 +505,8 @@ int slam_pf_set_map_dev(slam_pf *pf, const float *d_rows, int64_t row_stride, in
  * (as if created with SLAM_MAP_PAGES); 0 restores AUTO's own choice.  slam_pf_is_paged: the layout right now. */
 int slam_pf_paged_set(slam_engine *e, int on);
 int slam_pf_is_paged(const slam_pf *pf);
+/* the layout right now: SLAM_MAP_ROWS, SLAM_MAP_PAGES or SLAM_MAP_SPLIT */
+int slam_pf_layout(const slam_pf *pf);
 /* one frame against grid `slot`; asynchronous */
 int slam_pf_step(slam_pf *pf, int slot, const float dp[3], int use_observations);
 /* heaviest particle of the last frame (lowest index on ties): its pose, log-weight and index; synchronises.
@@ -557,6 +570,17 @@ typedef struct {
     int64_t npages;
 } slam_pf_paged_view;
 int slam_pf_paged_device_view(slam_pf *pf, slam_pf_paged_view *out);
+
+/* Inspection of a session that is on the split layout right now (tests, debugging; SLAM_ERR_NOT_READY otherwise).  Device
+ * pointers, valid until the next slam_pf_* call: mean[rows][2][plane_stride] and cls[rows] of the CURRENT particles before the
+ * pending gather; cov[..][3][plane_stride]: row c = the covariance planes of class c; live[0 .. *live_count): the classes in use
+ * as of the last landmark update (a superset of those the current particles name). */
+typedef struct {
+    const float *mean, *cov;
+    const int32_t *cls, *live, *live_count;
+    int32_t plane_stride, rows;
+} slam_pf_split_view;
+int slam_pf_split_device_view(slam_pf *pf, slam_pf_split_view *out);
 
 /* ------------------------------------------------------------------ mapper: the reference's frame loop in one call
  * (SURVEY.md §8f rows N1 + N2).  One slam_mapper_next_frame = one iteration of the reference's loop

@@ -90,3 +90,25 @@ def test_auto_layout_in_a_sharded_session(world):
     assert np.array_equal(bits(np.concatenate([p["pose"] for p in many], axis=1)), bits(ref["pose"]))
     assert np.array_equal(bits(np.concatenate([p["map"] for p in many], axis=0)), bits(ref["map"]))
     assert any(p["paged_end"] for p in many)
+
+
+def test_sharded_auto_with_a_map_read_between_every_two_frames():
+    """A map getter between two frames completes the exchange early: the rows of remote ancestors then already sit in the
+    staging tail when SLAM_MAP_AUTO moves the maps at the start of the next frame, and the pending gather index names them.
+    Both moves (rows -> pages on sparse frames, pages -> rows on dense ones) must take the tail along: the population equals
+    one rank on rows, frame by frame."""
+    from test_gpu_configs import _run_c_session_ranks
+
+    n_total, L, frames, world = 3072, 100, 30, 3
+    kw = dict(sparse_obs=True, dense_from=12, maps_every_frame=True)
+    ref = _run_c_session_ranks(1, n_total, L, frames, transport=None, **kw)[0]
+    many = _run_c_session_ranks(world, n_total, L, frames, layout="auto", **kw)
+    assert set(ref["layouts"]) == {"rows"}
+    moved = [p["layouts"] for p in many]
+    assert any("pages" in m[:12] for m in moved) and any("pages" in m and m[-1] == "rows" for m in moved), moved
+    assert any(sum(p["rows"]) > 0 for p in many), "nothing migrated: the staging tail was never used"
+    assert np.array_equal(bits(np.concatenate([p["pose"] for p in many], axis=1)), bits(ref["pose"]))
+    assert np.array_equal(bits(np.concatenate([p["map"] for p in many], axis=0)), bits(ref["map"]))
+    for f in range(frames):   # every 97th particle of the population, every frame
+        got = np.concatenate([p["frame_maps"][f] for p in many], axis=0)
+        assert np.array_equal(bits(got), bits(ref["frame_maps"][f])), f

@@ -168,7 +168,7 @@ def test_ekf_long_rows_small_n(eng, orc, L, Lp):
 
 # ------------------------------------------------------------------ the sharded C session (slam_pf_create_sharded)
 def _run_c_session_ranks(world, n_total, L, frames, transport="local", recv_capacity=0, ess=0.0, inplace_form=-1, paged=False,
-                         fail_rank=None, fail_frame=None, layout=None, sparse_obs=False):
+                         fail_rank=None, fail_frame=None, layout=None, sparse_obs=False, dense_from=None, maps_every_frame=False):
     """`world` ranks of the C-level sharded session in THIS process, one host thread per rank, all on cuda:0
     (in-process transport), or a one-rank RCCL communicator.  Returns the concatenated population."""
     import threading
@@ -204,24 +204,31 @@ def _run_c_session_ranks(world, n_total, L, frames, transport="local", recv_capa
             ses.set_poses(x[sl], y[sl], th[sl])
             if L:
                 ses.set_map(mp[sl])
-            rows, bests = [], []
+            rows, bests, layouts, frame_maps = [], [], [], []
             for f in range(frames):
                 use = L > 0 and f != 2                      # one frame without observations: the maps just follow
                 if r == fail_rank and f == fail_frame:
                     comm.abort()                            # this rank gives up: the others must fail, not wait
                     raise RuntimeError("rank gave up")
-                if use and sparse_obs:                      # 12 neighbouring landmarks: under a quarter of the map
+                if use and sparse_obs and (dense_from is None or f < dense_from):   # 12 neighbouring landmarks: under a quarter of the map
                     ids = ((np.arange(12) + 17 * f) % L).astype(np.int32)
                     z = lm[ids] + 0.01 * np.float32(f)
                     eng.obs_upload(ids, z[:, 0].copy(), z[:, 1].copy(), L)
+                elif use and dense_from is not None:         # every landmark, every frame: AUTO's way back to rows
+                    z = lm + 0.01 * np.float32(f)
+                    eng.obs_upload(np.arange(L, dtype=np.int32), z[:, 0].copy(), z[:, 1].copy(), L)
                 elif use:
                     eng.obs_upload(*W.observations(lm, f), L)
                 ses.step(0, [0.01, -0.005, 0.002], use)
                 rows.append(ses.rows_received())
+                layouts.append(ses.layout())
+                if maps_every_frame:                        # collective; completes the exchange of this frame early
+                    gsel = np.arange(0, n_total, 97)        # every 97th particle of the POPULATION: this rank's share of them
+                    frame_maps.append(ses.map_rows((gsel[(gsel >= r * n) & (gsel < (r + 1) * n)] - r * n).astype(np.int32)))
                 if f % 3 == 1:
                     bests.append(ses.best())                 # collective; must not disturb the pending exchange
             res = {"pose": ses.poses(), "best": ses.best(), "rows": rows, "bests": bests, "resampled": ses.frames_resampled(),
-                   "mean": ses.mean(0.07), "paged_end": ses.is_paged()}
+                   "mean": ses.mean(0.07), "paged_end": ses.is_paged(), "layouts": layouts, "frame_maps": frame_maps}
             if L:
                 res["map"] = ses.maps()
             out[r] = res

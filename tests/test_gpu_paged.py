@@ -149,7 +149,7 @@ def test_paged_session_set_map_dev_and_views():
     assert v["map"] is None and v["map_spare"] is None and v["pose"] is not None
     ses.close()
     eng.pf_paged_set(False)
-    ses = pkg.PfSession(eng, n, L)                 # rows: the same entry point copies into the row buffer
+    ses = pkg.PfSession(eng, n, L, map_layout="rows")   # rows: the same entry point copies into the row buffer
     ses.set_map_dev(d, 5 * Lp, Lp)
     assert np.array_equal(bits(ses.maps()), bits(rows[:, :, :L]))
     wide = torch.full((n, 5 * Lp + 37), 7.0, device=DEV)          # a row stride wider than 5 planes

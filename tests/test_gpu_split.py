@@ -1,0 +1,236 @@
+"""The SPLIT layout of the landmark maps (csrc/split_kernels.hip, ekf_split_body in csrc/pf_kernels.hip): means per particle,
+covariances per covariance class.  The layout is not part of the specification: a split session must give the bits of a row
+session — poses, maps, heaviest particle, frame after frame — whatever the classes look like (one for the whole population;
+one per particle; anything between), for every row length (whole passes, tails, rows shorter than a batch), fused with the
+scorer or as a launch of its own, on frames that observe everything, something or nothing.  PARITY UNPINNED all the same: the
+reference has no landmarks; the split kernel is compared with the CPU specification directly in
+tests/test_gpu_frame_front_at_size.py.
+
+The bookkeeping is checked from the outside through slam_pf_split_device_view: neighbouring particles with bit-identical
+covariance planes share a class, the list of classes in use only shrinks and always covers the classes the particles name,
+and the class rows equal what the particles of a row session carry.
+"""
+import numpy as np
+import pytest
+import torch
+
+from __graft_entry__ import load_package
+from conftest import bits
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda", 0)
+
+
+def _tensor(a):
+    return torch.as_tensor(a, device=DEV)
+
+
+def _maps(n, L, lm, cov, seed=17):
+    """cov: "shared" (every particle the same covariances), "own" (every particle its own, some landmarks unseen),
+    "families" (runs of 1 .. 40 neighbouring particles share theirs)."""
+    import _shard_worker as W
+
+    x, y, th, mp = W.init_state(n, L, lm)
+    rng = np.random.default_rng(seed)
+    if cov == "shared":
+        mp[:, 2], mp[:, 3], mp[:, 4] = 0.05, 0.01, 0.04
+        mp[:, 2, L // 3] = -1.0
+    else:
+        a = (0.02 + 0.2 * rng.random((n, L))).astype(np.float32)
+        c = (0.02 + 0.2 * rng.random((n, L))).astype(np.float32)
+        b = ((rng.random((n, L)) - 0.5) * np.sqrt(a * c)).astype(np.float32)
+        a[rng.random((n, L)) < 0.05] = -1.0
+        if cov == "families":
+            head = np.zeros(n, np.int64)
+            i = 0
+            while i < n:
+                k = int(rng.integers(1, 41))
+                head[i:i + k] = i
+                i += k
+            a, b, c = a[head], b[head], c[head]
+        mp[:, 2], mp[:, 3], mp[:, 4] = a, b, c
+    return x, y, th, mp
+
+
+def _run(layout, n, L, frames, cov="own", fused=True, form=-1, nbeams=None, skip_obs=(), inspect=False):
+    import _shard_worker as W
+
+    pkg = load_package()
+    meta, edt, bx, by, lm = W.make_world(L=L)
+    x, y, th, mp = _maps(n, L, lm, cov)
+    eng = pkg.Engine(0)
+    eng.frame_fusion_set(fused)
+    eng.ekf_form_set(form)
+    eng.grid_set_dev(0, torch.from_numpy(edt).to(DEV), pkg.grid_meta(meta.rows, meta.cols, meta.ld, meta.pixel, meta.min_x, meta.min_y))
+    eng.scan_upload(bx[:nbeams], by[:nbeams]) if nbeams else eng.scan_upload(bx, by)
+    ses = pkg.PfSession(eng, n, L, seed=91, sigma=(0.02, 0.02, 0.004), meas_var=0.02, score_gain=0.05, map_layout=layout)
+    ses.set_poses(x, y, th)
+    ses.set_map(mp)
+    out = {"best": [], "maps": {}, "layout": [], "live": [], "classes": []}
+    if inspect:
+        v = ses.split_view()
+        cls = _tensor(v["cls"])[:n].cpu().numpy()
+        same = np.all(bits(mp[1:, 2:5]) == bits(mp[:-1, 2:5]), axis=(1, 2))
+        want = np.concatenate([[0], np.cumsum(~same)])
+        assert np.array_equal(cls, want), "classes = runs of neighbouring particles with identical covariance planes"
+        assert int(_tensor(v["live_count"])[0]) == want[-1] + 1
+        got_cov = _tensor(v["cov"])[torch.from_numpy(cls).to(DEV).long()][:, :, :L].cpu().numpy()
+        assert np.array_equal(bits(got_cov), bits(mp[:, 2:5]))
+        assert np.array_equal(bits(_tensor(v["mean"])[:n, :, :L].cpu().numpy()), bits(mp[:, 0:2]))
+    rng = np.random.default_rng(5)
+    for f in range(frames):
+        ids = np.sort(rng.choice(L, size=(L if f % 3 else max(L // 3, 1)), replace=False)).astype(np.int32)   # all, or a third
+        z = lm[ids] + np.float32(0.01) * np.float32(f % 5)
+        eng.obs_upload(ids, z[:, 0].copy(), z[:, 1].copy(), L)
+        ses.step(0, [0.01, -0.005, 0.002], f not in skip_obs)
+        out["best"].append(ses.best())
+        out["layout"].append(ses.layout())
+        if inspect:
+            eng.sync()
+            v = ses.split_view()
+            nlive = int(_tensor(v["live_count"])[0])
+            live = set(_tensor(v["live"])[:nlive].cpu().numpy().tolist())
+            named = set(np.unique(_tensor(v["cls"])[:n].cpu().numpy()).tolist())
+            assert len(live) == nlive and named <= live, f"frame {f}: the list of classes in use misses {sorted(named - live)[:5]}"
+            out["live"].append(nlive)
+            out["classes"].append(len(named))
+        if f in (1, frames - 1):
+            sel = np.unique(np.concatenate([np.arange(0, n, max(n // 257, 1)), [n - 1]])).astype(np.int32)
+            out["maps"][f] = ses.map_rows(sel)
+    out["pose"] = ses.poses()
+    out["all_maps"] = ses.maps() if n * L <= 4_000_000 else None
+    out["fused_launches"] = eng.frame_fusion_count()
+    ses.close()
+    eng.close()
+    return out
+
+
+def _same(a, b):
+    assert np.array_equal(bits(a["pose"]), bits(b["pose"]))
+    for f, m in b["maps"].items():
+        assert np.array_equal(bits(a["maps"][f]), bits(m)), f
+    if b["all_maps"] is not None:
+        assert np.array_equal(bits(a["all_maps"]), bits(b["all_maps"]))
+    for p, q in zip(a["best"], b["best"]):
+        assert p[2] == q[2] and p[1] == q[1] and np.array_equal(bits(p[0]), bits(q[0]))
+
+
+@pytest.mark.parametrize("n,L,cov,form,nbeams", [
+    (16384, 300, "own", -1, None), (16384, 300, "shared", -1, None), (16384, 300, "families", 1, None),
+    (5000, 513, "families", -1, None), (6001, 700, "own", 2, None), (140000, 200, "families", -1, None),
+    (3073, 130, "own", -1, 37), (4099, 129, "shared", 1, 1), (4096, 100, "families", -1, None), (2048, 300, "own", -1, None),
+    (3000, 31, "families", -1, None), (1500, 5000, "families", -1, None)])
+def test_split_gives_the_bits_of_rows(n, L, cov, form, nbeams):
+    frames = 7
+    rows = _run("rows", n, L, frames, cov, True, form, nbeams)
+    for fused in (True, False):
+        split = _run("split", n, L, frames, cov, fused, form, nbeams)
+        assert set(split["layout"]) == {"split"}
+        assert fused or split["fused_launches"] == 0
+        _same(split, rows)
+
+
+def test_split_fused_front_runs_where_the_row_session_fuses():
+    rows = _run("rows", 16384, 300, 5, "shared")
+    split = _run("split", 16384, 300, 5, "shared")
+    assert rows["fused_launches"] == 4 and split["fused_launches"] == 4
+
+
+def test_frames_without_observations_and_auto():
+    """Frames without a landmark update move means and classes with their particles (split_gather_kernel); AUTO keeps a
+    single-GPU session that resamples every frame on the split layout while its frames are dense."""
+    rows = _run("rows", 8192, 260, 9, "families", skip_obs=(0, 3, 4, 8))
+    split = _run("split", 8192, 260, 9, "families", skip_obs=(0, 3, 4, 8), inspect=True)
+    auto = _run("auto", 8192, 260, 9, "families", skip_obs=(0, 3, 4, 8))
+    assert set(auto["layout"]) == {"split"}
+    _same(split, rows)
+    _same(auto, rows)
+
+
+@pytest.mark.parametrize("cov", ["shared", "families", "own"])
+def test_classes_in_use_only_shrink(cov):
+    out = _run("split", 12000, 200, 10, cov, inspect=True)
+    live, classes = out["live"], out["classes"]
+    assert all(a >= b for a, b in zip(live, live[1:])), live
+    assert all(nl >= nc for nl, nc in zip(live, classes))
+    if cov == "shared":
+        assert live == [1] * 10
+    else:
+        assert live[0] > 100 and live[-1] < live[0]
+
+
+def test_split_map_io_and_views():
+    """Maps in and out through every entry point while the session is split: set_map (host), set_map_dev (any strides), maps(),
+    map_rows(); slam_pf_device_view shows no rows; a reset leaves one class of landmarks not seen yet."""
+    import _shard_worker as W
+
+    pkg = load_package()
+    n, L = 3000, 70
+    Lp = (L + 31) // 32 * 32
+    meta, edt, bx, by, lm = W.make_world(L=L)
+    x, y, th, mp = _maps(n, L, lm, "families")
+    eng = pkg.Engine(0)
+    eng.grid_set_dev(0, torch.from_numpy(edt).to(DEV), pkg.grid_meta(meta.rows, meta.cols, meta.ld, meta.pixel, meta.min_x, meta.min_y))
+    eng.scan_upload(bx, by)
+    ses = pkg.PfSession(eng, n, L, seed=3, sigma=(0.02, 0.02, 0.004), meas_var=0.02, score_gain=0.05, map_layout="split")
+    assert ses.layout() == "split" and not ses.is_paged()
+    v = ses.device_view()
+    assert v["map"] is None and v["map_spare"] is None and v["pose"] is not None
+    sv = ses.split_view()
+    assert int(_tensor(sv["live_count"])[0]) == 1 and bool((_tensor(sv["cov"])[0, 0, :L] == -1).all())   # after create: nothing seen
+    ses.set_poses(x, y, th)
+    ses.set_map(mp)
+    assert np.array_equal(bits(ses.maps()), bits(mp))
+    sel = np.array([5, 5, 0, n - 1, 1234, 77], np.int32)
+    assert np.array_equal(bits(ses.map_rows(sel)), bits(mp[sel]))
+    wide = torch.full((n, 5 * Lp + 37), 7.0, device=DEV)
+    d = torch.zeros((n, 5, Lp), device=DEV)
+    d[:, :, :L] = torch.from_numpy(mp).to(DEV)
+    wide[:, :5 * Lp] = d.reshape(n, 5 * Lp)
+    torch.cuda.synchronize()
+    ses.set_map_dev(wide, 5 * Lp + 37, Lp)
+    assert np.array_equal(bits(ses.maps()), bits(mp))
+    for f in range(3):
+        eng.obs_upload(*W.observations(lm, f), L)
+        ses.step(0, [0.01, -0.005, 0.002], True)
+    assert np.array_equal(bits(ses.map_rows(sel)), bits(ses.maps()[sel]))      # pending gather applied in both
+    with pytest.raises(pkg.SlamError):
+        ses.set_map(mp)                                                         # a gather is pending
+    ses.reset([0.0, 0.0, 0.0])
+    m = ses.maps()
+    assert bool((m[:, 2] == -1).all()) and bool((m[:, [0, 1, 3, 4]] == 0).all())
+    ses.close()
+    with pytest.raises(pkg.SlamError):                                          # classes are local to a GPU
+        grp = pkg.LocalGroup(1)
+        comm = pkg.Comm.local(eng, grp, 0)
+        try:
+            pkg.PfSession(eng, 512, 40, comm=comm, map_layout="split")
+        finally:
+            comm.close()
+            grp.close()
+    eng.close()
+
+
+def test_auto_moves_between_split_and_pages_and_keeps_the_bits():
+    """The AUTO run of tests/test_gpu_auto_layout.py, looked at from this side: dense frames on split, sparse ones on pages."""
+    from test_gpu_auto_layout import _run as auto_run
+
+    pkg = load_package()
+    seen = []
+    step = pkg.PfSession.step
+
+    def spy(self, *a, **k):
+        step(self, *a, **k)
+        seen.append(self.layout())
+
+    pkg.PfSession.step = spy
+    try:
+        auto = auto_run("auto", 4096, 400, 44)
+    finally:
+        pkg.PfSession.step = step
+    assert seen[0] == "split" and "pages" in seen[:14] and "split" in seen[14:40], seen
+    assert "rows" not in seen
+    rows = auto_run("rows", 4096, 400, 44)
+    assert np.array_equal(bits(auto["pose"]), bits(rows["pose"]))
+    for f, m in rows["maps"].items():
+        assert np.array_equal(bits(auto["maps"][f]), bits(m)), f
