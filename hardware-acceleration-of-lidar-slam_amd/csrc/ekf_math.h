@@ -121,12 +121,23 @@ template <class T> struct EkfShared {
     T hl;                   // 0.5 * log det (P + q I)
 };
 
-template <class T> __device__ __forceinline__ EkfShared<T> ekf_shared(T pxx, T pxy, T pyy, T q)
+// ... in two steps.  The two expensive values — the reciprocal of det (P + q I) and half its logarithm — and then the rest.
+// The split layout (split_kernels.hip) keeps the two values beside every covariance class's planes: they are worked out
+// when the class's covariances are, once, and the particles' update starts from them (ekf_shared_from).
+template <class T> __device__ __forceinline__ void ekf_det_terms(T pxx, T pxy, T pyy, T q, T& idet, T& hl)
+{
+    const T a = pxx + q, c = pyy + q;
+    const T det = a * c - pxy * pxy;
+    idet = ekf_rcp(det);
+    hl = ekf_splat<T>(0.5f) * ekf_log(det);
+}
+
+// WITH_POSTERIOR = false: o2 .. o4 are not wanted (the particles' update of the split layout)
+template <class T, bool WITH_POSTERIOR = true>
+__device__ __forceinline__ EkfShared<T> ekf_shared_from(T pxx, T pxy, T pyy, T q, T idet, T hl)
 {
     EkfShared<T> h;
     const T a = pxx + q, c = pyy + q;
-    const T det = a * c - pxy * pxy;
-    const T idet = ekf_rcp(det);
     h.i00 = c * idet;
     h.i01 = -pxy * idet;
     h.i11 = a * idet;
@@ -134,11 +145,20 @@ template <class T> __device__ __forceinline__ EkfShared<T> ekf_shared(T pxx, T p
     h.w01 = pxx * h.i01 + pxy * h.i11;
     h.w10 = pxy * h.i00 + pyy * h.i01;
     h.w11 = pxy * h.i01 + pyy * h.i11;
-    h.o2 = pxx - (h.w00 * pxx + h.w01 * pxy);
-    h.o3 = pxy - (h.w00 * pxy + h.w01 * pyy);
-    h.o4 = pyy - (h.w10 * pxy + h.w11 * pyy);
-    h.hl = ekf_splat<T>(0.5f) * ekf_log(det);
+    if constexpr (WITH_POSTERIOR) {
+        h.o2 = pxx - (h.w00 * pxx + h.w01 * pxy);
+        h.o3 = pxy - (h.w00 * pxy + h.w01 * pyy);
+        h.o4 = pyy - (h.w10 * pxy + h.w11 * pyy);
+    }
+    h.hl = hl;
     return h;
+}
+
+template <class T> __device__ __forceinline__ EkfShared<T> ekf_shared(T pxx, T pxy, T pyy, T q)
+{
+    T idet, hl;
+    ekf_det_terms<T>(pxx, pxy, pyy, q, idet, hl);
+    return ekf_shared_from<T>(pxx, pxy, pyy, q, idet, hl);
 }
 
 // the part that depends on the particle: its pose (px, py, heading sine s / cosine c), the prior mean and the measurement

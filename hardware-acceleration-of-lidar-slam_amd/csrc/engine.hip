@@ -857,7 +857,7 @@ int slam_frame_front_dev(slam_engine* e, int slot, const float* d_src_x, const f
         return SLAM_OK;
     if (int rc = check_score_inputs(e, slot)) return rc;
     if (e->obs_nlandmarks < 0 || e->obs_nlandmarks != nlandmarks) return SLAM_ERR_NOT_READY;
-    const int group = e->ekf_group_size(n, true, plane_stride, true);
+    const int group = e->ekf_group_size(n, true, plane_stride, true, split != nullptr);
     if (!frame_front_fits(n, nlandmarks, group)) return SLAM_OK;
     HIP_TRY(e->ll_buf.ensure(sizeof(float) * (size_t)n));
     EkfArgs a;
@@ -880,6 +880,8 @@ int slam_frame_front_dev(slam_engine* e, int slot, const float* d_src_x, const f
     if (split) {
         a.cov = split->cov;
         a.cov_stride = split->cov_stride;
+        a.covx = split->covx;
+        a.covx_stride = split->covx_stride;
         a.cls_in = split->cls_in;
         a.cls_out = split->cls_out;
         a.cstamp = split->cstamp;
@@ -908,7 +910,7 @@ int slam_ekf_split_dev(slam_engine* e, const float* d_mean_in, float* d_mean_out
 {
     ENTER(e);
     if (n <= 0 || nlandmarks <= 0 || plane_stride < nlandmarks || row_stride < 2 * (int64_t)plane_stride || !(meas_var > 0.0f) ||
-        !d_mean_in || !d_mean_out || d_mean_in == d_mean_out || !d_x || !d_y || !d_th || !split || !split->cov || !split->cls_in ||
+        !d_mean_in || !d_mean_out || d_mean_in == d_mean_out || !d_x || !d_y || !d_th || !split || !split->cov || !split->covx || !split->cls_in ||
         !split->cls_out || !split->cstamp)
         return SLAM_ERR_INVALID_ARG;
     if (e->obs_nlandmarks < 0 || e->obs_nlandmarks != nlandmarks) return SLAM_ERR_NOT_READY;
@@ -932,12 +934,14 @@ int slam_ekf_split_dev(slam_engine* e, const float* d_mean_in, float* d_mean_out
     a.xcd_chunk = 0;
     a.cov = split->cov;
     a.cov_stride = split->cov_stride;
+    a.covx = split->covx;
+    a.covx_stride = split->covx_stride;
     a.cls_in = split->cls_in;
     a.cls_out = split->cls_out;
     a.cstamp = split->cstamp;
     a.stamp_now = split->stamp_now;
-    const int group = e->ekf_group_size(n, d_anc != nullptr, plane_stride, false);
-    HIP_TRY(launch_ekf_update(e->stream, a, e->prof_next(SLAM_PROF_EKF), group == 4 ? 4 : 2));
+    const int group = e->ekf_group_size(n, d_anc != nullptr, plane_stride, false, true);
+    HIP_TRY(launch_ekf_update(e->stream, a, e->prof_next(SLAM_PROF_EKF), group));
     e->ekf_form_launches[1]++;
     e->ll_n = n;
     return SLAM_OK;

@@ -154,9 +154,16 @@ struct slam_engine {
     // front of a small frame, where 4 keep the number of updating workgroups per scoring workgroup low (64k x 500: 143
     // against 160 us; 3 particles per wavefront: 143.5 against 142.6 us fused, 138 against 134 us alone) as long as neighbours
     // share ancestors (fewer than 3 distinct in 10 slots, as far as the last resample stage reported).
-    int ekf_group_size(int n, bool has_anc, int plane_stride, bool fused) const
+    // Split layout: the kernel is bound by its vector instructions and by what a wavefront does once per pass whatever its
+    // group (observation flags, the class's covariances, its own start-up with the motion sample), so larger groups win:
+    // fused front at 64k x 500: 2 particles per wavefront 116 us, 4: 99 us, 8: 92.6 us.
+    int ekf_group_size(int n, bool has_anc, int plane_stride, bool fused, bool split = false) const
     {
-        if (ekf_form >= 0) return ekf_form == 0 ? 0 : (ekf_form == 2 ? 2 : 4);
+        if (ekf_form >= 0) return ekf_form == 0 ? (split ? 2 : 0) : (ekf_form == 2 ? 2 : 4);
+        if (split) {
+            const int heads = h_heads[0], hn = h_heads[1];
+            return hn == n && (int64_t)heads * 10 < (int64_t)n * 3 ? 8 : 4;
+        }
         if (!has_anc) return 0;
         if (!fused) return 2;
         const int heads = h_heads[0], hn = h_heads[1];

@@ -109,6 +109,8 @@ struct EkfArgs {
     // class), hands the class of the source particle on to its offspring and marks it as still in use.
     const float* cov = nullptr;       // [classes][3][plane_stride]
     int64_t cov_stride = 0;           // floats between the rows of two classes
+    const float* covx = nullptr;      // [classes][2][plane_stride]: 1 / det (P + q I) and 0.5 log det (P + q I) of the same covariances
+    int64_t covx_stride = 0;          //   (ekf_math.h: ekf_det_terms), kept up to date by whoever writes cov
     const int32_t* cls_in = nullptr;  // class of every source particle
     int32_t* cls_out = nullptr;       // class of every particle of this frame
     uint32_t* cstamp = nullptr;       // [classes]: stamp_now = "a particle of this frame belongs to the class"
@@ -118,6 +120,8 @@ struct EkfArgs {
 struct SplitIO {
     const float* cov;
     int64_t cov_stride;
+    const float* covx;
+    int64_t covx_stride;
     const int32_t* cls_in;
     int32_t* cls_out;
     uint32_t* cstamp;
@@ -147,6 +151,8 @@ hipError_t launch_frame_front(hipStream_t stream, const ScoreGrid& g, const floa
 struct CovArgs {
     float* cov;
     int64_t cov_stride;
+    float* covx;           // the determinant terms of the NEW covariances go here (EkfArgs::covx)
+    int64_t covx_stride;
     int plane_stride, nlandmarks;
     const float *obs_zx, *obs_zy;
     float meas_var;
@@ -165,9 +171,11 @@ hipError_t launch_cov_update(hipStream_t stream, const CovArgs& a, int bound, co
 // order; all particles alike -> one class).  scratch: split_scratch_words(n) int32 words.  live[k] = k, cnt[phase] = number
 // of classes (cnt[other] = 0), every class stamped stamp_now; h_live = {classes, epoch}.
 size_t split_scratch_words(int n);
+// covx (written by a second launch, so that it may lie where the rows came from): the determinant terms of every class.
 hipError_t launch_split_from_rows(hipStream_t stream, const float* rows, int64_t row_stride_in, int plane_stride_in, int nlandmarks,
-                                  int n, int Lp, float* mean, float* cov, int32_t* cls, int32_t* live, int32_t* cnt, int phase,
-                                  uint32_t* cstamp, uint32_t stamp_now, int32_t* h_live, uint32_t epoch, void* scratch);
+                                  int n, int Lp, float* mean, float* cov, float* covx, float meas_var, int32_t* cls, int32_t* live,
+                                  int32_t* cnt, int phase, uint32_t* cstamp, uint32_t stamp_now, int32_t* h_live, uint32_t epoch,
+                                  void* scratch);
 // out row k = [means of particle idx[k] (or k) | the covariance planes of its class], nlandmarks columns of each plane
 hipError_t launch_rows_from_split(hipStream_t stream, const float* mean, const float* cov, const int32_t* cls, int Lp,
                                   const int32_t* idx, int count, float* rows, int64_t row_stride, int plane_stride, int nlandmarks);
@@ -175,8 +183,8 @@ hipError_t launch_rows_from_split(hipStream_t stream, const float* mean, const f
 hipError_t launch_split_gather(hipStream_t stream, const float* mean_in, float* mean_out, const int32_t* cls_in, int32_t* cls_out,
                                int Lp, const int32_t* anc, int n, uint32_t* cstamp, uint32_t stamp_now);
 // every particle: all landmarks "not seen yet", one class
-hipError_t launch_split_reset(hipStream_t stream, float* mean, float* cov, int32_t* cls, int Lp, int n, int32_t* live, int32_t* cnt,
-                              int phase, uint32_t* cstamp, uint32_t stamp_now, int32_t* h_live, uint32_t epoch);
+hipError_t launch_split_reset(hipStream_t stream, float* mean, float* cov, float* covx, int32_t* cls, int Lp, int n, int32_t* live,
+                              int32_t* cnt, int phase, uint32_t* cstamp, uint32_t stamp_now, int32_t* h_live, uint32_t epoch);
 
 // carry / prev_resampled (optional): see logweight_kernel — the weights a frame without resample left behind
 // In-place update of the OBSERVED landmarks only (frames that keep their population): the observation table is first

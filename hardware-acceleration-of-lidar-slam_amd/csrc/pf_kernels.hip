@@ -77,6 +77,9 @@ __device__ __forceinline__ float row_load(__amdgpu_buffer_rsrc_t r, unsigned vof
 }
 __device__ __forceinline__ void row_store(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff, float v)
 {
+#ifdef EKF_MEASURE_NO_STORES   // measurement builds only (wrong results): what the kernels take without their row stores
+    if (__float_as_uint(v) == 0x7fc12345u)
+#endif
     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, (int)voff, soff, EKF_STORE_AUX);
 }
 __device__ __forceinline__ gchar* uniform_gptr(const void* p)   // tell the compiler the pointer is wave-uniform
@@ -377,6 +380,15 @@ __device__ __forceinline__ float lane_value(float v, int k)   // lane k's value,
 #define EKF_GROUP_NB 2
 #endif
 #define EKF_GROUP_ATTR __attribute__((amdgpu_waves_per_eu(EKF_GROUP_WPE, EKF_GROUP_WPE)))
+// the same two knobs for the kernels of the split layout (a batch costs fewer registers there: no covariance planes to carry)
+#ifndef EKF_SPLIT_WPE
+#define EKF_SPLIT_WPE 5   // 64k x 500, fused front: 4 waves 97.7 us, 5 waves 94.8 us, 6 waves 99.4 us, 8 waves (spills) 149 us
+#endif
+#ifndef EKF_SPLIT_NB
+#define EKF_SPLIT_NB 2
+#endif
+#define EKF_SPLIT_ATTR __attribute__((amdgpu_waves_per_eu(EKF_SPLIT_WPE, EKF_SPLIT_WPE)))
+#define EKF_FRONT_ATTR(SPLIT_) __attribute__((amdgpu_waves_per_eu((SPLIT_) ? EKF_SPLIT_WPE : EKF_GROUP_WPE, (SPLIT_) ? EKF_SPLIT_WPE : EKF_GROUP_WPE)))
 // `bid`: the workgroup's index after the XCD-contiguous renumbering; s_acc: per particle of the group the 128 accumulators of
 // the specification.  OWN_MOTION (the fused front kernel of a frame, below): the poses are not read from a.x / a.y / a.th but
 // worked out here — pose = motion_sample(source pose of the ancestor), the very computation the scoring workgroups of the
@@ -521,46 +533,59 @@ __global__ __launch_bounds__(kEkfWaves * 64) EKF_GROUP_ATTR void ekf_update_grou
 template <int NB>
 struct SplitBatch {
     v2f mx[NB], my[NB];        // prior means of the current source row
-    EkfShared<v2f> sh[NB];     // the pose-independent part of the update, from the current class's covariance row
+    EkfShared<v2f> sh[NB];     // the pose-independent part of the update, from the current class's covariance row (o2 .. o4 unused)
     v2f zx[NB], zy[NB];
-    bool obs[NB][2], first[NB][2];
-    bool any_obs[NB], all_obs[NB], any_first[NB];   // wave-uniform
+    // the two special cases of a landmark, as lane masks: `keep` = no observation (the prior mean stays, no likelihood term),
+    // `first` = observed for the first time (the observed point becomes the mean, no likelihood term); wave-uniform: whether a
+    // batch holds any observation at all, and whether it holds a special lane
+    bool keep[NB][2], first[NB][2];
+    bool any_obs[NB], any_keep[NB], special[NB];
     unsigned off[NB][2];
 };
+
+// One batch of one particle.  SPECIAL = false: every lane holds an observed landmark seen before — the plain update, no
+// select anywhere.  In a running filter that is nearly every batch, and left to itself the compiler turns the two wave-uniform
+// tests around the special cases into 26 v_cndmask per batch (as many instructions as the update's arithmetic: counted in
+// the ISA of round 3's kernel): hence two copies of the batch, chosen by a REAL branch (the asm statement keeps the copies
+// from being merged back into one).
+template <int NB, bool SPECIAL>
+__device__ __forceinline__ void split_apply_one(const SplitBatch<NB>& b, int g, const EkfPose& w, int pl, v2f& acc)
+{
+    v2f zx = b.zx[g];
+    if constexpr (SPECIAL) asm volatile("" : "+v"(zx));
+    const EkfParticle<v2f> u = ekf_particle<v2f>(b.sh[g], b.mx[g], b.my[g], zx, b.zy[g], w.s, w.c, w.px, w.py);
+    v2f r0 = u.o0, r1 = u.o1, ll = u.ll;
+    if constexpr (SPECIAL) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {   // obs ? (first ? the observed point : the update) : the prior
+            r0[t] = b.keep[g][t] ? b.mx[g][t] : (b.first[g][t] ? u.wx[t] : r0[t]);
+            r1[t] = b.keep[g][t] ? b.my[g][t] : (b.first[g][t] ? u.wy[t] : r1[t]);
+            ll[t] = (b.keep[g][t] || b.first[g][t]) ? 0.0f : ll[t];
+        }
+    }
+    acc = acc + ll;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        row_store(w.rout, b.off[g][t], 0, r0[t]);
+        row_store(w.rout, b.off[g][t], pl, r1[t]);
+    }
+}
 
 template <int NB>
 __device__ __forceinline__ void split_apply(const SplitBatch<NB>& b, const EkfPose& w, int pl, v2f& acc)
 {
 #pragma unroll
     for (int g = 0; g < NB; ++g) {
-        v2f r0 = b.mx[g], r1 = b.my[g];
-        if (b.any_obs[g]) {
-            const EkfParticle<v2f> u = ekf_particle<v2f>(b.sh[g], b.mx[g], b.my[g], b.zx[g], b.zy[g], w.s, w.c, w.px, w.py);
-            v2f ll = u.ll;
-            r0 = u.o0;
-            r1 = u.o1;
-            if (b.any_first[g]) {
+        if (!b.any_obs[g]) {   // nothing observed among these 128 landmarks: the means are copied
 #pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    r0[t] = b.first[g][t] ? u.wx[t] : r0[t];
-                    r1[t] = b.first[g][t] ? u.wy[t] : r1[t];
-                    ll[t] = b.first[g][t] ? 0.0f : ll[t];
-                }
+            for (int t = 0; t < 2; ++t) {
+                row_store(w.rout, b.off[g][t], 0, b.mx[g][t]);
+                row_store(w.rout, b.off[g][t], pl, b.my[g][t]);
             }
-            if (!b.all_obs[g]) {
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    r0[t] = b.obs[g][t] ? r0[t] : b.mx[g][t];
-                    r1[t] = b.obs[g][t] ? r1[t] : b.my[g][t];
-                    ll[t] = b.obs[g][t] ? ll[t] : 0.0f;
-                }
-            }
-            acc = acc + ll;
-        }
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            row_store(w.rout, b.off[g][t], 0, r0[t]);
-            row_store(w.rout, b.off[g][t], pl, r1[t]);
+        } else if (b.special[g]) {
+            split_apply_one<NB, true>(b, g, w, pl, acc);
+        } else {
+            split_apply_one<NB, false>(b, g, w, pl, acc);
         }
     }
 }
@@ -616,60 +641,103 @@ __device__ __forceinline__ void ekf_split_body(const EkfArgs& a, int bid, float 
         return w;
     };
 
-    for (unsigned lb = 0; lb < L; lb += 128u * NB) {
-        SplitBatch<NB> b;
+    // What a pass needs from memory before it can start: the observations of its landmarks, the means of the group's first
+    // ancestor and the covariance row of its class, all issued together.  (Issuing the loads of pass p + 1 before pass p is
+    // worked on was built and measured: 99.2 against 97.7 us for the fused front at 64k x 500, at 44 more VGPRs — the kernel is
+    // bound by its vector instructions, 61 us of them at 64k x 500, and by the drain of its row stores, which a load phase
+    // behind them has to wait for on this hardware; removed.)
+    struct Raw {
+        v2f zx[NB], zy[NB], mx[NB], my[NB], pr[NB][5];
+        unsigned off[NB][2];
+        bool in[NB][2];
+    };
+    const int src0 = __builtin_amdgcn_readlane(src_l, 0), cls0 = __builtin_amdgcn_readlane(cls_l, 0);
+    auto load_means = [&](int src, const unsigned (&off)[NB][2], v2f (&mx)[NB], v2f (&my)[NB]) {
+        const __amdgpu_buffer_rsrc_t rin =
+            __builtin_amdgcn_make_buffer_rsrc((void*)uniform_gptr(a.map_in + (int64_t)src * a.row_stride), 0, mean_bytes, 0x00020000);
+#pragma unroll
+        for (int g = 0; g < NB; ++g)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                mx[g][t] = row_load(rin, off[g][t], 0);
+                my[g][t] = row_load(rin, off[g][t], pl);
+            }
+    };
+    auto load_cov = [&](int cls, const unsigned (&off)[NB][2], v2f (&pr)[NB][5]) {
+        const __amdgpu_buffer_rsrc_t rc =
+            __builtin_amdgcn_make_buffer_rsrc((void*)uniform_gptr(a.cov + (int64_t)cls * a.cov_stride), 0, cov_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rx =
+            __builtin_amdgcn_make_buffer_rsrc((void*)uniform_gptr(a.covx + (int64_t)cls * a.covx_stride), 0, 2 * pl, 0x00020000);
+#pragma unroll
+        for (int g = 0; g < NB; ++g)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+#pragma unroll
+                for (int p = 0; p < 3; ++p) pr[g][p][t] = row_load(rc, off[g][t], p * pl);
+                pr[g][3][t] = row_load(rx, off[g][t], 0);
+                pr[g][4][t] = row_load(rx, off[g][t], pl);
+            }
+    };
+    auto issue = [&](unsigned lb, Raw& r) {
 #pragma unroll
         for (int g = 0; g < NB; ++g)
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const unsigned l = lb + (unsigned)g * 128u + 64u * t + lane;
-                const bool in = l < L;
-                b.off[g][t] = l < room ? l * 4u : 0xffffffffu;   // beyond the planes: loads give 0, stores are dropped
-                const unsigned zo = (in ? l : 0u) * 4u;
-                const float vx = *(const gfloat*)(ozx + zo), vy = *(const gfloat*)(ozy + zo);
-                b.zx[g][t] = in ? vx : nan;
-                b.zy[g][t] = in ? vy : nan;
-                b.obs[g][t] = b.zx[g][t] == b.zx[g][t] && b.zy[g][t] == b.zy[g][t];
+                r.in[g][t] = l < L;
+                r.off[g][t] = l < room ? l * 4u : 0xffffffffu;   // beyond the planes: loads give 0, stores are dropped
+                const unsigned zo = (r.in[g][t] ? l : 0u) * 4u;
+                r.zx[g][t] = *(const gfloat*)(ozx + zo);
+                r.zy[g][t] = *(const gfloat*)(ozy + zo);
+            }
+        load_means(src0, r.off, r.mx, r.my);
+        load_cov(cls0, r.off, r.pr);
+    };
+    // everything about the update that depends on the class's covariances alone
+    auto prepare = [&](SplitBatch<NB>& b, const v2f (&pr)[NB][5]) {
+#pragma unroll
+        for (int g = 0; g < NB; ++g) {
+            b.first[g][0] = pr[g][0][0] < 0.0f;
+            b.first[g][1] = pr[g][0][1] < 0.0f;
+            b.special[g] = b.any_keep[g] || __ballot(b.first[g][0] || b.first[g][1]) != 0;
+            if (b.any_obs[g]) b.sh[g] = ekf_shared_from<v2f, false>(pr[g][0], pr[g][1], pr[g][2], q2, pr[g][3], pr[g][4]);
+        }
+    };
+
+    constexpr unsigned kStep = 128u * NB;
+    for (unsigned lb = 0; lb < L; lb += kStep) {
+        Raw cur;
+        issue(lb, cur);
+        SplitBatch<NB> b;
+#pragma unroll
+        for (int g = 0; g < NB; ++g)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                b.off[g][t] = cur.off[g][t];
+                b.zx[g][t] = cur.in[g][t] ? cur.zx[g][t] : nan;
+                b.zy[g][t] = cur.in[g][t] ? cur.zy[g][t] : nan;
+                b.keep[g][t] = !(b.zx[g][t] == b.zx[g][t] && b.zy[g][t] == b.zy[g][t]);
+                b.mx[g][t] = cur.mx[g][t];
+                b.my[g][t] = cur.my[g][t];
             }
 #pragma unroll
         for (int g = 0; g < NB; ++g) {
-            b.any_obs[g] = __ballot(b.obs[g][0] || b.obs[g][1]) != 0;
-            b.all_obs[g] = __ballot(!(b.obs[g][0] && b.obs[g][1])) == 0;
+            b.any_obs[g] = __ballot(!(b.keep[g][0] && b.keep[g][1])) != 0;
+            b.any_keep[g] = __ballot(b.keep[g][0] || b.keep[g][1]) != 0;
         }
-        int prev = -1, prev_cls = -1;
+        prepare(b, cur.pr);
+        int prev = src0, prev_cls = cls0;
         for (int k = 0; k < nslots; ++k) {
             const int src = __builtin_amdgcn_readlane(src_l, k);
             const int cls = __builtin_amdgcn_readlane(cls_l, k);
-            const bool new_cls = cls != prev_cls;
-            v2f pr[NB][3];
-            if (src != prev) {   // a new ancestor: its means into registers (wave-uniform branch)
-                const __amdgpu_buffer_rsrc_t rin =
-                    __builtin_amdgcn_make_buffer_rsrc((void*)uniform_gptr(a.map_in + (int64_t)src * a.row_stride), 0, mean_bytes, 0x00020000);
-#pragma unroll
-                for (int g = 0; g < NB; ++g)
-#pragma unroll
-                    for (int t = 0; t < 2; ++t) {
-                        b.mx[g][t] = row_load(rin, b.off[g][t], 0);
-                        b.my[g][t] = row_load(rin, b.off[g][t], pl);
-                    }
+            if (src != prev) {   // another ancestor: its means into registers (wave-uniform branch)
+                load_means(src, b.off, b.mx, b.my);
                 prev = src;
             }
-            if (new_cls) {   // a new class: its covariances, and everything about the update that depends on them alone
-                const __amdgpu_buffer_rsrc_t rc =
-                    __builtin_amdgcn_make_buffer_rsrc((void*)uniform_gptr(a.cov + (int64_t)cls * a.cov_stride), 0, cov_bytes, 0x00020000);
-#pragma unroll
-                for (int g = 0; g < NB; ++g)
-#pragma unroll
-                    for (int t = 0; t < 2; ++t)
-#pragma unroll
-                        for (int p = 0; p < 3; ++p) pr[g][p][t] = row_load(rc, b.off[g][t], p * pl);
-#pragma unroll
-                for (int g = 0; g < NB; ++g) {
-                    b.first[g][0] = pr[g][0][0] < 0.0f;
-                    b.first[g][1] = pr[g][0][1] < 0.0f;
-                    b.any_first[g] = __ballot(b.first[g][0] || b.first[g][1]) != 0;
-                    if (b.any_obs[g]) b.sh[g] = ekf_shared<v2f>(pr[g][0], pr[g][1], pr[g][2], q2);
-                }
+            if (cls != prev_cls) {   // another class: its covariances with their determinant terms
+                v2f pr[NB][5];
+                load_cov(cls, b.off, pr);
+                prepare(b, pr);
                 prev_cls = cls;
             }
             const EkfPose w = pose_of(k);
@@ -689,7 +757,7 @@ __device__ __forceinline__ void ekf_split_body(const EkfArgs& a, int bid, float 
 }
 
 template <int NB, int G>
-__global__ __launch_bounds__(kEkfWaves * 64) EKF_GROUP_ATTR void ekf_split_kernel(EkfArgs a)
+__global__ __launch_bounds__(kEkfWaves * 64) EKF_SPLIT_ATTR void ekf_split_kernel(EkfArgs a)
 {
     __shared__ float s_acc[kEkfWaves][G][128];
     int bid = blockIdx.x;
@@ -721,7 +789,7 @@ struct FrontArgs {
 };
 
 template <int NB, int G, int LPP, int DEPTH, bool SPLIT = false, bool PACKED = false>
-__global__ __launch_bounds__(kEkfWaves * 64) EKF_GROUP_ATTR void frame_front_kernel(FrontArgs f)
+__global__ __launch_bounds__(kEkfWaves * 64) EKF_FRONT_ATTR(SPLIT) void frame_front_kernel(FrontArgs f)
 {
     static_assert(kScoreBlock == kEkfWaves * 64, "both kinds of workgroup have 256 threads");
     extern __shared__ float4 s_pair[];
@@ -1881,8 +1949,9 @@ hipError_t launch_ekf_update(hipStream_t stream, const EkfArgs& a_in, const Even
         a.xcd_chunk = (blocks + 7) / 8;
         blocks = 8 * a.xcd_chunk;
     }
-    if (a.cov) {   // split layout: always the grouped form (2 particles per wavefront unless the caller asks for 4)
-        const int G = group_size == 4 ? 4 : 2;
+    if (a.cov) {   // split layout: always the grouped form (2 particles per wavefront unless the caller asks for 4 or 8)
+        static const int forced = getenv("SLAM_SPLIT_G") ? atoi(getenv("SLAM_SPLIT_G")) : 0;   // measurements
+        const int G = forced ? forced : (group_size == 4 || group_size == 8 ? group_size : 2);
         int gblocks = (a.n + kEkfWaves * G - 1) / (kEkfWaves * G);
         a.xcd_chunk = 0;
         if (gblocks >= 64) {
@@ -1890,8 +1959,9 @@ hipError_t launch_ekf_update(hipStream_t stream, const EkfArgs& a_in, const Even
             gblocks = 8 * a.xcd_chunk;
         }
         if (ev) (void)hipEventRecord(ev->start, stream);
-        if (G == 4) ekf_split_kernel<EKF_GROUP_NB, 4><<<gblocks, kEkfWaves * 64, 0, stream>>>(a);
-        else ekf_split_kernel<EKF_GROUP_NB, 2><<<gblocks, kEkfWaves * 64, 0, stream>>>(a);
+        if (G == 8) ekf_split_kernel<EKF_SPLIT_NB, 8><<<gblocks, kEkfWaves * 64, 0, stream>>>(a);
+        else if (G == 4) ekf_split_kernel<EKF_SPLIT_NB, 4><<<gblocks, kEkfWaves * 64, 0, stream>>>(a);
+        else ekf_split_kernel<EKF_SPLIT_NB, 2><<<gblocks, kEkfWaves * 64, 0, stream>>>(a);
         if (ev) (void)hipEventRecord(ev->stop, stream);
         return hipGetLastError();
     }
@@ -1939,7 +2009,7 @@ hipError_t launch_ekf_update(hipStream_t stream, const EkfArgs& a_in, const Even
 bool frame_front_fits(int n, int nlandmarks, int group_size)
 {
     static const int wave_max = getenv("SLAM_SCORE_WAVE_MAX") ? atoi(getenv("SLAM_SCORE_WAVE_MAX")) : kWaveMaxPoses;
-    if (n < wave_max || nlandmarks <= 128 || (group_size != 2 && group_size != 4)) return false;
+    if (n < wave_max || nlandmarks <= 128 || (group_size != 2 && group_size != 4 && group_size != 8)) return false;
     return (n + kEkfWaves * group_size - 1) / (kEkfWaves * group_size) >= 64;
 }
 
@@ -1954,6 +2024,9 @@ hipError_t launch_frame_front(hipStream_t stream, const ScoreGrid& g, const floa
     *launched = false;
     const int n = a_in.n;
     static const int quad_max = getenv("SLAM_SCORE_QUAD_MAX") ? atoi(getenv("SLAM_SCORE_QUAD_MAX")) : kQuadMaxPoses;
+    static const int forced_g = getenv("SLAM_SPLIT_G") ? atoi(getenv("SLAM_SPLIT_G")) : 0;   // measurements (split layout)
+    if (a_in.cov && forced_g) group_size = forced_g;
+    if (!a_in.cov && group_size == 8) group_size = 4;   // rows: 2 or 4 particles per updating wavefront
     if (a_in.map_in == a_in.map_out || !frame_front_fits(n, a_in.nlandmarks, group_size)) return hipSuccess;
     const int G = group_size;
     const int gblocks = (n + kEkfWaves * G - 1) / (kEkfWaves * G);
@@ -1983,14 +2056,16 @@ hipError_t launch_frame_front(hipStream_t stream, const ScoreGrid& g, const floa
     if (ev) (void)hipEventRecord(ev->start, stream);
     // the instantiation: particles per updating wavefront x scorer's lane mapping x map layout x grid copy the scorer reads
 #define SLAM_FRONT(G_, LPP_, DEPTH_, SP_, PK_) \
-    frame_front_kernel<EKF_GROUP_NB, G_, LPP_, DEPTH_, SP_, PK_><<<grid, kEkfWaves * 64, lds, stream>>>(f)
+    frame_front_kernel<(SP_) ? EKF_SPLIT_NB : EKF_GROUP_NB, G_, LPP_, DEPTH_, SP_, PK_><<<grid, kEkfWaves * 64, lds, stream>>>(f)
 #define SLAM_FRONT_GL(SP_, PK_)                          \
     do {                                                 \
         if (quad) {                                      \
             if (G == 2) SLAM_FRONT(2, 4, kQuadDepth, SP_, PK_); \
+            else if (G == 8 && (SP_)) SLAM_FRONT((SP_) ? 8 : 4, 4, kQuadDepth, SP_, PK_); \
             else SLAM_FRONT(4, 4, kQuadDepth, SP_, PK_);        \
         } else {                                         \
             if (G == 2) SLAM_FRONT(2, 1, kLaneDepth, SP_, PK_); \
+            else if (G == 8 && (SP_)) SLAM_FRONT((SP_) ? 8 : 4, 1, kLaneDepth, SP_, PK_); \
             else SLAM_FRONT(4, 1, kLaneDepth, SP_, PK_);        \
         }                                                \
     } while (0)

@@ -80,6 +80,7 @@ struct slam_pf {
     bool dense_split = false;       // AUTO's layout for dense frames is split (else rows)
     float* mean[2] = { nullptr, nullptr };   // [cap][2][Lp]: mean[0] and cov share one half of the store, mean[1] starts the other
     float* cov = nullptr;           // [cap][3][Lp], updated in place once per class and frame
+    float* covx = nullptr;          // [cap][2][Lp]: the determinant terms of the same covariances (behind mean[1])
     int sp_base = 0;                // the half of the store that holds mean[0] and cov
     int sp_cur = 0;                 // mean / class buffer of the current particles
     int32_t* cls[2] = { nullptr, nullptr };    // [cap]
@@ -366,14 +367,15 @@ bool alloc_split_tables(slam_pf* pf)
     return ok;
 }
 
-// mean[0] and cov take the half `base` of the store (2 + 3 of its 5 units), mean[1] the start of the other half
+// mean[0] and cov take the half `base` of the store (2 + 3 of its 5 units), mean[1] and covx (2 + 2) the other half
 void place_split(slam_pf* pf, int base)
 {
-    const size_t half = 5 * (size_t)pf->Lp * (size_t)pf->cap;
+    const size_t half = 5 * (size_t)pf->Lp * (size_t)pf->cap, unit = (size_t)pf->Lp * (size_t)pf->cap;
     pf->sp_base = base;
     pf->mean[0] = pf->store + (size_t)base * half;
-    pf->cov = pf->mean[0] + 2 * (size_t)pf->Lp * (size_t)pf->cap;
+    pf->cov = pf->mean[0] + 2 * unit;
     pf->mean[1] = pf->store + (size_t)(1 - base) * half;
+    pf->covx = pf->mean[1] + 2 * unit;
 }
 
 int32_t* split_h_live(slam_pf* pf) { return reinterpret_cast<int32_t*>(pf->d_hres) + 22; }   // {classes in use, epoch}
@@ -393,8 +395,8 @@ int split_from_rows(slam_pf* pf, const float* d_rows, int64_t row_stride, int pl
     slam_engine* e = pf->e;
     split_new_epoch(pf);
     SLAM_HIP_TRY(e, launch_split_from_rows(e->stream, d_rows, row_stride, plane_stride, pf->L, pf->n, pf->Lp, pf->mean[pf->sp_cur], pf->cov,
-                                           pf->cls[pf->sp_cur], pf->live[0], pf->cov_cnt, 0, pf->cstamp, pf->cstamp_now,
-                                           split_h_live(pf), pf->cls_epoch, pf->split_scratch));
+                                           pf->covx, pf->cfg.meas_var, pf->cls[pf->sp_cur], pf->live[0], pf->cov_cnt, 0, pf->cstamp,
+                                           pf->cstamp_now, split_h_live(pf), pf->cls_epoch, pf->split_scratch));
     return SLAM_OK;
 }
 
@@ -641,8 +643,8 @@ int slam_pf_reset(slam_pf* pf, const float pose[3])
     if (hipMemcpy(pf->pose[pf->cur], h.data(), 3 * n * 4, hipMemcpyHostToDevice) != hipSuccess) return SLAM_ERR_HIP;
     if (pf->split) {   // every landmark of every particle "not seen yet": one class
         split_new_epoch(pf);
-        SLAM_HIP_TRY(pf->e, launch_split_reset(pf->e->stream, pf->mean[pf->sp_cur], pf->cov, pf->cls[pf->sp_cur], pf->Lp, pf->n, pf->live[0],
-                                               pf->cov_cnt, 0, pf->cstamp, pf->cstamp_now, split_h_live(pf), pf->cls_epoch));
+        SLAM_HIP_TRY(pf->e, launch_split_reset(pf->e->stream, pf->mean[pf->sp_cur], pf->cov, pf->covx, pf->cls[pf->sp_cur], pf->Lp, pf->n,
+                                               pf->live[0], pf->cov_cnt, 0, pf->cstamp, pf->cstamp_now, split_h_live(pf), pf->cls_epoch));
         if (int rc = slam_engine_sync(pf->e)) return rc;
     } else if (pf->paged) {   // every particle names ONE shared page of landmarks not seen yet
         SLAM_HIP_TRY(pf->e, launch_pages_reset(pf->e->stream, pf->pool, pf->pt[pf->pt_cur], (int64_t)pf->n * pf->nb, pf->freelist,
@@ -766,6 +768,8 @@ static int pf_step_impl(slam_pf* pf, int slot, const float dp[3], int use_observ
     if (pf->split) {   // the classes follow their particles through the update; it stamps the ones still in use
         sio.cov = pf->cov;
         sio.cov_stride = 3 * (int64_t)pf->Lp;
+        sio.covx = pf->covx;
+        sio.covx_stride = 2 * (int64_t)pf->Lp;
         sio.cls_in = pf->cls[pf->sp_cur];
         sio.cls_out = pf->cls[1 - pf->sp_cur];
         sio.cstamp = pf->cstamp;
@@ -840,6 +844,8 @@ static int pf_step_impl(slam_pf* pf, int slot, const float dp[3], int use_observ
             CovArgs ca;
             ca.cov = pf->cov;
             ca.cov_stride = 3 * (int64_t)pf->Lp;
+            ca.covx = pf->covx;
+            ca.covx_stride = 2 * (int64_t)pf->Lp;
             ca.plane_stride = pf->Lp;
             ca.nlandmarks = L;
             ca.obs_zx = e->d_obs_zx;

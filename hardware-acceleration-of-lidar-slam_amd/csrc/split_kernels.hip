@@ -13,6 +13,9 @@
 //     cls[particle]             the particle's class, handed from ancestor to offspring by the update itself
 //     cov[class][3][Lp]         updated IN PLACE, once per class and frame, by cov_update_kernel — after the particles' update,
 //                               which reads the prior
+//     covx[class][2][Lp]        1 / det (P + q I) and 0.5 log det (P + q I) of the same covariances: the two expensive values
+//                               of the update (a reciprocal and a logarithm), worked out by whoever writes cov so that the
+//                               particles' update — every wavefront of it — starts from them instead of recomputing them
 //     live[..], cnt[3]          the classes still in use, as a list that only ever shrinks: classes die with their last
 //                               particle and are never born (set_map / reset start a new epoch)
 // The values are those of the row layout, bit for bit (the same ekf_shared / ekf_particle, the same order); the layout is not
@@ -59,7 +62,9 @@ __global__ __launch_bounds__(256) void cov_update_kernel(CovArgs a)
     const float pxx = row[0], pxy = row[a.plane_stride], pyy = row[2 * (int64_t)a.plane_stride];
     float o2 = a.meas_var, o3 = 0.0f, o4 = a.meas_var;   // a first sighting: q I
     if (!(pxx < 0.0f)) {
-        const EkfShared<float> h = ekf_shared<float>(pxx, pxy, pyy, a.meas_var);
+        // (the prior's determinant terms lie in covx; starting from them instead of recomputing them gives the same bits)
+        const float* xr = a.covx + (int64_t)c * a.covx_stride + l;
+        const EkfShared<float> h = ekf_shared_from<float>(pxx, pxy, pyy, a.meas_var, xr[0], xr[a.plane_stride]);
         o2 = h.o2;
         o3 = h.o3;
         o4 = h.o4;
@@ -67,6 +72,28 @@ __global__ __launch_bounds__(256) void cov_update_kernel(CovArgs a)
     row[0] = o2;
     row[a.plane_stride] = o3;
     row[2 * (int64_t)a.plane_stride] = o4;
+    // what the next update of this landmark starts from
+    float idet, hl;
+    ekf_det_terms<float>(o2, o3, o4, a.meas_var, idet, hl);
+    float* xw = a.covx + (int64_t)c * a.covx_stride + l;
+    xw[0] = idet;
+    xw[a.plane_stride] = hl;
+}
+
+// the determinant terms of classes 0 .. *count - 1 from their covariance planes (after a conversion or a reset)
+__global__ __launch_bounds__(256) void cov_terms_kernel(const float* __restrict__ cov, float* __restrict__ covx, int Lp, int nlandmarks,
+                                                        float q, const int32_t* __restrict__ count)
+{
+    const int c = blockIdx.x;
+    if (c >= *count) return;
+    const int l = blockIdx.y * 256 + threadIdx.x;
+    if (l >= Lp) return;
+    const float* r = cov + (int64_t)c * 3 * Lp + l;
+    float idet = 1.0f, hl = 0.0f;   // (padding columns and landmarks not seen yet: never read)
+    if (l < nlandmarks && !(r[0] < 0.0f)) ekf_det_terms<float>(r[0], r[Lp], r[2 * (int64_t)Lp], q, idet, hl);
+    float* x = covx + (int64_t)c * 2 * Lp + l;
+    x[0] = idet;
+    x[Lp] = hl;
 }
 
 // ---- rows -> split
@@ -212,8 +239,9 @@ hipError_t launch_cov_update(hipStream_t stream, const CovArgs& a, int bound, co
 size_t split_scratch_words(int n) { return 2 * (2 * (size_t)n + (size_t)prefix_sum_scratch_elems(n)) + 4; }
 
 hipError_t launch_split_from_rows(hipStream_t stream, const float* rows, int64_t row_stride_in, int plane_stride_in, int nlandmarks,
-                                  int n, int Lp, float* mean, float* cov, int32_t* cls, int32_t* live, int32_t* cnt, int phase,
-                                  uint32_t* cstamp, uint32_t stamp_now, int32_t* h_live, uint32_t epoch, void* scratch)
+                                  int n, int Lp, float* mean, float* cov, float* covx, float meas_var, int32_t* cls, int32_t* live,
+                                  int32_t* cnt, int phase, uint32_t* cstamp, uint32_t stamp_now, int32_t* h_live, uint32_t epoch,
+                                  void* scratch)
 {
     if (n <= 0) return hipSuccess;
     uint64_t* flag = static_cast<uint64_t*>(scratch);
@@ -224,6 +252,8 @@ hipError_t launch_split_from_rows(hipStream_t stream, const float* rows, int64_t
     if (err != hipSuccess) return err;
     split_from_rows_kernel<<<n, 256, 0, stream>>>(rows, row_stride_in, plane_stride_in, nlandmarks, n, Lp, flag, sum, mean, cov, cls,
                                                   live, cnt, phase, cstamp, stamp_now, h_live, epoch);
+    // at most n classes: the launch is as wide as that, workgroups beyond the count leave at once
+    cov_terms_kernel<<<dim3((unsigned)n, (unsigned)((Lp + 255) / 256)), 256, 0, stream>>>(cov, covx, Lp, nlandmarks, meas_var, cnt + phase);
     return hipGetLastError();
 }
 
@@ -243,12 +273,13 @@ hipError_t launch_split_gather(hipStream_t stream, const float* mean_in, float* 
     return hipGetLastError();
 }
 
-hipError_t launch_split_reset(hipStream_t stream, float* mean, float* cov, int32_t* cls, int Lp, int n, int32_t* live, int32_t* cnt,
-                              int phase, uint32_t* cstamp, uint32_t stamp_now, int32_t* h_live, uint32_t epoch)
+hipError_t launch_split_reset(hipStream_t stream, float* mean, float* cov, float* covx, int32_t* cls, int Lp, int n, int32_t* live,
+                              int32_t* cnt, int phase, uint32_t* cstamp, uint32_t stamp_now, int32_t* h_live, uint32_t epoch)
 {
     const int64_t m = (int64_t)n * 2 * Lp;
     split_reset_kernel<<<blocks256(m > 3 * (int64_t)Lp ? m : 3 * (int64_t)Lp), 256, 0, stream>>>(mean, cov, cls, Lp, n, live, cnt, phase,
                                                                                               cstamp, stamp_now, h_live, epoch);
+    cov_terms_kernel<<<dim3(1, (unsigned)((Lp + 255) / 256)), 256, 0, stream>>>(cov, covx, Lp, 0, 1.0f, cnt + phase);   // nothing seen yet
     return hipGetLastError();
 }
 
