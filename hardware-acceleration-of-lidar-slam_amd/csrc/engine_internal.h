@@ -263,7 +263,8 @@ int slam_engine_fastmatch(slam_engine* e, int slot, const float* d_bx, const flo
 // slam_migrate_pack_dev for a session with paged maps (d_pt: page tables of nb entries, d_map: the page pool)
 extern "C" int slam_migrate_pack_paged(slam_engine* e, int n_local, int rank, int world, const int32_t* plan, const float* d_pose,
                             int64_t pose_ld, const float* d_map, int64_t row_stride, int plane_stride, int nlandmarks,
-                            float* d_out, const int32_t* d_pt, int nb);
+                            float* d_out, const int32_t* d_pt, int nb, const float* d_split_cov = nullptr,
+                            const int32_t* d_split_cls = nullptr);   // split layout: d_map = the means (row_stride >= 2 planes)
 
 #define SLAM_HIP_TRY(e, call)                                                     \
     do {                                                                          \

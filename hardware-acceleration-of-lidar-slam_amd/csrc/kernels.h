@@ -162,8 +162,10 @@ struct CovArgs {
     int phase;
     const uint32_t* cstamp;
     uint32_t stamp_now;
-    int32_t* h_live;
+    int32_t* h_live;       // 8-byte word {cnt[phase], epoch} in mapped host memory
+    int32_t* h_mark;       // ... and, written behind a system-scope fence, {mark, epoch}
     uint32_t epoch;
+    uint32_t mark;         // the host's running count of classes appended to the list so far (sharded sessions: rows received)
 };
 hipError_t launch_cov_update(hipStream_t stream, const CovArgs& a, int bound, const EventPair* ev = nullptr);
 // rows [n][5][plane_stride_in] (row_stride_in floats apart) -> means [n][2][Lp], classes, class rows [..][3][Lp]: neighbouring
@@ -179,6 +181,13 @@ hipError_t launch_split_from_rows(hipStream_t stream, const float* rows, int64_t
 // out row k = [means of particle idx[k] (or k) | the covariance planes of its class], nlandmarks columns of each plane
 hipError_t launch_rows_from_split(hipStream_t stream, const float* mean, const float* cov, const int32_t* cls, int Lp,
                                   const int32_t* idx, int count, float* rows, int64_t row_stride, int plane_stride, int nlandmarks);
+// Sharded sessions on the split layout.  A migrating particle travels as the same record whatever the layouts of the two ranks
+// (pose, then five planes of nlandmarks values): launch_migrate_pack(.., split_cov, split_cls) reads it from the means and the
+// class's covariance row, and this launch puts record p of `in` into staging row n + p of the means, with a class of its own —
+// first_class + p, covariance planes and determinant terms filled in, appended to the list of classes in use (live[*cnt ..)).
+hipError_t launch_migrate_unpack_split(hipStream_t stream, const float* in, int total, int n, float* pose, int64_t pose_ld, float* mean,
+                                       float* cov, float* covx, int32_t* cls, int Lp, int nlandmarks, float meas_var, int first_class,
+                                       int32_t* live, int32_t* cnt);
 // a frame without a landmark update: means and classes follow their particles (out[i] = in[anc[i]])
 hipError_t launch_split_gather(hipStream_t stream, const float* mean_in, float* mean_out, const int32_t* cls_in, int32_t* cls_out,
                                int Lp, const int32_t* anc, int n, uint32_t* cstamp, uint32_t stamp_now);
@@ -340,7 +349,8 @@ hipError_t launch_ancestors_sharded(hipStream_t stream, const int32_t* first_all
 hipError_t launch_migrate_pack(hipStream_t stream, const int32_t* scratch, int n, const MigratePlan& plan,
                                const float* pose, int64_t pose_ld, const float* map, int64_t row_stride,
                                int plane_stride, int nlandmarks, float* out,
-                               const int32_t* pt = nullptr, int nb = 0);
+                               const int32_t* pt = nullptr, int nb = 0,
+                               const float* split_cov = nullptr, const int32_t* split_cls = nullptr);
 hipError_t launch_migrate_unpack(hipStream_t stream, const float* in, const MigratePlan& plan, int n, float* pose,
                                  int64_t pose_ld, float* map, int64_t row_stride, int plane_stride, int nlandmarks);
 hipError_t launch_argmax(hipStream_t stream, const float* v, int n, int32_t* idx_out, float* val_out);

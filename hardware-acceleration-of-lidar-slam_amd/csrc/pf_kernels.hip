@@ -1749,7 +1749,8 @@ __global__ __launch_bounds__(kBlock) void migrate_pack_kernel(const int32_t* __r
                                                               int64_t pose_ld, const float* __restrict__ map,
                                                               int64_t row_stride, int plane_stride, int nlandmarks,
                                                               float* __restrict__ out, const int32_t* __restrict__ pt,
-                                                              int nb)
+                                                              int nb, const float* __restrict__ split_cov,
+                                                              const int32_t* __restrict__ split_cls)
 {
     const int p = blockIdx.x;
     int d = 0;
@@ -1772,6 +1773,13 @@ __global__ __launch_bounds__(kBlock) void migrate_pack_kernel(const int32_t* __r
         return;
     }
     const float* __restrict__ row = map + (int64_t)loc * row_stride;
+    if (split_cls) {   // split layout: `map` holds the means (two planes), the covariance planes are the class's (split_kernels.hip)
+        const float* __restrict__ crow = split_cov + (int64_t)split_cls[loc] * 3 * plane_stride;
+        for (int pl = 0; pl < 5; ++pl)
+            for (int l = threadIdx.x; l < nlandmarks; l += kBlock)
+                rec[3 + pl * nlandmarks + l] = pl < 2 ? row[pl * plane_stride + l] : crow[(pl - 2) * plane_stride + l];
+        return;
+    }
     for (int pl = 0; pl < 5; ++pl)
         for (int l = threadIdx.x; l < nlandmarks; l += kBlock) rec[3 + pl * nlandmarks + l] = row[pl * plane_stride + l];
 }
@@ -2274,7 +2282,8 @@ hipError_t launch_ancestors_sharded(hipStream_t stream, const int32_t* first_all
 // plan.lo[d] = send_base[d] (the P value of the first particle sent to d), plan.off = running record offsets
 hipError_t launch_migrate_pack(hipStream_t stream, const int32_t* scratch, int n, const MigratePlan& plan,
                                const float* pose, int64_t pose_ld, const float* map, int64_t row_stride,
-                               int plane_stride, int nlandmarks, float* out, const int32_t* pt, int nb)
+                               int plane_stride, int nlandmarks, float* out, const int32_t* pt, int nb, const float* split_cov,
+                               const int32_t* split_cls)
 {
     const int total = plan.off[plan.world];
     if (total <= 0) return hipSuccess;
@@ -2282,7 +2291,7 @@ hipError_t launch_migrate_pack(hipStream_t stream, const int32_t* scratch, int n
     const int32_t* pfx = scratch + n;
     const int32_t* boff = pfx + 2 * (int64_t)n;
     migrate_pack_kernel<<<total, kBlock, 0, stream>>>(pfx, boff, ntiles, n, plan, pose, pose_ld, map, row_stride,
-                                                     plane_stride, nlandmarks, out, pt, nb);
+                                                     plane_stride, nlandmarks, out, pt, nb, split_cov, split_cls);
     return hipGetLastError();
 }
 

@@ -89,6 +89,10 @@ struct slam_pf {
     uint32_t* cstamp = nullptr;     // [cap]
     uint32_t cstamp_now = 0, cls_epoch = 0;
     int live_cur = 0, cov_phase = 0;
+    // sharded: a row that arrives from another rank gets a class of its own, numbered from next_cls on (the classes made when
+    // maps came in are numbered below it); when the numbers run out the classes are renumbered (one pass over the maps)
+    int next_cls = 0;
+    uint32_t cls_appended = 0;      // classes appended to the list so far in this epoch (what cov_update_kernel's `mark` carries)
     void* split_scratch = nullptr;  // flags, prefix sums of a rows -> split move
     bool gated = false;             // cfg.resample_ess_frac in (0, 1): a frame resamples only when its ESS is low
     int64_t frames_resampled = 0;   // (as far as the host has looked: one frame behind)
@@ -110,6 +114,9 @@ struct slam_pf {
 namespace {
 
 hipError_t dev_alloc(void** p, size_t bytes) { return hipMalloc(p, bytes ? bytes : 4); }
+
+int convert_split_to_rows(slam_pf* pf);
+int convert_rows_to_split(slam_pf* pf);
 
 int grow(slam_pf* pf, float** buf, size_t* have, size_t want)
 {
@@ -158,13 +165,32 @@ int migrate(slam_pf* pf)
     pf->rows_received = (int)rtot;
     if (int rc = grow(pf, &pf->sbuf, &pf->sbuf_floats, (size_t)(rec * stot))) return rc;
     if (int rc = grow(pf, &pf->rbuf, &pf->rbuf_floats, (size_t)(rec * rtot))) return rc;
-    const float* mp = L ? (pf->paged ? pf->pool : pf->map[pf->map_cur]) : nullptr;
+    const bool split = L && pf->split;
+    const float* mp = L ? (pf->paged ? pf->pool : split ? pf->mean[pf->sp_cur] : pf->map[pf->map_cur]) : nullptr;
     if (stot)
-        if (int rc = slam_migrate_pack_paged(e, n, pf->rank, G, plan, pf->pose[pf->cur], n, mp, 5 * (int64_t)pf->Lp, pf->Lp, L,
-                                             pf->sbuf, pf->paged ? pf->pt[pf->pt_cur] : nullptr, pf->nb))
+        if (int rc = slam_migrate_pack_paged(e, n, pf->rank, G, plan, pf->pose[pf->cur], n, mp, (split ? 2 : 5) * (int64_t)pf->Lp, pf->Lp, L,
+                                             pf->sbuf, pf->paged ? pf->pt[pf->pt_cur] : nullptr, pf->nb, split ? pf->cov : nullptr,
+                                             split ? pf->cls[pf->sp_cur] : nullptr))
             return rc;
     if (int rc = comm_all_to_all_f32(pf->comm, pf->sbuf, sfl, pf->rbuf, rfl)) return rc;
-    if (rtot && pf->paged) {
+    if (rtot && split) {
+        // every received row becomes a class of its own (it brings its covariances along); when the numbers run out, the
+        // classes are renumbered from 0 by moving the maps to rows and back: one pass each way, every cap - n received rows
+        // (SLAM_SPLIT_CLASS_ROOM: tests make the numbers run out early)
+        const char* room_env = getenv("SLAM_SPLIT_CLASS_ROOM");
+        const int64_t last = room_env && atoi(room_env) > 0 && pf->n + (int64_t)atoi(room_env) < pf->cap ? pf->n + (int64_t)atoi(room_env) : pf->cap;
+        if (pf->next_cls + rtot > last && rtot <= last - pf->n) {
+            if (int rc = convert_split_to_rows(pf)) return rc;
+            if (int rc = convert_rows_to_split(pf)) return rc;
+            pf->conversions -= 2;   // (not a change of layout)
+        }
+        const ProfScope prof(e, SLAM_PROF_UNPACK);
+        SLAM_HIP_TRY(e, launch_migrate_unpack_split(e->stream, pf->rbuf, (int)rtot, n, pf->pose_stage, pf->cap, pf->mean[pf->sp_cur], pf->cov,
+                                                    pf->covx, pf->cls[pf->sp_cur], pf->Lp, L, pf->cfg.meas_var, pf->next_cls,
+                                                    pf->live[pf->live_cur], pf->cov_cnt + pf->cov_phase));
+        pf->next_cls += (int)rtot;
+        pf->cls_appended += (uint32_t)rtot;
+    } else if (rtot && pf->paged) {
         // fresh pages for the received rows (a new free list first if the old one runs short), table rows n .. n + rtot - 1
         int32_t* pstate = pf->page_scratch;
         const ProfScope prof(e, SLAM_PROF_UNPACK);
@@ -359,7 +385,7 @@ bool alloc_split_tables(slam_pf* pf)
         ok = ok && dev_alloc((void**)&pf->cls[b], cap * 4) == hipSuccess && dev_alloc((void**)&pf->live[b], cap * 4) == hipSuccess;
     ok = ok && dev_alloc((void**)&pf->cov_cnt, 16) == hipSuccess && hipMemset(pf->cov_cnt, 0, 16) == hipSuccess &&
          dev_alloc((void**)&pf->cstamp, cap * 4) == hipSuccess && hipMemset(pf->cstamp, 0, cap * 4) == hipSuccess &&
-         dev_alloc(&pf->split_scratch, split_scratch_words(pf->n) * 4) == hipSuccess;
+         dev_alloc(&pf->split_scratch, split_scratch_words(pf->cap) * 4) == hipSuccess;
     if (!ok) {
         (void)hipGetLastError();
         free_split_tables(pf);
@@ -381,20 +407,22 @@ void place_split(slam_pf* pf, int base)
 int32_t* split_h_live(slam_pf* pf) { return reinterpret_cast<int32_t*>(pf->d_hres) + 22; }   // {classes in use, epoch}
 
 // a new set of classes is about to be made (set_map, reset, rows -> split): lists and counters start afresh
-void split_new_epoch(slam_pf* pf)
+void split_new_epoch(slam_pf* pf, int nrows)
 {
     pf->cls_epoch++;
     pf->cstamp_now++;
     pf->live_cur = 0;
     pf->cov_phase = 0;
+    pf->next_cls = nrows;   // the classes of an epoch's start are numbered 0 .. (at most) nrows - 1
+    pf->cls_appended = 0;
 }
 
-// rows (as given, any strides) -> means + classes + class rows in the buffers of the current placement
-int split_from_rows(slam_pf* pf, const float* d_rows, int64_t row_stride, int plane_stride)
+// nrows rows (as given, any strides) -> means + classes + class rows in the buffers of the current placement
+int split_from_rows(slam_pf* pf, const float* d_rows, int64_t row_stride, int plane_stride, int nrows)
 {
     slam_engine* e = pf->e;
-    split_new_epoch(pf);
-    SLAM_HIP_TRY(e, launch_split_from_rows(e->stream, d_rows, row_stride, plane_stride, pf->L, pf->n, pf->Lp, pf->mean[pf->sp_cur], pf->cov,
+    split_new_epoch(pf, nrows);
+    SLAM_HIP_TRY(e, launch_split_from_rows(e->stream, d_rows, row_stride, plane_stride, pf->L, nrows, pf->Lp, pf->mean[pf->sp_cur], pf->cov,
                                            pf->covx, pf->cfg.meas_var, pf->cls[pf->sp_cur], pf->live[0], pf->cov_cnt, 0, pf->cstamp,
                                            pf->cstamp_now, split_h_live(pf), pf->cls_epoch, pf->split_scratch));
     return SLAM_OK;
@@ -407,7 +435,7 @@ int convert_rows_to_split(slam_pf* pf)
     const int mc = pf->map_cur;
     place_split(pf, 1 - mc);
     pf->sp_cur = 0;
-    if (int rc = split_from_rows(pf, pf->map[mc], 5 * (int64_t)pf->Lp, pf->Lp)) return rc;
+    if (int rc = split_from_rows(pf, pf->map[mc], 5 * (int64_t)pf->Lp, pf->Lp, rows_to_convert(pf))) return rc;
     pf->split = true;
     pf->conversions++;
     return SLAM_OK;
@@ -418,14 +446,15 @@ int convert_rows_to_split(slam_pf* pf)
 int convert_split_to_rows(slam_pf* pf)
 {
     slam_engine* e = pf->e;
-    const size_t n = (size_t)pf->n, Lp = (size_t)pf->Lp;
+    const int nrows = rows_to_convert(pf);   // sharded: the staging tail moves along when the exchange has been completed already
+    const size_t n = (size_t)nrows, Lp = (size_t)pf->Lp;
     if (pf->sp_cur == 1) {
         SLAM_HIP_TRY(e, hipMemcpyAsync(pf->mean[0], pf->mean[1], 2 * Lp * n * 4, hipMemcpyDeviceToDevice, e->stream));
         SLAM_HIP_TRY(e, hipMemcpyAsync(pf->cls[0], pf->cls[1], n * 4, hipMemcpyDeviceToDevice, e->stream));
         pf->sp_cur = 0;
     }
     const int target = 1 - pf->sp_base;
-    SLAM_HIP_TRY(e, launch_rows_from_split(e->stream, pf->mean[0], pf->cov, pf->cls[0], pf->Lp, nullptr, pf->n, pf->map[target],
+    SLAM_HIP_TRY(e, launch_rows_from_split(e->stream, pf->mean[0], pf->cov, pf->cls[0], pf->Lp, nullptr, nrows, pf->map[target],
                                            5 * (int64_t)Lp, pf->Lp, pf->L));
     pf->map_cur = target;
     pf->split = false;
@@ -474,10 +503,7 @@ int create_common(slam_engine* e, const slam_pf_config* cfg, slam_comm* comm, in
     if (!e || !cfg || !out || cfg->n_particles <= 0 || cfg->n_landmarks < 0 || !(cfg->meas_var > 0.0f) ||
         cfg->map_layout < SLAM_MAP_AUTO || cfg->map_layout > SLAM_MAP_SPLIT)
         return SLAM_ERR_INVALID_ARG;
-    if (comm && cfg->map_layout == SLAM_MAP_SPLIT) {
-        snprintf(e->err, sizeof e->err, "SLAM_MAP_SPLIT: covariance classes are local to a GPU; sharded sessions keep rows or pages");
-        return SLAM_ERR_INVALID_ARG;
-    }
+
     *out = nullptr;
     if (e->live_sessions > 0) {   // the stages keep per-population state in the engine (gate, carried weights, exchange plan)
         snprintf(e->err, sizeof e->err, "this engine already runs a particle-filter session: one session per engine");
@@ -525,9 +551,9 @@ int create_common(slam_engine* e, const slam_pf_config* cfg, slam_comm* comm, in
     }
     pf->gated = cfg->resample_ess_frac > 0.0f && cfg->resample_ess_frac < 1.0f;
     if (L) ok = alloc_store(pf);
-    // the split layout: asked for, or what AUTO keeps a single-GPU session that resamples every frame on while its frames
-    // observe most landmarks (a sharded session's classes would have to travel; a gated one updates in place, which rows do)
-    if (L && ok && !comm && (pf->layout_cfg == SLAM_MAP_SPLIT || (pf->layout_cfg == SLAM_MAP_AUTO && !pf->gated))) {
+    // the split layout: asked for, or what AUTO keeps a session that resamples every frame on while its frames observe most
+    // landmarks (a gated one updates in place, which rows do)
+    if (L && ok && (pf->layout_cfg == SLAM_MAP_SPLIT || (pf->layout_cfg == SLAM_MAP_AUTO && !pf->gated))) {
         const bool have = alloc_split_tables(pf);
         if (!have && pf->layout_cfg == SLAM_MAP_SPLIT) ok = false;
         pf->dense_split = have && pf->layout_cfg == SLAM_MAP_AUTO;
@@ -642,7 +668,7 @@ int slam_pf_reset(slam_pf* pf, const float pose[3])
     if (int rc = slam_engine_sync(pf->e)) return rc;
     if (hipMemcpy(pf->pose[pf->cur], h.data(), 3 * n * 4, hipMemcpyHostToDevice) != hipSuccess) return SLAM_ERR_HIP;
     if (pf->split) {   // every landmark of every particle "not seen yet": one class
-        split_new_epoch(pf);
+        split_new_epoch(pf, pf->n);
         SLAM_HIP_TRY(pf->e, launch_split_reset(pf->e->stream, pf->mean[pf->sp_cur], pf->cov, pf->covx, pf->cls[pf->sp_cur], pf->Lp, pf->n,
                                                pf->live[0], pf->cov_cnt, 0, pf->cstamp, pf->cstamp_now, split_h_live(pf), pf->cls_epoch));
         if (int rc = slam_engine_sync(pf->e)) return rc;
@@ -709,7 +735,7 @@ int slam_pf_set_map_dev(slam_pf* pf, const float* d_rows, int64_t row_stride, in
     if (pf->has_anc) return SLAM_ERR_NOT_READY;   // set poses / reset first: a gather is pending
     slam_engine* e = pf->e;
     SLAM_HIP_TRY(e, hipSetDevice(e->device));
-    if (pf->split) return split_from_rows(pf, d_rows, row_stride, plane_stride);
+    if (pf->split) return split_from_rows(pf, d_rows, row_stride, plane_stride, pf->n);
     if (pf->paged) {
         SLAM_HIP_TRY(e, launch_pages_from_rows(e->stream, d_rows, row_stride, plane_stride, pf->L, pf->nb, pf->n, pf->pool,
                                                pf->pt[pf->pt_cur], pf->freelist, pf->npages, pf->page_scratch));
@@ -765,7 +791,7 @@ static int pf_step_impl(slam_pf* pf, int slot, const float dp[3], int use_observ
     // side, the scorer's gathers in the shadow of the update's row stores (slam_frame_front_dev; the same bits)
     bool fused = false;
     SplitIO sio{};
-    if (pf->split) {   // the classes follow their particles through the update; it stamps the ones still in use
+    auto make_sio = [&]() {   // the classes follow their particles through the update; it stamps the ones still in use
         sio.cov = pf->cov;
         sio.cov_stride = 3 * (int64_t)pf->Lp;
         sio.covx = pf->covx;
@@ -774,7 +800,8 @@ static int pf_step_impl(slam_pf* pf, int slot, const float dp[3], int use_observ
         sio.cls_out = pf->cls[1 - pf->sp_cur];
         sio.cstamp = pf->cstamp;
         sio.stamp_now = pf->cstamp_now + 1;
-    }
+    };
+    if (pf->split) make_sio();
     if (!comm && !pf->paged && !pf->gated && anc && L > 0 && use_observations && e->obs_nlandmarks == L) {
         if (pf->split)
             rc = slam_frame_front_dev(e, slot, src, src + sn, src + 2 * sn, anc, dst, dst + sn, dst + 2 * sn, n, first_id, dp,
@@ -824,6 +851,7 @@ static int pf_step_impl(slam_pf* pf, int slot, const float dp[3], int use_observ
     float* d_max = comm ? pf->d_max : nullptr;
     if (pf->split && L > 0) {
         const int sc = pf->sp_cur;
+        make_sio();   // (again: the exchange above may have renumbered the classes and moved the buffers)
         if (ekf) {
             if (e->obs_nlandmarks != L) return SLAM_ERR_NOT_READY;
             if (sample_obs) SLAM_HIP_TRY(e, launch_obs_count(e->stream, e->d_obs_zx, e->d_obs_zy, L, d_hobs, ++pf->obs_seq_issued, pf->votes));
@@ -838,9 +866,15 @@ static int pf_step_impl(slam_pf* pf, int slot, const float dp[3], int use_observ
             // ... then the classes' update, in place, once per class still in use.  The launch is as wide as the host knows the
             // list to be at most: its length as of some earlier frame (mapped memory, read without waiting; the list only
             // shrinks), the population before anything of this epoch has arrived.
-            const uint64_t hl = __atomic_load_n(reinterpret_cast<const uint64_t*>(reinterpret_cast<const int32_t*>(pf->h_res) + 22), __ATOMIC_ACQUIRE);
-            const int32_t seen = (int32_t)(uint32_t)hl;   // {count, epoch} in one word
-            const int bound = (uint32_t)(hl >> 32) == pf->cls_epoch && seen > 0 && seen < n ? seen : n;
+            // (sharded: plus the classes that arrived since — the second word is the running count of arrivals as of that
+            // launch; it is read FIRST and written last, so a torn pair only over-estimates)
+            const int32_t* hw = reinterpret_cast<const int32_t*>(pf->h_res);   // words 22-23: {count, epoch}; 18-19: {mark, epoch}
+            const uint64_t hm = __atomic_load_n(reinterpret_cast<const uint64_t*>(hw + 18), __ATOMIC_ACQUIRE),
+                           hl = __atomic_load_n(reinterpret_cast<const uint64_t*>(hw + 22), __ATOMIC_ACQUIRE);
+            const bool fresh = (uint32_t)(hl >> 32) == pf->cls_epoch && (uint32_t)hl > 0;
+            const uint32_t mark = (uint32_t)(hm >> 32) == pf->cls_epoch ? (uint32_t)hm : 0u;   // (no launch of this epoch has said yet: 0)
+            const int64_t upper = fresh ? (int64_t)(uint32_t)hl + (int64_t)(pf->cls_appended - mark) : (int64_t)pf->cap;
+            const int bound = upper < pf->cap ? (int)upper : pf->cap;
             CovArgs ca;
             ca.cov = pf->cov;
             ca.cov_stride = 3 * (int64_t)pf->Lp;
@@ -858,7 +892,9 @@ static int pf_step_impl(slam_pf* pf, int slot, const float dp[3], int use_observ
             ca.cstamp = pf->cstamp;
             ca.stamp_now = pf->cstamp_now;
             ca.h_live = split_h_live(pf);
+            ca.h_mark = reinterpret_cast<int32_t*>(pf->d_hres) + 18;
             ca.epoch = pf->cls_epoch;
+            ca.mark = pf->cls_appended;
             SLAM_HIP_TRY(e, launch_cov_update(e->stream, ca, bound, e->prof_next(SLAM_PROF_PAGES)));
             pf->live_cur = 1 - pf->live_cur;
             pf->cov_phase = (pf->cov_phase + 1) % 3;

@@ -48,7 +48,11 @@ __global__ __launch_bounds__(256) void cov_update_kernel(CovArgs a)
     const int nlive = a.cnt[a.phase];
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
         a.cnt[(a.phase + 2) % 3] = 0;   // the list after next: nobody reads or writes it during this launch
-        if (a.h_live) publish_live(a.h_live, nlive, a.epoch);
+        if (a.h_live) {
+            publish_live(a.h_live, nlive, a.epoch);
+            __threadfence_system();   // the count first: a host that pairs a newer count with an older mark over-estimates
+            publish_live(a.h_mark, (int)a.mark, a.epoch);
+        }
     }
     if (k >= nlive) return;
     const int c = a.live_in[k];
@@ -204,6 +208,41 @@ __global__ __launch_bounds__(256) void split_gather_kernel(const float* __restri
     }
 }
 
+// ---- a received record (sharded sessions) -> staging row n + p of the means and a class of its own
+__global__ __launch_bounds__(256) void migrate_unpack_split_kernel(const float* __restrict__ in, int total, int n, float* __restrict__ pose,
+                                                                   int64_t pose_ld, float* __restrict__ mean, float* __restrict__ cov,
+                                                                   float* __restrict__ covx, int32_t* __restrict__ cls, int Lp,
+                                                                   int nlandmarks, float q, int first_class, int32_t* __restrict__ live,
+                                                                   int32_t* __restrict__ cnt)
+{
+    const int p = blockIdx.x;
+    if (p >= total) return;
+    const float* __restrict__ rec = in + (int64_t)(3 + 5 * nlandmarks) * p;
+    const int c = first_class + p;
+    if (threadIdx.x < 3) pose[threadIdx.x * pose_ld + n + p] = rec[threadIdx.x];
+    float* m = mean + (int64_t)(n + p) * 2 * Lp;
+    float* cr = cov + (int64_t)c * 3 * Lp;
+    float* xr = covx + (int64_t)c * 2 * Lp;
+    for (int l = threadIdx.x; l < Lp; l += 256) {
+        const bool in_row = l < nlandmarks;
+        m[l] = in_row ? rec[3 + l] : 0.0f;
+        m[Lp + l] = in_row ? rec[3 + nlandmarks + l] : 0.0f;
+        const float pxx = in_row ? rec[3 + 2 * nlandmarks + l] : 1.0f, pxy = in_row ? rec[3 + 3 * nlandmarks + l] : 0.0f,
+                    pyy = in_row ? rec[3 + 4 * nlandmarks + l] : 1.0f;
+        cr[l] = pxx;
+        cr[Lp + l] = pxy;
+        cr[2 * Lp + l] = pyy;
+        float idet = 1.0f, hl = 0.0f;
+        if (in_row && !(pxx < 0.0f)) ekf_det_terms<float>(pxx, pxy, pyy, q, idet, hl);
+        xr[l] = idet;
+        xr[Lp + l] = hl;
+    }
+    if (threadIdx.x == 0) {
+        cls[n + p] = c;
+        live[atomicAdd(cnt, 1)] = c;
+    }
+}
+
 // ---- reset: every landmark of every particle "not seen yet" (P_xx = -1), one class
 __global__ __launch_bounds__(256) void split_reset_kernel(float* __restrict__ mean, float* __restrict__ cov, int32_t* __restrict__ cls,
                                                           int Lp, int n, int32_t* __restrict__ live, int32_t* __restrict__ cnt, int phase,
@@ -262,6 +301,16 @@ hipError_t launch_rows_from_split(hipStream_t stream, const float* mean, const f
 {
     if (count <= 0) return hipSuccess;
     rows_from_split_kernel<<<count, 256, 0, stream>>>(mean, cov, cls, Lp, idx, count, rows, row_stride, plane_stride, nlandmarks);
+    return hipGetLastError();
+}
+
+hipError_t launch_migrate_unpack_split(hipStream_t stream, const float* in, int total, int n, float* pose, int64_t pose_ld, float* mean,
+                                       float* cov, float* covx, int32_t* cls, int Lp, int nlandmarks, float meas_var, int first_class,
+                                       int32_t* live, int32_t* cnt)
+{
+    if (total <= 0) return hipSuccess;
+    migrate_unpack_split_kernel<<<total, 256, 0, stream>>>(in, total, n, pose, pose_ld, mean, cov, covx, cls, Lp, nlandmarks, meas_var,
+                                                          first_class, live, cnt);
     return hipGetLastError();
 }
 

@@ -200,15 +200,52 @@ def test_split_map_io_and_views():
     m = ses.maps()
     assert bool((m[:, 2] == -1).all()) and bool((m[:, [0, 1, 3, 4]] == 0).all())
     ses.close()
-    with pytest.raises(pkg.SlamError):                                          # classes are local to a GPU
-        grp = pkg.LocalGroup(1)
-        comm = pkg.Comm.local(eng, grp, 0)
-        try:
-            pkg.PfSession(eng, 512, 40, comm=comm, map_layout="split")
-        finally:
-            comm.close()
-            grp.close()
     eng.close()
+
+
+@pytest.mark.parametrize("world,n_total,L,recv_capacity,frames", [(2, 4096, 6, 0, 12), (3, 3000, 40, 0, 12), (4, 8192, 130, 0, 12),
+                                                                  (8, 32768, 40, 0, 12), (4, 4096, 70, -600, 30)])
+def test_sharded_split_ranks_on_one_card_equal_one_rank_on_rows(world, n_total, L, recv_capacity, frames, monkeypatch):
+    """A sharded session on the split layout: covariance classes are local to a rank, a migrating particle travels as the same
+    record as on rows (its means and its class's covariances) and becomes a class of its own where it arrives.  2 / 3 / 4 / 8
+    ranks sharing this card against ONE rank on rows: poses, maps, heaviest particle, bit for bit.  The last case gives the
+    ranks fewer spare class numbers (600, SLAM_SPLIT_CLASS_ROOM) than rows arrive over the run, so the classes are renumbered on
+    the way."""
+    from test_gpu_configs import _run_c_session_ranks
+
+    if recv_capacity < 0:
+        monkeypatch.setenv("SLAM_SPLIT_CLASS_ROOM", str(-recv_capacity))
+        room, recv_capacity = -recv_capacity, 0
+    else:
+        room = 0
+    one = _run_c_session_ranks(1, n_total, L, frames, transport=None)[0]
+    many = _run_c_session_ranks(world, n_total, L, frames, layout="split", recv_capacity=recv_capacity)
+    assert all(set(p["layouts"]) == {"split"} for p in many)
+    assert sum(sum(p["rows"]) for p in many) > 0, "nothing migrated"
+    assert np.array_equal(bits(np.concatenate([p["pose"] for p in many], axis=1)), bits(one["pose"]))
+    assert np.array_equal(bits(np.concatenate([p["map"] for p in many], axis=0)), bits(one["map"]))
+    for p in many:
+        assert p["best"][2] == one["best"][2] and p["best"][1] == one["best"][1]
+        assert np.array_equal(bits(p["best"][0]), bits(one["best"][0]))
+    if room:   # more rows arrived than a rank has spare class numbers: it must have renumbered on the way
+        assert max(sum(p["rows"]) for p in many) > room, [sum(p["rows"]) for p in many]
+
+
+def test_sharded_auto_is_split_and_sharded_split_with_map_reads():
+    """AUTO keeps the ranks of a sharded session on the split layout too; a map getter between two frames completes the
+    exchange early, after which a move of the maps has to take the staging tail along (rows <-> split through the same
+    conversions as one GPU)."""
+    from test_gpu_configs import _run_c_session_ranks
+
+    n_total, L, frames, world = 3072, 100, 14, 3
+    ref = _run_c_session_ranks(1, n_total, L, frames, transport=None, maps_every_frame=True)[0]
+    many = _run_c_session_ranks(world, n_total, L, frames, layout="auto", maps_every_frame=True)
+    assert all(set(p["layouts"]) == {"split"} for p in many), [p["layouts"] for p in many]
+    assert np.array_equal(bits(np.concatenate([p["pose"] for p in many], axis=1)), bits(ref["pose"]))
+    assert np.array_equal(bits(np.concatenate([p["map"] for p in many], axis=0)), bits(ref["map"]))
+    for f in range(frames):
+        got = np.concatenate([p["frame_maps"][f] for p in many], axis=0)
+        assert np.array_equal(bits(got), bits(ref["frame_maps"][f])), f
 
 
 def test_auto_moves_between_split_and_pages_and_keeps_the_bits():
