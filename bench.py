@@ -385,7 +385,7 @@ class SingleCtx:
         self.dist = None
 
     def init(self, torch, dev):
-        if self.world > 1:
+        if self.world > 1 and self.dist is None:   # (a second leg of the same process keeps the process group)
             import torch.distributed as dist
 
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -502,7 +502,8 @@ def obs_tables(torch, frames, L, dev):
     return torch.from_numpy(tab).to(dev)
 
 
-def run_rank(args, ctx, inp):
+def run_rank(args, ctx, inp, last=True):
+    """last = False: another leg follows in this process (the rendezvous of the ranks stays up)."""
     import torch
 
     from __graft_entry__ import load_package
@@ -744,7 +745,7 @@ def run_rank(args, ctx, inp):
     elif fused_n > forms[1] // 2:
         ekf_name = "frame_front_kernel"   # motion + score and the grouped landmark update in one launch
     else:
-        ekf_name = "ekf_update_group_kernel" if forms[1] > forms[0] else "ekf_update_kernel"
+        ekf_name = "ekf_split_kernel" if split_in_region else ("ekf_update_group_kernel" if forms[1] > forms[0] else "ekf_update_kernel")
     if ekf_n and (ekf_ms / ekf_n >= score_ms / max(score_n, 1) or args.mode == "ekf"):
         kern, raw_ms, dur_ms, alg = ekf_name, ekf_ms / ekf_n, kernel_ms(ekf_ms, ekf_n), ekf_bytes
     else:
@@ -766,7 +767,7 @@ def run_rank(args, ctx, inp):
     # update out of L2, read and rewritten once by cov_update_kernel).  A static PMC record that is far off this model was
     # taken on another filter state (or another kernel) and is flagged.
     traffic_model = None
-    if args.mode == "pf" and L and not paged_in_region and distinct_frac is not None and kern.startswith(("frame_front", "ekf_update")):
+    if args.mode == "pf" and L and not paged_in_region and distinct_frac is not None and kern.startswith(("frame_front", "ekf_update", "ekf_split")):
         per = 8 if split_in_region else 20
         written = per * n * Lp
         read = distinct_frac * per * n * Lp + (24 * Lp * classes_in_use if split_in_region else 0)
@@ -784,7 +785,7 @@ def run_rank(args, ctx, inp):
         achieved, a_kernel = traffic_model["bytes"] / (dur_ms * 1e-3) / 1e9, kern
         basis = ("traffic model of this run (no PMC record for this workload and kernel): " + traffic_model["basis"]
                  + " / this run's launch time")
-    elif (kern.startswith("ekf_update") or kern.startswith("frame_front")) and no_reuse and args.mode == "pf":
+    elif kern.startswith(("ekf_update", "ekf_split", "frame_front")) and no_reuse and args.mode == "pf":
         achieved, a_kernel = no_reuse["achieved"], no_reuse["kernel"]
         basis = "no_reuse sweep (no PMC record for this workload and kernel): HBM bytes of a launch without shared rows / its launch time"
     else:
@@ -879,7 +880,8 @@ def run_rank(args, ctx, inp):
     elif rank == 0:
         out["cpu_baseline"] = None
     torch.cuda.synchronize()
-    ctx.finish()
+    if last:
+        ctx.finish()
     eng.close()
     if legs_ok and args.mode == "pf" and not args.no_extra_legs and not args.force_collectives:
         out["sharded_rehearsal_2_ranks_one_card"] = sharded_rehearsal(args)
@@ -1050,6 +1052,38 @@ def extra_legs(args, torch, pkg, eng, dev, inp, kernel_ms):
     return res
 
 
+def wants_strong_leg(args):
+    """The north star's scaling target (>= 6x at 8 GPUs against 1) is defined on ONE problem, 1 048 576 particles x 1 000
+    landmarks, split over the ranks — not on the weak-scaling headline.  A default run (the driver's `bench.py --gpus N`)
+    therefore measures that problem too, as a second leg at every N, 1 included: the curve falls out of the legs' values."""
+    return (args.mode == "pf" and args.scaling == "weak" and not args.no_extra_legs and not args.force_collectives and args.ess == 0.0
+            and args.observed == 0 and (args.particles, args.landmarks, args.beams, args.grid) == (65536, 500, 360, 1024)
+            and 1048576 % args.gpus == 0)
+
+
+def strong_leg(args, ctx):
+    """The second leg: `--scaling strong --particles-total 1048576 --landmarks 1000` on the same ranks."""
+    import copy
+
+    a = copy.copy(args)
+    a.scaling, a.particles_total, a.particles, a.landmarks = "strong", 1048576, 1048576 // args.gpus, 1000
+    a.steps, a.warmup, a.preroll = min(args.steps, 30), 5, 30
+    a.no_extra_legs = a.no_cpu_baseline = a.no_sweep = True
+    a.event_every = 2
+    r = run_rank(a, ctx, build_inputs(a))
+    if r is None:
+        return None
+    keep = {k: r[k] for k in ("value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "scaling", "stage_avg_ms")}
+    keep["what"] = ("the north-star problem, 1 048 576 particles x 1 000 landmarks (all observed), 360 beams, 1024^2 EDT, split over the "
+                    "ranks: whole frames on the C session after 30 pre-roll + 5 warm-up frames; speed-up at N GPUs = this value at N / "
+                    "this value at 1")
+    keep["particles_per_gpu"] = r["config"]["particles_per_gpu"]
+    keep["map_layout"] = r["config"]["map_layout"]["in_timed_region"]
+    keep["rows_received_per_frame_max_rank"] = r["config"]["rows_received_per_frame_max_rank"]
+    keep["dominant_kernel"] = {k: r["roofline"][k] for k in ("kernel", "avg_launch_ms", "launches", "traffic_model")}
+    return keep
+
+
 # ------------------------------------------------------------------------------------------------ launching
 def free_port():
     with socket.socket() as s:
@@ -1152,7 +1186,12 @@ def main():
 
         def work(r):
             try:
-                results[r] = run_rank(args, ThreadCtx(args, r, shared), inp)
+                tctx = ThreadCtx(args, r, shared)
+                results[r] = run_rank(args, tctx, inp, last=not wants_strong_leg(args))
+                if wants_strong_leg(args):
+                    leg = strong_leg(args, tctx)
+                    if r == 0:
+                        results[0]["north_star_strong"] = leg
             except BaseException as ex:   # a rank that dies must not leave the others inside a rendezvous
                 errors.append((r, ex))
                 shared.bar.abort()
@@ -1173,7 +1212,16 @@ def main():
     ctx = SingleCtx(args)
     if ctx.world != args.gpus:
         sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={ctx.world}")
-    out = run_rank(args, ctx, build_inputs(args))
+    out = run_rank(args, ctx, build_inputs(args), last=not wants_strong_leg(args))
+    if wants_strong_leg(args):
+        try:
+            leg = strong_leg(args, ctx)
+        except Exception as ex:   # (single rank: a leg that fails must not cost the headline line)
+            if ctx.world > 1:
+                raise
+            leg = {"error": f"{type(ex).__name__}: {ex}"}
+        if ctx.rank == 0:
+            out["north_star_strong"] = leg
     if ctx.rank == 0:
         print(json.dumps(out))
 

@@ -389,3 +389,88 @@ def test_ess_gated_sharded_session_equals_one_rank(orc, world, L):
     for p in many:
         assert p["resampled"] == one["resampled"] and 0 < p["resampled"] < frames - 1
         assert p["best"][2] == one["best"][2]
+
+
+def test_north_star_split_8_ranks_x_131072_x_1000_on_one_card():
+    """The north-star problem as the eight-way shard it is meant to run as — 8 ranks x 131 072 particles x 1 000 landmarks —
+    rehearsed on ONE card (in-process transport: the whole sharded C session, every exchange step, except RCCL itself) against
+    the same 1 048 576 particles on one rank: poses of every slot, maps of 4 096 sampled slots and the heaviest particle, bit
+    for bit, after 3 frames.  NOT a scaling figure (the ranks share a GPU), and no scaling curve exists yet: RCCL with more than
+    one rank has never run (single-GPU boxes)."""
+    import threading
+
+    import _shard_worker as W
+
+    pkg = load_package()
+    world, n, L, frames = 8, 131072, 1000, 3
+    n_total, Lp = world * n, 1024
+    meta, edt, bx, by, lm = W.make_world(L=L)
+    d_edt = torch.from_numpy(edt).to(DEV)
+    gm = pkg.grid_meta(meta.rows, meta.cols, meta.ld, meta.pixel, meta.min_x, meta.min_y)
+    rng = np.random.default_rng(8)
+    x, y, th = ((s * rng.standard_normal(n_total)).astype(np.float32) for s in (0.3, 0.3, 0.05))
+    g = torch.Generator(device=DEV).manual_seed(8)
+    d_lm = torch.from_numpy(lm).to(DEV)
+    m0 = torch.zeros((n_total, 5, Lp), device=DEV)
+    for i0 in range(0, n_total, 65536):           # means near the landmarks; covariances shared by runs of 512 particles
+        m0[i0:i0 + 65536, 0, :L] = d_lm[:, 0] + 0.1 * torch.randn((65536, L), device=DEV, generator=g)
+        m0[i0:i0 + 65536, 1, :L] = d_lm[:, 1] + 0.1 * torch.randn((65536, L), device=DEV, generator=g)
+        for j0 in range(i0, i0 + 65536, 512):
+            a = 0.02 + 0.1 * torch.rand((3, L), device=DEV, generator=g)
+            m0[j0:j0 + 512, 2, :L], m0[j0:j0 + 512, 4, :L] = a[0], a[1]
+            m0[j0:j0 + 512, 3, :L] = (a[2] - 0.07) * 0.3
+    m0[:, 2, 7:L:13] = -1.0                        # some landmarks nobody has seen yet
+    torch.cuda.synchronize()
+    sel = np.unique(np.concatenate([rng.integers(0, n_total, 4096), [0, n - 1, n, n_total - 1]])).astype(np.int64)
+    obs = [(np.arange(L, dtype=np.int32), (lm[:, 0] + 0.01 * f).astype(np.float32), (lm[:, 1] - 0.01 * f).astype(np.float32))
+           for f in range(frames)]
+
+    def run(rank, world_, group, out):
+        eng = pkg.Engine(0)
+        eng.grid_set_dev(0, d_edt, gm)
+        eng.scan_upload(bx, by)
+        comm = pkg.Comm.local(eng, group, rank) if group else None
+        k = n_total // world_
+        ses = pkg.PfSession(eng, k, L, seed=77, sigma=(0.02, 0.02, 0.004), meas_var=0.02, score_gain=0.05, comm=comm)
+        sl = slice(rank * k, (rank + 1) * k)
+        ses.set_poses(x[sl], y[sl], th[sl])
+        ses.set_map_dev(m0[sl], 5 * Lp, Lp)
+        eng.sync()
+        for f in range(frames):
+            eng.obs_upload(*obs[f], L)
+            ses.step(0, [0.01, -0.005, 0.002], True)
+        mine = sel[(sel >= rank * k) & (sel < (rank + 1) * k)] - rank * k
+        out[rank] = {"pose": ses.poses(), "maps": ses.map_rows(mine.astype(np.int32)), "best": ses.best(), "layout": ses.layout(),
+                     "rows": ses.rows_received()}
+        ses.close()
+        if comm:
+            comm.close()
+        eng.close()
+
+    one = [None]
+    run(0, 1, None, one)
+    torch.cuda.empty_cache()
+    group = pkg.LocalGroup(world)
+    many, errors = [None] * world, []
+
+    def guarded(r):
+        try:
+            run(r, world, group, many)
+        except BaseException as exc:   # noqa: BLE001
+            errors.append(exc)
+
+    ths = [threading.Thread(target=guarded, args=(r,)) for r in range(world)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    group.close()
+    del m0
+    torch.cuda.empty_cache()
+    if errors:
+        raise errors[0]
+    assert one[0]["layout"] == "split" and all(p["layout"] == "split" for p in many)
+    assert np.array_equal(bits(np.concatenate([p["pose"] for p in many], axis=1)), bits(one[0]["pose"]))
+    assert np.array_equal(bits(np.concatenate([p["maps"] for p in many], axis=0)), bits(one[0]["maps"]))
+    for p in many:
+        assert p["best"][2] == one[0]["best"][2] and np.array_equal(bits(p["best"][0]), bits(one[0]["best"][0]))
