@@ -225,8 +225,8 @@ class Engine:
         self._ck(self.lib.slam_engine_sync(self.h), "sync")
 
     PROF_SCORE, PROF_EDT, PROF_EKF, PROF_WEIGHTS, PROF_SCAN, PROF_ANCESTORS, PROF_PLAN, PROF_PACK, PROF_UNPACK = range(9)
-    PROF_COLLECTIVES, PROF_PAGES, PROF_COUNT = 9, 10, 11
-    PROF_NAMES = ("score", "edt", "ekf", "weights", "scan", "ancestors", "plan", "pack", "unpack", "collectives", "pages")
+    PROF_COLLECTIVES, PROF_PAGES, PROF_EKF_TAIL, PROF_COUNT = 9, 10, 11, 12
+    PROF_NAMES = ("score", "edt", "ekf", "weights", "scan", "ancestors", "plan", "pack", "unpack", "collectives", "pages", "ekf_tail")
 
     def profile_enable(self, *kernels):
         """profile_enable(PROF_EKF, ...) times those kernels; profile_enable() switches timing off."""

@@ -869,7 +869,7 @@ int slam_frame_front_dev(slam_engine* e, int slot, const float* d_src_x, const f
     a.x = d_x;   // not read by the fused launch: the update works out its motion samples itself
     a.y = d_y;
     a.th = d_th;
-    a.anc = d_anc;
+    a.anc = split && split->map_anc ? split->map_anc : d_anc;
     a.n = n;
     a.obs_zx = e->d_obs_zx;
     a.obs_zy = e->d_obs_zy;
@@ -878,6 +878,7 @@ int slam_frame_front_dev(slam_engine* e, int slot, const float* d_src_x, const f
     a.loglik_user = nullptr;
     a.xcd_chunk = 0;
     if (split) {
+        a.group_filter = split->group_filter;
         a.cov = split->cov;
         a.cov_stride = split->cov_stride;
         a.covx = split->covx;
@@ -932,6 +933,7 @@ int slam_ekf_split_dev(slam_engine* e, const float* d_mean_in, float* d_mean_out
     a.loglik = e->ll_buf.as<float>();
     a.loglik_user = nullptr;
     a.xcd_chunk = 0;
+    a.group_filter = split->group_filter;
     a.cov = split->cov;
     a.cov_stride = split->cov_stride;
     a.covx = split->covx;
@@ -941,8 +943,8 @@ int slam_ekf_split_dev(slam_engine* e, const float* d_mean_in, float* d_mean_out
     a.cstamp = split->cstamp;
     a.stamp_now = split->stamp_now;
     const int group = e->ekf_group_size(n, d_anc != nullptr, plane_stride, false, true);
-    HIP_TRY(launch_ekf_update(e->stream, a, e->prof_next(SLAM_PROF_EKF), group));
-    e->ekf_form_launches[1]++;
+    HIP_TRY(launch_ekf_update(e->stream, a, e->prof_next(split->group_filter == 2 ? SLAM_PROF_EKF_TAIL : SLAM_PROF_EKF), group));
+    if (split->group_filter != 2) e->ekf_form_launches[1]++;
     e->ll_n = n;
     return SLAM_OK;
 }

@@ -115,9 +115,18 @@ struct EkfArgs {
     int32_t* cls_out = nullptr;       // class of every particle of this frame
     uint32_t* cstamp = nullptr;       // [classes]: stamp_now = "a particle of this frame belongs to the class"
     uint32_t stamp_now = 0;
+    // Sharded sessions, split layout: a frame's update in two launches.  Source rows below n are this rank's own particles;
+    // rows from n on are the staging tail, filled by the exchange of the frame.  group_filter 1: only the groups (the particles
+    // of one wavefront) whose sources are ALL local — they need nothing from the exchange and go out with the score, in the
+    // fused front launch, before the host has even looked at the exchange plan; 2: only the other groups, behind the unpack.
+    // 0: every group.
+    int group_filter = 0;
 };
 // the split layout's part of EkfArgs, as the session hands it to the engine's stage functions
 struct SplitIO {
+    int group_filter;          // EkfArgs::group_filter
+    const int32_t* map_anc;    // the gather index of the MAPS when it is not the scorer's pose index (sharded: poses come out of
+                               // the all-gathered array of every rank, maps out of the local rows + staging tail); nullptr: the same
     const float* cov;
     int64_t cov_stride;
     const float* covx;
@@ -185,9 +194,19 @@ hipError_t launch_rows_from_split(hipStream_t stream, const float* mean, const f
 // (pose, then five planes of nlandmarks values): launch_migrate_pack(.., split_cov, split_cls) reads it from the means and the
 // class's covariance row, and this launch puts record p of `in` into staging row n + p of the means, with a class of its own —
 // first_class + p, covariance planes and determinant terms filled in, appended to the list of classes in use (live[*cnt ..)).
+// Class numbers for the arrivals come from a free list on the device: the classes no current particle belongs to, i.e. whose
+// stamp is older than `min_live` — the stamp of the last update whose particles are the current ones.  At most n classes are in
+// use and there are n + staging rows of them, so a list made anew holds at least as many numbers as a rank has staging rows,
+// whatever else it holds: the HOST hands them out (entries [first, first + total) of the list go to this launch) and asks for
+// a new list (launch_class_free_list, in front of the unpack) when the guaranteed part of the old one is used up.
+//   fs: two int32 words on the device, zero before the first launch and zero again behind every launch.
+hipError_t launch_class_free_list(hipStream_t stream, const uint32_t* cstamp, int nclasses, uint32_t min_live, int32_t* freelist,
+                                  int32_t* fs);
+// the arrivals' classes are stamped `stamp` (= min_live: in use until the next update has said which of them have offspring)
 hipError_t launch_migrate_unpack_split(hipStream_t stream, const float* in, int total, int n, float* pose, int64_t pose_ld, float* mean,
-                                       float* cov, float* covx, int32_t* cls, int Lp, int nlandmarks, float meas_var, int first_class,
-                                       int32_t* live, int32_t* cnt);
+                                       float* cov, float* covx, int32_t* cls, int Lp, int nlandmarks, float meas_var,
+                                       const int32_t* freelist, int first, uint32_t* cstamp, uint32_t stamp, int32_t* live,
+                                       int32_t* cnt);
 // a frame without a landmark update: means and classes follow their particles (out[i] = in[anc[i]])
 hipError_t launch_split_gather(hipStream_t stream, const float* mean_in, float* mean_out, const int32_t* cls_in, int32_t* cls_out,
                                int Lp, const int32_t* anc, int n, uint32_t* cstamp, uint32_t stamp_now);

@@ -602,11 +602,18 @@ __device__ __forceinline__ void ekf_split_body(const EkfArgs& a, int bid, float 
     // lane k prepares particle g0 + k: source row, class, pose; read back with v_readlane below
     const int mine = g0 + ((int)lane < nslots ? (int)lane : 0);
     const int src_l = a.anc ? a.anc[mine] : mine;
+    if (a.group_filter) {   // sharded: this launch takes the groups fed from local rows only (1) or the others (2)
+        const bool remote = __ballot(src_l >= a.n) != 0;
+        if (remote != (a.group_filter == 2)) return;
+    }
     const int cls_l = a.cls_in[src_l];
     float st_l, ct_l, px_l, py_l;
     if constexpr (OWN_MOTION) {
+        // the ancestor's POSE comes through the scorer's index (a sharded session reads it out of the all-gathered poses of
+        // every rank; on one GPU the two indices are the same array)
+        const int psrc = mio.anc ? mio.anc[mine] : mine;
         float th_l;
-        motion_sample_one(mpar, (uint64_t)mine, mio.sx[src_l], mio.sy[src_l], mio.sth[src_l], px_l, py_l, th_l);
+        motion_sample_one(mpar, (uint64_t)mine, mio.sx[psrc], mio.sy[psrc], mio.sth[psrc], px_l, py_l, th_l);
         det_sincosf(th_l, st_l, ct_l);
     } else {
         det_sincosf(a.th[mine], st_l, ct_l);

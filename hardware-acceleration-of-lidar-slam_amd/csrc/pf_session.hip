@@ -89,9 +89,11 @@ struct slam_pf {
     uint32_t* cstamp = nullptr;     // [cap]
     uint32_t cstamp_now = 0, cls_epoch = 0;
     int live_cur = 0, cov_phase = 0;
-    // sharded: a row that arrives from another rank gets a class of its own, numbered from next_cls on (the classes made when
-    // maps came in are numbered below it); when the numbers run out the classes are renumbered (one pass over the maps)
-    int next_cls = 0;
+    // sharded: a row that arrives from another rank gets a class of its own; the numbers come from a free list on the device
+    // (split_kernels.hip: class_free_list_kernel), handed out by the host: a fresh list holds at least recv_cap numbers
+    int32_t* cls_free = nullptr;    // [cap]
+    int32_t* cls_fs = nullptr;      // two words of the list kernel's bookkeeping
+    int64_t cls_cursor = 0;         // entries of the current list handed out so far (beyond its guaranteed length: make a new one)
     uint32_t cls_appended = 0;      // classes appended to the list so far in this epoch (what cov_update_kernel's `mark` carries)
     void* split_scratch = nullptr;  // flags, prefix sums of a rows -> split move
     bool gated = false;             // cfg.resample_ess_frac in (0, 1): a frame resamples only when its ESS is low
@@ -174,21 +176,21 @@ int migrate(slam_pf* pf)
             return rc;
     if (int rc = comm_all_to_all_f32(pf->comm, pf->sbuf, sfl, pf->rbuf, rfl)) return rc;
     if (rtot && split) {
-        // every received row becomes a class of its own (it brings its covariances along); when the numbers run out, the
-        // classes are renumbered from 0 by moving the maps to rows and back: one pass each way, every cap - n received rows
-        // (SLAM_SPLIT_CLASS_ROOM: tests make the numbers run out early)
+        // every received row becomes a class of its own (it brings its covariances along); its number comes from the free list
+        // of classes on the device, made anew from the stamps when its guaranteed length — a rank's staging rows: at most n
+        // classes are in use — is used up (SLAM_SPLIT_CLASS_ROOM: tests make the lists short)
         const char* room_env = getenv("SLAM_SPLIT_CLASS_ROOM");
-        const int64_t last = room_env && atoi(room_env) > 0 && pf->n + (int64_t)atoi(room_env) < pf->cap ? pf->n + (int64_t)atoi(room_env) : pf->cap;
-        if (pf->next_cls + rtot > last && rtot <= last - pf->n) {
-            if (int rc = convert_split_to_rows(pf)) return rc;
-            if (int rc = convert_rows_to_split(pf)) return rc;
-            pf->conversions -= 2;   // (not a change of layout)
-        }
+        const int64_t room = room_env && atoi(room_env) > 0 && atoi(room_env) < pf->recv_cap ? atoi(room_env) : pf->recv_cap;
         const ProfScope prof(e, SLAM_PROF_UNPACK);
+        if (pf->cls_cursor + rtot > room) {
+            SLAM_HIP_TRY(e, launch_class_free_list(e->stream, pf->cstamp, pf->cap, pf->cstamp_now, pf->cls_free, pf->cls_fs));
+            pf->cls_cursor = 0;
+        }
         SLAM_HIP_TRY(e, launch_migrate_unpack_split(e->stream, pf->rbuf, (int)rtot, n, pf->pose_stage, pf->cap, pf->mean[pf->sp_cur], pf->cov,
-                                                    pf->covx, pf->cls[pf->sp_cur], pf->Lp, L, pf->cfg.meas_var, pf->next_cls,
-                                                    pf->live[pf->live_cur], pf->cov_cnt + pf->cov_phase));
-        pf->next_cls += (int)rtot;
+                                                    pf->covx, pf->cls[pf->sp_cur], pf->Lp, L, pf->cfg.meas_var, pf->cls_free,
+                                                    (int)pf->cls_cursor, pf->cstamp, pf->cstamp_now, pf->live[pf->live_cur],
+                                                    pf->cov_cnt + pf->cov_phase));
+        pf->cls_cursor += rtot;
         pf->cls_appended += (uint32_t)rtot;
     } else if (rtot && pf->paged) {
         // fresh pages for the received rows (a new free list first if the old one runs short), table rows n .. n + rtot - 1
@@ -371,7 +373,7 @@ int convert_to_rows(slam_pf* pf)
 void free_split_tables(slam_pf* pf)
 {
     for (void** p : { (void**)&pf->cls[0], (void**)&pf->cls[1], (void**)&pf->live[0], (void**)&pf->live[1], (void**)&pf->cov_cnt,
-                      (void**)&pf->cstamp, &pf->split_scratch }) {
+                      (void**)&pf->cstamp, &pf->split_scratch, (void**)&pf->cls_free, (void**)&pf->cls_fs }) {
         if (*p) (void)hipFree(*p);
         *p = nullptr;
     }
@@ -385,7 +387,9 @@ bool alloc_split_tables(slam_pf* pf)
         ok = ok && dev_alloc((void**)&pf->cls[b], cap * 4) == hipSuccess && dev_alloc((void**)&pf->live[b], cap * 4) == hipSuccess;
     ok = ok && dev_alloc((void**)&pf->cov_cnt, 16) == hipSuccess && hipMemset(pf->cov_cnt, 0, 16) == hipSuccess &&
          dev_alloc((void**)&pf->cstamp, cap * 4) == hipSuccess && hipMemset(pf->cstamp, 0, cap * 4) == hipSuccess &&
-         dev_alloc(&pf->split_scratch, split_scratch_words(pf->cap) * 4) == hipSuccess;
+         dev_alloc(&pf->split_scratch, split_scratch_words(pf->cap) * 4) == hipSuccess &&
+         dev_alloc((void**)&pf->cls_fs, 8) == hipSuccess && hipMemset(pf->cls_fs, 0, 8) == hipSuccess &&
+         (!pf->comm || dev_alloc((void**)&pf->cls_free, cap * 4) == hipSuccess);
     if (!ok) {
         (void)hipGetLastError();
         free_split_tables(pf);
@@ -407,21 +411,21 @@ void place_split(slam_pf* pf, int base)
 int32_t* split_h_live(slam_pf* pf) { return reinterpret_cast<int32_t*>(pf->d_hres) + 22; }   // {classes in use, epoch}
 
 // a new set of classes is about to be made (set_map, reset, rows -> split): lists and counters start afresh
-void split_new_epoch(slam_pf* pf, int nrows)
+void split_new_epoch(slam_pf* pf)
 {
     pf->cls_epoch++;
     pf->cstamp_now++;
     pf->live_cur = 0;
     pf->cov_phase = 0;
-    pf->next_cls = nrows;   // the classes of an epoch's start are numbered 0 .. (at most) nrows - 1
     pf->cls_appended = 0;
+    pf->cls_cursor = (int64_t)1 << 40;   // no list of free class numbers yet: the first arrivals make one
 }
 
 // nrows rows (as given, any strides) -> means + classes + class rows in the buffers of the current placement
 int split_from_rows(slam_pf* pf, const float* d_rows, int64_t row_stride, int plane_stride, int nrows)
 {
     slam_engine* e = pf->e;
-    split_new_epoch(pf, nrows);
+    split_new_epoch(pf);
     SLAM_HIP_TRY(e, launch_split_from_rows(e->stream, d_rows, row_stride, plane_stride, pf->L, nrows, pf->Lp, pf->mean[pf->sp_cur], pf->cov,
                                            pf->covx, pf->cfg.meas_var, pf->cls[pf->sp_cur], pf->live[0], pf->cov_cnt, 0, pf->cstamp,
                                            pf->cstamp_now, split_h_live(pf), pf->cls_epoch, pf->split_scratch));
@@ -668,7 +672,7 @@ int slam_pf_reset(slam_pf* pf, const float pose[3])
     if (int rc = slam_engine_sync(pf->e)) return rc;
     if (hipMemcpy(pf->pose[pf->cur], h.data(), 3 * n * 4, hipMemcpyHostToDevice) != hipSuccess) return SLAM_ERR_HIP;
     if (pf->split) {   // every landmark of every particle "not seen yet": one class
-        split_new_epoch(pf, pf->n);
+        split_new_epoch(pf);
         SLAM_HIP_TRY(pf->e, launch_split_reset(pf->e->stream, pf->mean[pf->sp_cur], pf->cov, pf->covx, pf->cls[pf->sp_cur], pf->Lp, pf->n,
                                                pf->live[0], pf->cov_cnt, 0, pf->cstamp, pf->cstamp_now, split_h_live(pf), pf->cls_epoch));
         if (int rc = slam_engine_sync(pf->e)) return rc;
@@ -750,6 +754,47 @@ int slam_pf_set_map_dev(slam_pf* pf, const float* d_rows, int64_t row_stride, in
 
 int slam_pf_is_paged(const slam_pf* pf) { return pf && pf->paged ? 1 : 0; }
 
+// The classes' update of a frame (cov_update_kernel), in place, once per class still in use; nlandmarks = 0: only the list of
+// classes in use is brought up to date (a frame without observations).  The launch is as wide as the host knows the list to
+// be at most: its length as of some earlier launch (mapped memory, read without waiting) plus the classes that arrived since
+// (sharded sessions) — the second word is the running count of arrivals as of that launch; it is read FIRST and written
+// last, so a torn pair only over-estimates; before anything of this epoch has arrived: every class there can be.
+static int split_class_update(slam_pf* pf, int nlandmarks)
+{
+    slam_engine* e = pf->e;
+    const int32_t* hw = reinterpret_cast<const int32_t*>(pf->h_res);   // words 22-23: {count, epoch}; 18-19: {mark, epoch}
+    const uint64_t hm = __atomic_load_n(reinterpret_cast<const uint64_t*>(hw + 18), __ATOMIC_ACQUIRE),
+                   hl = __atomic_load_n(reinterpret_cast<const uint64_t*>(hw + 22), __ATOMIC_ACQUIRE);
+    const bool fresh = (uint32_t)(hl >> 32) == pf->cls_epoch && (uint32_t)hl > 0;
+    const uint32_t mark = (uint32_t)(hm >> 32) == pf->cls_epoch ? (uint32_t)hm : 0u;   // (no launch of this epoch has said yet: 0)
+    const int64_t upper = fresh ? (int64_t)(uint32_t)hl + (int64_t)(pf->cls_appended - mark) : (int64_t)pf->cap;
+    const int bound = upper < pf->cap ? (int)upper : pf->cap;
+    CovArgs ca;
+    ca.cov = pf->cov;
+    ca.cov_stride = 3 * (int64_t)pf->Lp;
+    ca.covx = pf->covx;
+    ca.covx_stride = 2 * (int64_t)pf->Lp;
+    ca.plane_stride = pf->Lp;
+    ca.nlandmarks = nlandmarks;
+    ca.obs_zx = e->d_obs_zx;
+    ca.obs_zy = e->d_obs_zy;
+    ca.meas_var = pf->cfg.meas_var;
+    ca.live_in = pf->live[pf->live_cur];
+    ca.live_out = pf->live[1 - pf->live_cur];
+    ca.cnt = pf->cov_cnt;
+    ca.phase = pf->cov_phase;
+    ca.cstamp = pf->cstamp;
+    ca.stamp_now = pf->cstamp_now;
+    ca.h_live = split_h_live(pf);
+    ca.h_mark = reinterpret_cast<int32_t*>(pf->d_hres) + 18;
+    ca.epoch = pf->cls_epoch;
+    ca.mark = pf->cls_appended;
+    SLAM_HIP_TRY(e, launch_cov_update(e->stream, ca, bound, e->prof_next(SLAM_PROF_PAGES)));
+    pf->live_cur = 1 - pf->live_cur;
+    pf->cov_phase = (pf->cov_phase + 1) % 3;
+    return SLAM_OK;
+}
+
 static int pf_step_impl(slam_pf* pf, int slot, const float dp[3], int use_observations, bool* collective_verdict);
 
 int slam_pf_step(slam_pf* pf, int slot, const float dp[3], int use_observations)
@@ -792,6 +837,8 @@ static int pf_step_impl(slam_pf* pf, int slot, const float dp[3], int use_observ
     bool fused = false;
     SplitIO sio{};
     auto make_sio = [&]() {   // the classes follow their particles through the update; it stamps the ones still in use
+        sio.group_filter = 0;
+        sio.map_anc = nullptr;
         sio.cov = pf->cov;
         sio.cov_stride = 3 * (int64_t)pf->Lp;
         sio.covx = pf->covx;
@@ -802,6 +849,20 @@ static int pf_step_impl(slam_pf* pf, int slot, const float dp[3], int use_observ
         sio.stamp_now = pf->cstamp_now + 1;
     };
     if (pf->split) make_sio();
+    if (comm && pf->split && pf->has_anc && !pf->gated && anc && L > 0 && use_observations && e->obs_nlandmarks == L) {
+        // Sharded, split maps: the front launch scores every particle (its ancestor's pose comes out of the all-gathered poses)
+        // and updates the groups of particles whose ancestors are all rows of this rank; the groups with an ancestor in the
+        // staging tail follow behind the exchange (below).  Like the motion + score launch it replaces, it needs nothing from
+        // the exchange and goes out before the host has looked at the plan.
+        if ((rc = comm_all_gather_finish(comm)) != SLAM_OK) return rc;
+        const float* pa = pf->pose_all;
+        sio.group_filter = 1;
+        sio.map_anc = anc;
+        rc = slam_frame_front_dev(e, slot, pa, pa + sn, pa + 2 * sn, pf->pose_idx[cur], dst, dst + sn, dst + 2 * sn, n, first_id, dp,
+                                  pf->cfg.sigma, pf->cfg.seed, pf->frame, pf->score, pf->count, pf->mean[pf->sp_cur],
+                                  pf->mean[1 - pf->sp_cur], 2 * (int64_t)pf->Lp, pf->Lp, L, pf->cfg.meas_var, &fused, &sio);
+        if (rc != SLAM_OK) return rc;
+    }
     if (!comm && !pf->paged && !pf->gated && anc && L > 0 && use_observations && e->obs_nlandmarks == L) {
         if (pf->split)
             rc = slam_frame_front_dev(e, slot, src, src + sn, src + 2 * sn, anc, dst, dst + sn, dst + 2 * sn, n, first_id, dp,
@@ -851,53 +912,21 @@ static int pf_step_impl(slam_pf* pf, int slot, const float dp[3], int use_observ
     float* d_max = comm ? pf->d_max : nullptr;
     if (pf->split && L > 0) {
         const int sc = pf->sp_cur;
-        make_sio();   // (again: the exchange above may have renumbered the classes and moved the buffers)
+        make_sio();   // (again: a layout move in front of the frame leaves other buffers than the ones the first look saw)
         if (ekf) {
             if (e->obs_nlandmarks != L) return SLAM_ERR_NOT_READY;
             if (sample_obs) SLAM_HIP_TRY(e, launch_obs_count(e->stream, e->d_obs_zx, e->d_obs_zy, L, d_hobs, ++pf->obs_seq_issued, pf->votes));
             // the particles' update (a frame that kept its population runs it out of place all the same: its gather index is
             // the identity) ...
-            if (!fused)
+            if (fused && comm) sio.group_filter = 2;   // the groups that waited for the exchange
+            if (!fused || comm)
                 if ((rc = slam_ekf_split_dev(e, pf->mean[sc], pf->mean[1 - sc], 2 * (int64_t)pf->Lp, pf->Lp, L, dst, dst + sn, dst + 2 * sn,
                                              anc, n, pf->cfg.meas_var, &sio)) != SLAM_OK)
                     return rc;
             pf->cstamp_now++;
             pf->sp_cur = 1 - sc;
-            // ... then the classes' update, in place, once per class still in use.  The launch is as wide as the host knows the
-            // list to be at most: its length as of some earlier frame (mapped memory, read without waiting; the list only
-            // shrinks), the population before anything of this epoch has arrived.
-            // (sharded: plus the classes that arrived since — the second word is the running count of arrivals as of that
-            // launch; it is read FIRST and written last, so a torn pair only over-estimates)
-            const int32_t* hw = reinterpret_cast<const int32_t*>(pf->h_res);   // words 22-23: {count, epoch}; 18-19: {mark, epoch}
-            const uint64_t hm = __atomic_load_n(reinterpret_cast<const uint64_t*>(hw + 18), __ATOMIC_ACQUIRE),
-                           hl = __atomic_load_n(reinterpret_cast<const uint64_t*>(hw + 22), __ATOMIC_ACQUIRE);
-            const bool fresh = (uint32_t)(hl >> 32) == pf->cls_epoch && (uint32_t)hl > 0;
-            const uint32_t mark = (uint32_t)(hm >> 32) == pf->cls_epoch ? (uint32_t)hm : 0u;   // (no launch of this epoch has said yet: 0)
-            const int64_t upper = fresh ? (int64_t)(uint32_t)hl + (int64_t)(pf->cls_appended - mark) : (int64_t)pf->cap;
-            const int bound = upper < pf->cap ? (int)upper : pf->cap;
-            CovArgs ca;
-            ca.cov = pf->cov;
-            ca.cov_stride = 3 * (int64_t)pf->Lp;
-            ca.covx = pf->covx;
-            ca.covx_stride = 2 * (int64_t)pf->Lp;
-            ca.plane_stride = pf->Lp;
-            ca.nlandmarks = L;
-            ca.obs_zx = e->d_obs_zx;
-            ca.obs_zy = e->d_obs_zy;
-            ca.meas_var = pf->cfg.meas_var;
-            ca.live_in = pf->live[pf->live_cur];
-            ca.live_out = pf->live[1 - pf->live_cur];
-            ca.cnt = pf->cov_cnt;
-            ca.phase = pf->cov_phase;
-            ca.cstamp = pf->cstamp;
-            ca.stamp_now = pf->cstamp_now;
-            ca.h_live = split_h_live(pf);
-            ca.h_mark = reinterpret_cast<int32_t*>(pf->d_hres) + 18;
-            ca.epoch = pf->cls_epoch;
-            ca.mark = pf->cls_appended;
-            SLAM_HIP_TRY(e, launch_cov_update(e->stream, ca, bound, e->prof_next(SLAM_PROF_PAGES)));
-            pf->live_cur = 1 - pf->live_cur;
-            pf->cov_phase = (pf->cov_phase + 1) % 3;
+            // ... then the classes' update, in place, once per class still in use
+            if ((rc = split_class_update(pf, L)) != SLAM_OK) return rc;
             rc = slam_logweight_ekf_dev(e, pf->score, pf->cfg.score_gain, n, pf->logw, d_max);
         } else {
             if (anc) {   // means and classes follow their particles
@@ -905,6 +934,7 @@ static int pf_step_impl(slam_pf* pf, int slot, const float dp[3], int use_observ
                 SLAM_HIP_TRY(e, launch_split_gather(e->stream, pf->mean[sc], pf->mean[1 - sc], pf->cls[sc], pf->cls[1 - sc], pf->Lp, anc, n,
                                                     pf->cstamp, ++pf->cstamp_now));
                 pf->sp_cur = 1 - sc;
+                if ((rc = split_class_update(pf, 0)) != SLAM_OK) return rc;   // no observations: the list of classes in use only
             }
             rc = slam_logweight_dev(e, pf->score, nullptr, pf->cfg.score_gain, n, pf->logw, d_max);
         }

@@ -208,17 +208,41 @@ __global__ __launch_bounds__(256) void split_gather_kernel(const float* __restri
     }
 }
 
+// ---- class numbers for arrivals (sharded sessions): free = every class whose stamp is older than min_live, in no particular
+// order; fs = {fill cursor, ticket}, zero on entry, zeroed again by the last workgroup
+__global__ __launch_bounds__(256) void class_free_list_kernel(const uint32_t* __restrict__ cstamp, int nclasses, uint32_t min_live,
+                                                              int32_t* __restrict__ freelist, int32_t* __restrict__ fs)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    const bool is_free = c < nclasses && cstamp[c] < min_live;
+    const unsigned long long m = __ballot(is_free);
+    const int lane = threadIdx.x & 63;
+    int base = 0;
+    if (lane == 0 && m) base = atomicAdd(&fs[0], __popcll(m));
+    base = __shfl(base, 0);
+    if (is_free) freelist[base + __popcll(m & ((1ull << lane) - 1ull))] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(&fs[1], 1) == (int)gridDim.x - 1) {   // the last workgroup: the list is complete
+            fs[0] = 0;
+            fs[1] = 0;
+        }
+    }
+}
+
 // ---- a received record (sharded sessions) -> staging row n + p of the means and a class of its own
 __global__ __launch_bounds__(256) void migrate_unpack_split_kernel(const float* __restrict__ in, int total, int n, float* __restrict__ pose,
                                                                    int64_t pose_ld, float* __restrict__ mean, float* __restrict__ cov,
                                                                    float* __restrict__ covx, int32_t* __restrict__ cls, int Lp,
-                                                                   int nlandmarks, float q, int first_class, int32_t* __restrict__ live,
-                                                                   int32_t* __restrict__ cnt)
+                                                                   int nlandmarks, float q, const int32_t* __restrict__ freelist,
+                                                                   int first, uint32_t* __restrict__ cstamp, uint32_t stamp,
+                                                                   int32_t* __restrict__ live, int32_t* __restrict__ cnt)
 {
     const int p = blockIdx.x;
     if (p >= total) return;
     const float* __restrict__ rec = in + (int64_t)(3 + 5 * nlandmarks) * p;
-    const int c = first_class + p;
+    const int c = freelist[first + p];
     if (threadIdx.x < 3) pose[threadIdx.x * pose_ld + n + p] = rec[threadIdx.x];
     float* m = mean + (int64_t)(n + p) * 2 * Lp;
     float* cr = cov + (int64_t)c * 3 * Lp;
@@ -239,6 +263,7 @@ __global__ __launch_bounds__(256) void migrate_unpack_split_kernel(const float* 
     }
     if (threadIdx.x == 0) {
         cls[n + p] = c;
+        cstamp[c] = stamp;
         live[atomicAdd(cnt, 1)] = c;
     }
 }
@@ -267,9 +292,11 @@ __global__ __launch_bounds__(256) void split_reset_kernel(float* __restrict__ me
 
 hipError_t launch_cov_update(hipStream_t stream, const CovArgs& a, int bound, const EventPair* ev)
 {
-    if (bound <= 0 || a.nlandmarks <= 0) return hipSuccess;
+    if (bound <= 0) return hipSuccess;
     if (ev) (void)hipEventRecord(ev->start, stream);
-    cov_update_kernel<<<dim3((unsigned)bound, (unsigned)((a.nlandmarks + 255) / 256)), 256, 0, stream>>>(a);
+    // nlandmarks == 0: a frame without observations — only the list is brought up to date (classes whose last particle went
+    // with the frame's gather leave it: a sharded session may hand their numbers out again, and a number must not be listed twice)
+    cov_update_kernel<<<dim3((unsigned)bound, (unsigned)(a.nlandmarks > 0 ? (a.nlandmarks + 255) / 256 : 1)), 256, 0, stream>>>(a);
     if (ev) (void)hipEventRecord(ev->stop, stream);
     return hipGetLastError();
 }
@@ -304,13 +331,21 @@ hipError_t launch_rows_from_split(hipStream_t stream, const float* mean, const f
     return hipGetLastError();
 }
 
+hipError_t launch_class_free_list(hipStream_t stream, const uint32_t* cstamp, int nclasses, uint32_t min_live, int32_t* freelist,
+                                  int32_t* fs)
+{
+    class_free_list_kernel<<<blocks256(nclasses), 256, 0, stream>>>(cstamp, nclasses, min_live, freelist, fs);
+    return hipGetLastError();
+}
+
 hipError_t launch_migrate_unpack_split(hipStream_t stream, const float* in, int total, int n, float* pose, int64_t pose_ld, float* mean,
-                                       float* cov, float* covx, int32_t* cls, int Lp, int nlandmarks, float meas_var, int first_class,
-                                       int32_t* live, int32_t* cnt)
+                                       float* cov, float* covx, int32_t* cls, int Lp, int nlandmarks, float meas_var,
+                                       const int32_t* freelist, int first, uint32_t* cstamp, uint32_t stamp, int32_t* live,
+                                       int32_t* cnt)
 {
     if (total <= 0) return hipSuccess;
     migrate_unpack_split_kernel<<<total, 256, 0, stream>>>(in, total, n, pose, pose_ld, mean, cov, covx, cls, Lp, nlandmarks, meas_var,
-                                                          first_class, live, cnt);
+                                                          freelist, first, cstamp, stamp, live, cnt);
     return hipGetLastError();
 }
 

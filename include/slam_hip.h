@@ -97,8 +97,10 @@ typedef enum {
     SLAM_PROF_PACK = 7,         /* several GPUs: migrating rows into the send buffer */
     SLAM_PROF_UNPACK = 8,       /* several GPUs: received rows into the staging tail */
     SLAM_PROF_COLLECTIVES = 9,  /* every exchange between ranks (all-reduce, all-gathers, send/recv), as the stream sees them */
-    SLAM_PROF_PAGES = 10,       /* paged maps: touched-page list, free list, table gathers */
-    SLAM_PROF_COUNT = 11
+    SLAM_PROF_PAGES = 10,       /* map bookkeeping: paged maps' touched-page list, free list, table gathers; split maps' class update */
+    SLAM_PROF_EKF_TAIL = 11,    /* several GPUs, split maps: the part of the landmark update that waits for the exchange (the
+                                   groups with an ancestor in the staging tail); the rest went out with the score (SLAM_PROF_EKF) */
+    SLAM_PROF_COUNT = 12
 } slam_prof_kernel;
 int slam_profile_enable(slam_engine *e, int mask);
 int slam_profile_read(slam_engine *e, int kernel, double *total_ms, int64_t *launches);

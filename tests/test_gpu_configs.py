@@ -228,7 +228,8 @@ def _run_c_session_ranks(world, n_total, L, frames, transport="local", recv_capa
                 if f % 3 == 1:
                     bests.append(ses.best())                 # collective; must not disturb the pending exchange
             res = {"pose": ses.poses(), "best": ses.best(), "rows": rows, "bests": bests, "resampled": ses.frames_resampled(),
-                   "mean": ses.mean(0.07), "paged_end": ses.is_paged(), "layouts": layouts, "frame_maps": frame_maps}
+                   "mean": ses.mean(0.07), "paged_end": ses.is_paged(), "layouts": layouts, "frame_maps": frame_maps,
+                   "fused": eng.frame_fusion_count()}
             if L:
                 res["map"] = ses.maps()
             out[r] = res

@@ -204,13 +204,15 @@ def test_split_map_io_and_views():
 
 
 @pytest.mark.parametrize("world,n_total,L,recv_capacity,frames", [(2, 4096, 6, 0, 12), (3, 3000, 40, 0, 12), (4, 8192, 130, 0, 12),
-                                                                  (8, 32768, 40, 0, 12), (4, 4096, 70, -600, 30)])
+                                                                  (8, 32768, 40, 0, 12), (4, 4096, 70, -600, 30), (2, 16384, 140, 0, 10),
+                                                                  (3, 24576, 300, -900, 12)])
 def test_sharded_split_ranks_on_one_card_equal_one_rank_on_rows(world, n_total, L, recv_capacity, frames, monkeypatch):
     """A sharded session on the split layout: covariance classes are local to a rank, a migrating particle travels as the same
-    record as on rows (its means and its class's covariances) and becomes a class of its own where it arrives.  2 / 3 / 4 / 8
-    ranks sharing this card against ONE rank on rows: poses, maps, heaviest particle, bit for bit.  The last case gives the
-    ranks fewer spare class numbers (600, SLAM_SPLIT_CLASS_ROOM) than rows arrive over the run, so the classes are renumbered on
-    the way."""
+    record as on rows (its means and its class's covariances) and becomes a class of its own where it arrives, numbered from a
+    free list on the device.  2 / 3 / 4 / 8 ranks sharing this card against ONE rank on rows: poses, maps, heaviest particle,
+    bit for bit.  Negative capacities: a list of class numbers hands out at most that many (SLAM_SPLIT_CLASS_ROOM), fewer than
+    rows arrive over the run, so new lists are made from the stamps on the way.  Populations of >= 3 072 particles per rank with
+    rows longer than 128 take the fused front: the groups fed from local rows go out with the score, the rest behind the exchange."""
     from test_gpu_configs import _run_c_session_ranks
 
     if recv_capacity < 0:
@@ -227,7 +229,9 @@ def test_sharded_split_ranks_on_one_card_equal_one_rank_on_rows(world, n_total, 
     for p in many:
         assert p["best"][2] == one["best"][2] and p["best"][1] == one["best"][1]
         assert np.array_equal(bits(p["best"][0]), bits(one["best"][0]))
-    if room:   # more rows arrived than a rank has spare class numbers: it must have renumbered on the way
+    if n_total // world >= 3072 and L > 128:   # shapes the fused front takes: the update went out in two launches per frame
+        assert all(p["fused"] >= frames - 3 for p in many), [p["fused"] for p in many]
+    if room:   # more rows arrived than a list of class numbers hands out: new lists were made on the way
         assert max(sum(p["rows"]) for p in many) > room, [sum(p["rows"]) for p in many]
 
 
