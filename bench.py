@@ -753,7 +753,7 @@ def run_rank(args, ctx, inp, last=True):
     logical = alg / (dur_ms * 1e-3) / 1e9 if dur_ms > 0 else 0.0
     # HBM bytes per launch from rocprofv3 --pmc runs of this same command (profiles/collect_pmc.sh): used only when the
     # record is for this workload AND this kernel
-    traffic, traffic_src = None, None
+    traffic, traffic_src, valu = None, None, None
     tfile = ROOT / "profiles" / "traffic.json"
     if tfile.exists():
         key = (f"{args.mode}:{n}:{args.beams}:{L}:{args.grid}" + (":paged" if paged_in_region else "") + (":split" if split_in_region else "")
@@ -761,13 +761,18 @@ def run_rank(args, ctx, inp, last=True):
         rec = json.loads(tfile.read_text()).get(key, {})
         if rec.get("kernel", kern).split("<")[0] == kern.split(" ")[0]:
             traffic, traffic_src = rec.get("bytes_per_launch"), rec.get("source")
+            if rec.get("valu_instructions_per_launch"):   # the same record's vector-ALU counters (static, builder-run)
+                valu = {"instructions_per_launch": rec["valu_instructions_per_launch"], "busy_pct": rec.get("valu_busy_pct"),
+                        "issue_time_ms_on_1024_simds_at_2p4_ghz": rec["valu_instructions_per_launch"] * 4 / 1024 / 2.4e9 * 1e3,
+                        "source": rec.get("source"), "kernel_template": rec.get("kernel_template"), "head": rec.get("head")}
     # What the launch must move, from THIS run's own figures (checkable without a profiler): an out-of-place update writes
     # every row it owns in full and reads every distinct ancestor's row once (the offspring share it through registers / L2);
     # rows hold 20 B per landmark, split rows 8 B plus 24 B per landmark and covariance class in use (read by the particles'
     # update out of L2, read and rewritten once by cov_update_kernel).  A static PMC record that is far off this model was
     # taken on another filter state (or another kernel) and is flagged.
     traffic_model = None
-    if args.mode == "pf" and L and not paged_in_region and distinct_frac is not None and kern.startswith(("frame_front", "ekf_update", "ekf_split")):
+    if (args.mode == "pf" and L and not paged_in_region and distinct_frac is not None and not 0 < args.ess < 1
+            and kern.startswith(("frame_front", "ekf_update", "ekf_split"))):   # (a gated session's in-place frames rewrite nothing)
         per = 8 if split_in_region else 20
         written = per * n * Lp
         read = distinct_frac * per * n * Lp + (24 * Lp * classes_in_use if split_in_region else 0)
@@ -820,7 +825,7 @@ def run_rank(args, ctx, inp, last=True):
                                   "covariance_classes_in_use": classes_in_use},
                    "frames_resampled": (pf.frames_resampled() if 0 < args.ess < 1 else None)},
         "roofline": {"bound": "hbm", "kernel": kern, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_model": traffic_model,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_model": traffic_model, "valu": valu,
                      "achieved_basis": basis, "achieved_kernel": a_kernel,
                      "algorithmic_bytes_per_launch": alg, "logical_rate_gbs": logical,
                      "logical_frac": logical / HBM_PEAK_GBS,
@@ -838,7 +843,9 @@ def run_rank(args, ctx, inp, last=True):
                               "every row from HBM"
                               + ("; SPLIT layout: the update reads and writes the MEANS of a row only (8 B per particle and landmark "
                                  "each way), the covariance planes exist once per covariance class and are rewritten by "
-                                 "cov_update_kernel (stage `pages`), see `traffic_model`" if split_in_region else "")
+                                 "cov_update_kernel (stage `pages`), see `traffic_model`; with 2.5 x fewer bytes to move the launch is "
+                                 "bound by its vector instructions and the drain of its stores, not by HBM (`valu`, "
+                                 "profiles/r04_split_tuning.md): `frac` is what the remaining bytes amount to" if split_in_region else "")
                               if kern.startswith("frame_front") else
                               "paged maps: the update reads the touched pages of the ancestors (shared pages out of L2) and writes "
                               "fresh pages; `logical_rate_gbs` is SURVEY 8d's 40 B per particle and observed landmark / launch time"

@@ -69,7 +69,12 @@ const char *slam_status_string(int status);
  * slam_engine_create failed */
 const char *slam_last_error(const slam_engine *e);
 
-/* device: HIP device ordinal.  Fails with SLAM_ERR_NO_DEVICE when there is none. */
+/* device: HIP device ordinal.  Fails with SLAM_ERR_NO_DEVICE when there is none.
+ * A host that times its first frames should know: the engine makes ONE allocation of pinned host memory here (every mapped
+ * result buffer and the upload staging ring are carved out of it), and the driver answers such an allocation some 10-50 ms
+ * later by holding the process's queues for 65-80 ms (profiles/r03_stall_trigger.txt).  Results are
+ * unaffected; 50 ms between slam_engine_create and the first timed frame keep the hold out of the timing (bench.py sleeps
+ * 250 ms).  Creating and destroying sessions on a live engine allocates no pinned memory. */
 int slam_engine_create(int device, slam_engine **out);
 int slam_engine_destroy(slam_engine *e);
 /* Run the engine on a caller-provided hipStream_t (e.g. the framework's current stream) instead of
@@ -144,7 +149,12 @@ int slam_grid_upload_host(slam_engine *e, int slot, const int32_t *occ, const sl
  * reference runs its EDTs before it records pixel_size and top_left_corner (main.c:355-362); an
  * adapter with the reference's EDT signature therefore learns them one step later. */
 int slam_grid_set_meta(slam_engine *e, int slot, const slam_grid_meta *meta);
-/* Adopt an EDT that is already on the device (not copied; caller keeps it alive). */
+/* Adopt an EDT that is already on the device (not copied; caller keeps it alive).
+ * The scorers of many poses (slam_score_poses_*, slam_motion_score_dev, slam_pf_step with >= 3 072 poses) gather from a packed
+ * copy of the grid — one byte per cell, made on their first call after the grid changed (the capped EDT holds only 0,
+ * sqrtf of small integers and the cap: main.c:223-269; a grid with other values keeps the float path) — so call
+ * slam_grid_set_dev again after rewriting the cells of an adopted grid (slam_edt_dev into the adopted buffer is noticed
+ * by itself).  Results are bit-identical either way. */
 int slam_grid_set_dev(slam_engine *e, int slot, const float *d_edt, const slam_grid_meta *meta);
 /* Sensor-frame cartesian beams of the current scan = scan.x / scan.y (main.c:60-69). */
 int slam_scan_upload_host(slam_engine *e, const float *bx, const float *by, int nbeams);

@@ -18,10 +18,11 @@ for d in sorted(glob.glob(str(src / f"{tag}_ekfpmc_*"))):
     if not fs:
         continue
     rows = [r for r in csv.DictReader(open(max(fs, key=os.path.getmtime))) if "ekf_update" in r["Kernel_Name"] or "frame_front_kernel" in r["Kernel_Name"]]
-    for r in rows:
+    for k, r in enumerate(rows):
         vals[r["Counter_Name"]].append(float(r["Counter_Value"]))
-        kern = r["Kernel_Name"].replace("void slam::", "").replace("slam::", "").replace("(anonymous namespace)::", "").split("(")[0]
-md = [f"# {tag}: hardware counters of the in-filter EKF kernel (`{kern}`), configs[1], one `rocprofv3 --pmc` pass per group", "",
+        if k == 4:   # the header names the kernel of the launches that are averaged (4..9), not of the stage pass behind them
+            kern = r["Kernel_Name"].replace("void slam::", "").replace("slam::", "").replace("(anonymous namespace)::", "").split("(")[0]
+md = [f"# {tag}: hardware counters of the in-filter EKF kernel (`{kern}`, cold start: `--preroll 0`), configs[1], one `rocprofv3 --pmc` pass per group", "",
       "| counter | per-launch average (launches 4..9 of `bench.py --steps 8 --warmup 2 --preroll 0 --events none --no-sweep`) |", "|---|---|"]
 for name, v in vals.items():
     v = v[4:10] or v   # launches 4..9: steady frames of the timed region (the stage pass behind them runs the two-launch path)

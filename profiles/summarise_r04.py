@@ -13,8 +13,10 @@ import sys
 from collections import defaultdict
 from pathlib import Path
 
-tag = sys.argv[1]
-want = sys.argv[2] if len(sys.argv) > 2 else "frame_front_kernel"
+args = [a for a in sys.argv[1:] if not a.startswith("--traffic-key=")]
+traffic_key = next((a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--traffic-key=")), None)
+tag = args[0]
+want = args[1] if len(args) > 1 else "frame_front_kernel"
 here = Path(__file__).resolve().parent
 src = here.parent / "gpurun_out"
 stats = glob.glob(str(src / f"{tag}_trace" / "*" / "*kernel_stats.csv"))
@@ -48,3 +50,15 @@ if "SQ_WAVE_CYCLES" in g:
             md.append(f"{a} / SQ_WAVE_CYCLES = {g[a] / g['SQ_WAVE_CYCLES']:.3f}")
 (here / f"{tag}_pmc.md").write_text("\n".join(md) + "\n")
 print("\n".join(md))
+if traffic_key and "FETCH_SIZE" in g and "WRITE_SIZE" in g:   # the record bench.py's roofline.traffic comes from
+    import json
+
+    tf = here / "traffic.json"
+    rec = json.loads(tf.read_text()) if tf.exists() else {}
+    rd, wr = g["FETCH_SIZE"] * 1024 * 2, g["WRITE_SIZE"] * 1024
+    rec[traffic_key] = {"bytes_per_launch": rd + wr, "read_bytes": rd, "write_bytes": wr, "kernel": kern.split("<")[0],
+                        "kernel_template": kern, "source": f"profiles/{tag}_pmc.md", "head": head,
+                        "bench_args": "--steps 8 --warmup 2 --events none --no-sweep (120 pre-roll frames; the last six fused launches)",
+                        "valu_instructions_per_launch": g.get("SQ_INSTS_VALU"), "valu_busy_pct": g.get("VALUBusy")}
+    tf.write_text(json.dumps(rec, indent=1) + "\n")
+    print(f"traffic.json: {traffic_key} <- {(rd + wr) / 1e9:.4f} GB")
