@@ -549,7 +549,7 @@ struct SplitBatch {
 // the ISA of round 3's kernel): hence two copies of the batch, chosen by a REAL branch (the asm statement keeps the copies
 // from being merged back into one).
 template <int NB, bool SPECIAL>
-__device__ __forceinline__ void split_apply_one(const SplitBatch<NB>& b, int g, const EkfPose& w, int pl, v2f& acc)
+__device__ __forceinline__ void split_apply_one(const SplitBatch<NB>& b, int g, const EkfPose& w, int pl, v2f& term)
 {
     v2f zx = b.zx[g];
     if constexpr (SPECIAL) asm volatile("" : "+v"(zx));
@@ -563,7 +563,7 @@ __device__ __forceinline__ void split_apply_one(const SplitBatch<NB>& b, int g, 
             ll[t] = (b.keep[g][t] || b.first[g][t]) ? 0.0f : ll[t];
         }
     }
-    acc = acc + ll;
+    term = ll;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         row_store(w.rout, b.off[g][t], 0, r0[t]);
@@ -571,11 +571,13 @@ __device__ __forceinline__ void split_apply_one(const SplitBatch<NB>& b, int g, 
     }
 }
 
+// one particle, the NB batches of a pass: term[g] = the batch's log-likelihood terms (+0 where there is none)
 template <int NB>
-__device__ __forceinline__ void split_apply(const SplitBatch<NB>& b, const EkfPose& w, int pl, v2f& acc)
+__device__ __forceinline__ void split_apply_terms(const SplitBatch<NB>& b, const EkfPose& w, int pl, v2f (&term)[NB])
 {
 #pragma unroll
     for (int g = 0; g < NB; ++g) {
+        term[g] = bc2(0.0f);
         if (!b.any_obs[g]) {   // nothing observed among these 128 landmarks: the means are copied
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
@@ -583,11 +585,20 @@ __device__ __forceinline__ void split_apply(const SplitBatch<NB>& b, const EkfPo
                 row_store(w.rout, b.off[g][t], pl, b.my[g][t]);
             }
         } else if (b.special[g]) {
-            split_apply_one<NB, true>(b, g, w, pl, acc);
+            split_apply_one<NB, true>(b, g, w, pl, term[g]);
         } else {
-            split_apply_one<NB, false>(b, g, w, pl, acc);
+            split_apply_one<NB, false>(b, g, w, pl, term[g]);
         }
     }
+}
+
+template <int NB>
+__device__ __forceinline__ void split_apply(const SplitBatch<NB>& b, const EkfPose& w, int pl, v2f& acc)
+{
+    v2f term[NB];
+    split_apply_terms<NB>(b, w, pl, term);
+#pragma unroll
+    for (int g = 0; g < NB; ++g) acc = acc + term[g];   // (a batch without observations adds +0: the bits stay)
 }
 
 template <int NB, int G, bool OWN_MOTION>
@@ -762,6 +773,13 @@ __device__ __forceinline__ void ekf_split_body(const EkfArgs& a, int bid, float 
         }
     }
 }
+
+// (A second form of this update — ONE PASS PER WAVEFRONT: the four wavefronts of a workgroup take the passes of a row side by
+// side and share the group's particles, so that no wavefront loads after it has stored; the batches' log-likelihood terms parked
+// in LDS and added up in landmark order behind a workgroup barrier, the group's motion samples worked out by one wavefront —
+// was built, bit-exact on the whole split suite, and measured slower: fused front 95.5 against 88.6 us at 64k x 500, 2.21
+// against 1.80 ms at 1M x 1000 (twice / four times the wavefronts, three barriers per workgroup, 32 KB of LDS that cap the
+// occupancy at 4).  Removed; profiles/r04_split_tuning.md.)
 
 template <int NB, int G>
 __global__ __launch_bounds__(kEkfWaves * 64) EKF_SPLIT_ATTR void ekf_split_kernel(EkfArgs a)
