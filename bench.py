@@ -644,9 +644,9 @@ def run_rank(args, ctx, inp, last=True):
     forms1 = eng.ekf_form_counts() + eng.ekf_inplace_form_counts()
     forms = tuple(b - a for a, b in zip(forms0, forms1))   # EKF launches of the timed region, by kernel (out of place x2, in place x2)
     fused_n = eng.frame_fusion_count() - fused0             # ... of which went out fused with the motion + score launch
-    layout_in_region = pf.layout()   # "rows", "pages" or "split": what the timed frames ran on
-    paged_in_region = layout_in_region == "pages"
-    split_in_region = layout_in_region == "split"
+    layout_in_region = pf.layout()   # "rows", "pages", "split" or "split_pages": what the timed frames ran on
+    paged_in_region = layout_in_region in ("pages", "split_pages")
+    split_in_region = layout_in_region in ("split", "split_pages")
     elapsed = ctx.max_over_ranks(elapsed)
     migrated = ctx.max_over_ranks(migrated / max(args.steps, 1))
 
@@ -700,7 +700,7 @@ def run_rank(args, ctx, inp, last=True):
     no_reuse = None
     # classes in use (split layout): what the covariance part of a frame costs is proportional to it
     classes_in_use = None
-    if split_in_region:
+    if layout_in_region == "split":
         classes_in_use = int(torch.as_tensor(pf.split_view()["live_count"], device=dev)[0])
     sweep_rows = views()[1:3]
     if L and args.mode != "score" and not args.no_sweep and sweep_rows[0] is None and not paged_in_region:
@@ -821,7 +821,9 @@ def run_rank(args, ctx, inp, last=True):
                    "preroll_frames": off,
                    "map_layout": {"requested": args.map_layout,
                                   "in_timed_region": {"pages": "pages (copy-on-write, 32 landmarks)", "rows": "rows",
-                                                      "split": "split (means per particle, covariances per covariance class)"}[layout_in_region],
+                                                      "split": "split (means per particle, covariances per covariance class)",
+                                                      "split_pages": "split pages (means on copy-on-write pages of 32 landmarks, "
+                                                                     "covariances per covariance class)"}[layout_in_region],
                                   "covariance_classes_in_use": classes_in_use},
                    "frames_resampled": (pf.frames_resampled() if 0 < args.ess < 1 else None)},
         "roofline": {"bound": "hbm", "kernel": kern, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -981,7 +983,7 @@ def extra_legs(args, torch, pkg, eng, dev, inp, kernel_ms):
     e2e = {"what": "configs[1] (65536 x 500, 360 beams, 1024^2 EDT) with the 32 nearest landmarks observed per frame, every "
                    "frame resampled: whole frames on the C session; `*_ms` = median over chunks of 10 frames (one "
                    "synchronisation per chunk; `*_ms_chunks` lists them)", "steps": steps}
-    for layout in ("rows", "split", "pages", "auto"):
+    for layout in ("rows", "split", "pages", "split_pages", "auto"):
         ses = pkg.PfSession(eng, n, L, sigma=SIGMA, meas_var=MEAS_VAR, score_gain=SCORE_GAIN, seed=1234, map_layout=layout)
         g = torch.Generator(device="cpu").manual_seed(1234)
         p0 = true_pose(0)
@@ -1141,7 +1143,7 @@ def parse_args():
                     help="experiment, --mode score: upload the poses grouped by 4-pixel / matching-heading cells")
     ap.add_argument("--ekf-form", type=int, default=-1, choices=[-1, 0, 1, 2],
                     help="out-of-place EKF kernel: -1 the engine chooses (default), 0 one wavefront per particle, 1 / 2 per 4 / 2 particles")
-    ap.add_argument("--map-layout", choices=["auto", "rows", "pages", "split"], default="auto",
+    ap.add_argument("--map-layout", choices=["auto", "rows", "pages", "split", "split_pages"], default="auto",
                     help="slam_pf_config.map_layout: auto (default: the session chooses and may change while it runs: split for dense "
                          "frames on one GPU, pages for sparse ones, rows when sharded or gated), rows, pages, split (means per "
                          "particle, covariances per covariance class)")

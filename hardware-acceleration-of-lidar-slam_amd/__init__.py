@@ -518,9 +518,9 @@ class PfConfig(C.Structure):
                 ("map_layout", C.c_int32)]
 
 
-MAP_AUTO, MAP_ROWS, MAP_PAGES, MAP_SPLIT = 0, 1, 2, 3   # slam_map_layout
-_LAYOUTS = {"auto": MAP_AUTO, "rows": MAP_ROWS, "pages": MAP_PAGES, "split": MAP_SPLIT, None: MAP_AUTO}
-_LAYOUT_NAMES = {MAP_ROWS: "rows", MAP_PAGES: "pages", MAP_SPLIT: "split"}
+MAP_AUTO, MAP_ROWS, MAP_PAGES, MAP_SPLIT, MAP_SPLIT_PAGES = 0, 1, 2, 3, 4   # slam_map_layout
+_LAYOUTS = {"auto": MAP_AUTO, "rows": MAP_ROWS, "pages": MAP_PAGES, "split": MAP_SPLIT, "split_pages": MAP_SPLIT_PAGES, None: MAP_AUTO}
+_LAYOUT_NAMES = {MAP_ROWS: "rows", MAP_PAGES: "pages", MAP_SPLIT: "split", MAP_SPLIT_PAGES: "split_pages"}
 
 
 COMM_ID_BYTES = 128

@@ -210,6 +210,9 @@ hipError_t launch_migrate_unpack_split(hipStream_t stream, const float* in, int 
 // a frame without a landmark update: means and classes follow their particles (out[i] = in[anc[i]])
 hipError_t launch_split_gather(hipStream_t stream, const float* mean_in, float* mean_out, const int32_t* cls_in, int32_t* cls_out,
                                int Lp, const int32_t* anc, int n, uint32_t* cstamp, uint32_t stamp_now);
+// the classes alone follow their particles (split pages: the means follow through the page tables)
+hipError_t launch_class_gather(hipStream_t stream, const int32_t* cls_in, int32_t* cls_out, const int32_t* anc, int n, uint32_t* cstamp,
+                               uint32_t stamp_now);
 // every particle: all landmarks "not seen yet", one class
 hipError_t launch_split_reset(hipStream_t stream, float* mean, float* cov, float* covx, int32_t* cls, int Lp, int n, int32_t* live,
                               int32_t* cnt, int phase, uint32_t* cstamp, uint32_t stamp_now, int32_t* h_live, uint32_t epoch);
@@ -241,8 +244,25 @@ struct ObsListOut {   // where launch_page_list leaves the same list (id == null
     float *zx = nullptr, *zy = nullptr;
     int32_t *round = nullptr, *count = nullptr;
 };
+// Where a page lies.  The pages of a session on joint pages are one array of [5][32] floats; the pages of a SPLIT session on
+// pages hold the two planes of MEANS only ([2][32] floats, 256 bytes) and lie in the session's two mean buffers, which are
+// not neighbours in the store: pages below `half_pages` in the first, the others `gap` floats further on.
+struct PageGeom {
+    int planes = 5;                          // planes per page (5: means + covariances; 2: means)
+    int64_t half_pages = (int64_t)1 << 62;   // pages at or beyond this index lie `gap` floats further on
+    int64_t gap = 0;
+};
 struct PagedEkfArgs {
-    float* pool;             // [npages][5][32]
+    PageGeom geom;
+    // split session on pages (geom.planes == 2): the covariances come per class, as in EkfArgs
+    const float* cov = nullptr;
+    const float* covx = nullptr;
+    int plane_stride = 0;             // floats between the planes of a class row (Lp)
+    const int32_t* cls_in = nullptr;
+    int32_t* cls_out = nullptr;
+    uint32_t* cstamp = nullptr;
+    uint32_t cstamp_now = 0;
+    float* pool;             // [npages][planes][32]
     const int32_t* pt_in;    // [rows][nb] page tables of the ancestors
     int32_t* pt_out;         // [n][nb]    page tables of this frame's particles
     int nb;                  // pages per particle
@@ -290,11 +310,15 @@ hipError_t launch_compose_index(hipStream_t stream, const int32_t* sel, const in
 // rows -> pages page_base + j * nb + b behind identity tables; every other page of the pool goes on the free list
 hipError_t launch_pages_from_rows(hipStream_t stream, const float* rows, int64_t row_stride, int plane_stride, int nlandmarks,
                                   int nb, int n, float* pool, int32_t* pt, int32_t* freelist, int npages, int32_t* pool_state,
-                                  int page_base = 0);
+                                  int page_base = 0, const PageGeom& geom = PageGeom());
 hipError_t launch_rows_from_pages(hipStream_t stream, const float* pool, const int32_t* pt, int nb, const int32_t* anc, int n,
-                                  float* rows, int64_t row_stride, int plane_stride, int nlandmarks);
+                                  float* rows, int64_t row_stride, int plane_stride, int nlandmarks, const PageGeom& geom = PageGeom());
 hipError_t launch_pages_reset(hipStream_t stream, float* pool, int32_t* pt, int64_t nentries, int32_t* freelist, int npages,
-                              int32_t* pool_state);
+                              int32_t* pool_state, const PageGeom& geom = PageGeom());
+// split pages -> dense rows of 5 planes (means from the particle's pages of two planes, covariances from its class's rows)
+hipError_t launch_rows_from_split_pages(hipStream_t stream, const float* pool, const PageGeom& geom, const int32_t* pt, int nb,
+                                        const float* cov, const int32_t* cls, int Lp, const int32_t* idx, int count, float* rows,
+                                        int64_t row_stride, int plane_stride, int nlandmarks);
 // Sharded sessions: `want` pages for the rows about to be unpacked (pool_state then says where in the list they start and
 // whether launch_free_list, to be called behind it, has to make a new list first), and the unpack itself: record p of
 // `in` (pose + 5 x nlandmarks floats, as launch_migrate_pack writes them) -> table row n + p on fresh pages, stamped `live`

@@ -28,7 +28,13 @@ namespace slam {
 namespace {
 
 constexpr int kPage = kPageLandmarks;          // landmarks per page
-constexpr int kPageFloats = 5 * kPage;         // floats per page: planes mu_x | mu_y | P_xx | P_xy | P_yy
+constexpr int kPageFloats = 5 * kPage;         // floats per page of a session on joint pages: planes mu_x | mu_y | P_xx | P_xy | P_yy
+
+// offset (in floats) of page `page` from the pool's base (kernels.h: PageGeom)
+__device__ __forceinline__ int64_t page_off(const PageGeom& g, int64_t page)
+{
+    return page * (g.planes * kPage) + (page >= g.half_pages ? g.gap : 0);
+}
 constexpr int kWaves = 4;                      // wavefronts per workgroup (64 / kPage particles each)
 // PoolState (device, kPoolStateWords int32): bookkeeping of the free list between frames, all of it on the device
 enum { kPoolFree = 0,    // entries in the free list
@@ -238,6 +244,7 @@ __global__ __launch_bounds__(256) void migrate_unpack_paged_kernel(const float* 
 // particle's work is a handful of dependent round trips (ancestor -> table -> page -> store) and little else, so the
 // kernel's time is the number of wavefronts times those round trips: two particles per wavefront halve it (one particle
 // per wavefront, two pages per pass: 91 us at 64k x 500 with 32 observed).
+template <bool SPLIT>
 __global__ __launch_bounds__(kWaves * 64) void ekf_paged_kernel(PagedEkfArgs a)
 {
     constexpr int kGroups = 64 / kPage;          // particles per wavefront: kPage lanes = the landmarks of a page
@@ -264,6 +271,17 @@ __global__ __launch_bounds__(kWaves * 64) void ekf_paged_kernel(PagedEkfArgs a)
             row_out[b] = page;
             a.stamp[page] = a.stamp_now;   // named by a table of this frame (same value from every writer)
         }
+    // SPLIT: a page holds the means only; the covariances are the class's (split_kernels.hip), which follows the particle
+    int cls = 0;
+    if constexpr (SPLIT) {
+        cls = a.cls_in[src];
+        if (alive && slot == 0) {
+            a.cls_out[i] = cls;
+            a.cstamp[cls] = a.cstamp_now;
+        }
+    }
+    const float* __restrict__ crow = SPLIT ? a.cov + (int64_t)cls * 3 * a.plane_stride : nullptr;
+    const float* __restrict__ xrow = SPLIT ? a.covx + (int64_t)cls * 2 * a.plane_stride : nullptr;
     float st, ct;
     det_sincosf(a.th[i], st, ct);
     const float s = st, c = ct, px = a.x[i], py = a.y[i], q = a.meas_var;
@@ -279,12 +297,29 @@ __global__ __launch_bounds__(kWaves * 64) void ekf_paged_kernel(PagedEkfArgs a)
             const int from = half * kPage + t;
             const int b = __shfl(my_b, from, 64);
             const int l = b * kPage + slot;
-            const float* __restrict__ pin = a.pool + (int64_t)__shfl(my_old, from, 64) * kPageFloats + slot;
-            float* __restrict__ pout = a.pool + (int64_t)__shfl(my_new, from, 64) * kPageFloats + slot;
-            const float mx = pin[0 * kPage], my = pin[1 * kPage], pxx = pin[2 * kPage], pxy = pin[3 * kPage], pyy = pin[4 * kPage];
+            const float* __restrict__ pin = a.pool + page_off(a.geom, __shfl(my_old, from, 64)) + slot;
+            float* __restrict__ pout = a.pool + page_off(a.geom, __shfl(my_new, from, 64)) + slot;
             const bool in = l < a.nlandmarks;
             const float zx = in ? a.obs_zx[l] : __builtin_nanf(""), zy = in ? a.obs_zy[l] : __builtin_nanf("");
             const bool ob = zx == zx && zy == zy;
+            if constexpr (SPLIT) {   // means from the page, covariances and their determinant terms from the class's rows
+                const float mx = pin[0 * kPage], my = pin[1 * kPage];
+                const int lc = l < a.plane_stride ? l : 0;
+                const float pxx = crow[lc], pxy = crow[a.plane_stride + lc], pyy = crow[2 * a.plane_stride + lc];
+                const EkfShared<float> h = ekf_shared_from<float, false>(pxx, pxy, pyy, q, xrow[lc], xrow[a.plane_stride + lc]);
+                const EkfParticle<float> v = ekf_particle<float>(h, mx, my, zx, zy, s, c, px, py);
+                const bool first = pxx < 0.0f;
+                const float r0 = ob ? (first ? v.wx : v.o0) : mx, r1 = ob ? (first ? v.wy : v.o1) : my;
+                const float term = first ? 0.0f : v.ll;
+                if (alive) {
+                    pout[0 * kPage] = r0;
+                    pout[1 * kPage] = r1;
+                }
+                const int k = (b & (kAccPages - 1)) * kPage + slot;
+                if (ob) acc[k] = acc[k] + term;
+                continue;
+            }
+            const float mx = pin[0 * kPage], my = pin[1 * kPage], pxx = pin[2 * kPage], pxy = pin[3 * kPage], pyy = pin[4 * kPage];
             const EkfResult<float> u = ekf_update_one<float>(mx, my, pxx, pxy, pyy, zx, zy, s, c, px, py, q);   // one landmark per lane
             const float o0 = u.o0, o1 = u.o1, o2 = u.o2, o3 = u.o3, o4 = u.o4, ll = u.ll, f0 = u.f0, f1 = u.f1;
             const bool first = pxx < 0.0f;
@@ -336,11 +371,12 @@ __global__ __launch_bounds__(kWaves * 64) void ekf_paged_kernel(PagedEkfArgs a)
 // written once.  Against the page-wide form: the arithmetic runs once per observation instead of once per lane of every
 // touched page, a particle's pages are not fetched one dependent round trip after the other, and nothing is gathered from or
 // scattered to global memory.
-template <int PG>
+template <int PG, bool SPLIT>
 __global__ __launch_bounds__(kWaves * 64) void ekf_paged_lds_kernel(PagedEkfArgs a)
 {
     constexpr int kGroups = 64 / kPage;
-    __shared__ float s_img[kWaves][PG][5][64];       // [page of the chunk][plane][lane]: lane = particle of the wavefront x slot
+    constexpr int PL = SPLIT ? 2 : 5;                // planes per page
+    __shared__ float s_img[kWaves][PG][PL][64];      // [page of the chunk][plane][lane]: lane = particle of the wavefront x slot
     __shared__ float s_acc[kWaves][kGroups][128];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -359,7 +395,7 @@ __global__ __launch_bounds__(kWaves * 64) void ekf_paged_lds_kernel(PagedEkfArgs
     const int32_t* __restrict__ fresh = a.freelist + fbase + (int64_t)i * T;
     const float* __restrict__ pool_in = a.pool;   // pages named by the ancestors' tables: read only
     float* __restrict__ pool_out = a.pool;        // fresh pages: written only (never one of the above)
-    float(*img)[5][64] = s_img[wave];
+    float(*img)[PL][64] = s_img[wave];
 
     if (alive)
         for (int b = slot; b < a.nb; b += kPage) {
@@ -368,6 +404,16 @@ __global__ __launch_bounds__(kWaves * 64) void ekf_paged_lds_kernel(PagedEkfArgs
             row_out[b] = page;
             a.stamp[page] = a.stamp_now;
         }
+    int cls = 0;
+    if constexpr (SPLIT) {   // the class follows the particle and is still in use
+        cls = a.cls_in[src];
+        if (alive && slot == 0) {
+            a.cls_out[i] = cls;
+            a.cstamp[cls] = a.cstamp_now;
+        }
+    }
+    const float* __restrict__ crow = SPLIT ? a.cov + (int64_t)cls * 3 * a.plane_stride : nullptr;
+    const float* __restrict__ xrow = SPLIT ? a.covx + (int64_t)cls * 2 * a.plane_stride : nullptr;
     float st, ct;
     det_sincosf(a.th[i], st, ct);
     const float s = st, c = ct, px = a.x[i], py = a.y[i], q = a.meas_var;
@@ -382,20 +428,20 @@ __global__ __launch_bounds__(kWaves * 64) void ekf_paged_lds_kernel(PagedEkfArgs
         const int tl = c0 + slot < T ? c0 + slot : T - 1;
         const int my_old = row_in[a.tpage[tl]], my_new = fresh[tl];
         // (b) pages c0 .. c0 + tc - 1 of the ancestor -> image (chunk slots beyond tc re-read the last page: harmless)
-        float v[PG][5];
+        float v[PG][PL];
         int64_t oout[PG];
 #pragma unroll
         for (int j = 0; j < PG; ++j) {
             const int from = half * kPage + (j < kPage ? j : kPage - 1);
-            const int64_t oin = (int64_t)__shfl(my_old, from, 64) * kPageFloats + slot;
-            oout[j] = (int64_t)__shfl(my_new, from, 64) * kPageFloats + slot;
+            const int64_t oin = page_off(a.geom, __shfl(my_old, from, 64)) + slot;
+            oout[j] = page_off(a.geom, __shfl(my_new, from, 64)) + slot;
 #pragma unroll
-            for (int p = 0; p < 5; ++p) v[j][p] = pool_in[oin + p * kPage];
+            for (int p = 0; p < PL; ++p) v[j][p] = pool_in[oin + p * kPage];
         }
 #pragma unroll
         for (int j = 0; j < PG; ++j)
 #pragma unroll
-            for (int p = 0; p < 5; ++p) img[j][p][lane] = v[j][p];
+            for (int p = 0; p < PL; ++p) img[j][p][lane] = v[j][p];
         __builtin_amdgcn_wave_barrier();
         // (c) the observations that fall into these pages, one lane each
         const int k_lo = __builtin_amdgcn_readfirstlane(a.tbase[c0]), k_hi = __builtin_amdgcn_readfirstlane(a.tbase[c0 + tc]);
@@ -406,16 +452,30 @@ __global__ __launch_bounds__(kWaves * 64) void ekf_paged_lds_kernel(PagedEkfArgs
             const int l = a.ol.id[kk], rnd = a.ol.round[kk];
             const float zx = a.ol.zx[kk], zy = a.ol.zy[kk];
             const int j = a.tindex[l / kPage] - c0, at = half * kPage + l % kPage;
-            const float mx = img[j][0][at], my = img[j][1][at], pxx = img[j][2][at], pxy = img[j][3][at], pyy = img[j][4][at];
-            const EkfResult<float> u = ekf_update_one<float>(mx, my, pxx, pxy, pyy, zx, zy, s, c, px, py, q);
-            const bool first = pxx < 0.0f;
-            const float term = first ? 0.0f : u.ll;
-            if (on) {
-                img[j][0][at] = first ? u.f0 : u.o0;
-                img[j][1][at] = first ? u.f1 : u.o1;
-                img[j][2][at] = first ? q : u.o2;
-                img[j][3][at] = first ? 0.0f : u.o3;
-                img[j][4][at] = first ? q : u.o4;
+            float term;
+            if constexpr (SPLIT) {   // means from the image, covariances and their determinant terms from the class's rows
+                const float mx = img[j][0][at], my = img[j][1][at];
+                const float pxx = crow[l], pxy = crow[a.plane_stride + l], pyy = crow[2 * a.plane_stride + l];
+                const EkfShared<float> h = ekf_shared_from<float, false>(pxx, pxy, pyy, q, xrow[l], xrow[a.plane_stride + l]);
+                const EkfParticle<float> w = ekf_particle<float>(h, mx, my, zx, zy, s, c, px, py);
+                const bool first = pxx < 0.0f;
+                term = first ? 0.0f : w.ll;
+                if (on) {
+                    img[j][0][at] = first ? w.wx : w.o0;
+                    img[j][1][at] = first ? w.wy : w.o1;
+                }
+            } else {
+                const float mx = img[j][0][at], my = img[j][1][at], pxx = img[j][2][at], pxy = img[j][3][at], pyy = img[j][4][at];
+                const EkfResult<float> u = ekf_update_one<float>(mx, my, pxx, pxy, pyy, zx, zy, s, c, px, py, q);
+                const bool first = pxx < 0.0f;
+                term = first ? 0.0f : u.ll;
+                if (on) {
+                    img[j][0][at] = first ? u.f0 : u.o0;
+                    img[j][1][at] = first ? u.f1 : u.o1;
+                    img[j][2][at] = first ? q : u.o2;
+                    img[j][3][at] = first ? 0.0f : u.o3;
+                    img[j][4][at] = first ? q : u.o4;
+                }
             }
             // accumulator = landmark mod 128, in order of the landmark: round by round (the observations of one accumulator have
             // distinct rounds; the LDS operations of a wavefront execute in order)
@@ -429,7 +489,7 @@ __global__ __launch_bounds__(kWaves * 64) void ekf_paged_lds_kernel(PagedEkfArgs
         for (int j = 0; j < PG; ++j)
             if (j < tc && alive) {
 #pragma unroll
-                for (int p = 0; p < 5; ++p) pool_out[oout[j] + p * kPage] = img[j][p][lane];
+                for (int p = 0; p < PL; ++p) pool_out[oout[j] + p * kPage] = img[j][p][lane];
             }
         __builtin_amdgcn_wave_barrier();
     }
@@ -532,7 +592,7 @@ __global__ __launch_bounds__(256) void free_list_kernel(const uint32_t* __restri
 // rows [n][5][plane_stride] -> pages page_base + j * nb + b (the identity table, shifted)
 __global__ __launch_bounds__(256) void pages_from_rows_kernel(const float* __restrict__ rows, int64_t row_stride, int plane_stride,
                                                               int nlandmarks, int nb, int n, float* __restrict__ pool,
-                                                              int32_t* __restrict__ pt, int page_base)
+                                                              int32_t* __restrict__ pt, int page_base, PageGeom geom)
 {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;   // one thread per (particle, page, slot)
     if (idx >= (int64_t)n * nb * kPage) return;
@@ -541,9 +601,8 @@ __global__ __launch_bounds__(256) void pages_from_rows_kernel(const float* __res
     const int b = (int)(pb % nb), i = (int)(pb / nb);
     const int l = b * kPage + slot;
     const float* r = rows + (int64_t)i * row_stride;
-    float* pg = pool + (pb + page_base) * kPageFloats + slot;
-#pragma unroll
-    for (int p = 0; p < 5; ++p) pg[p * kPage] = l < nlandmarks ? r[(int64_t)p * plane_stride + l] : (p == 2 ? -1.0f : 0.0f);
+    float* pg = pool + page_off(geom, pb + page_base) + slot;
+    for (int p = 0; p < geom.planes; ++p) pg[p * kPage] = l < nlandmarks ? r[(int64_t)p * plane_stride + l] : (p == 2 ? -1.0f : 0.0f);
     if (slot == 0) pt[pb] = (int32_t)pb + page_base;
 }
 
@@ -551,7 +610,7 @@ __global__ __launch_bounds__(256) void pages_from_rows_kernel(const float* __res
 __global__ __launch_bounds__(256) void rows_from_pages_kernel(const float* __restrict__ pool, const int32_t* __restrict__ pt,
                                                               int nb, const int32_t* __restrict__ anc, int n,
                                                               float* __restrict__ rows, int64_t row_stride, int plane_stride,
-                                                              int nlandmarks)
+                                                              int nlandmarks, PageGeom geom)
 {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (int64_t)n * nb * kPage) return;
@@ -561,19 +620,41 @@ __global__ __launch_bounds__(256) void rows_from_pages_kernel(const float* __res
     const int l = b * kPage + slot;
     if (l >= nlandmarks) return;
     const int src = anc ? anc[i] : i;
-    const float* pg = pool + (int64_t)pt[(int64_t)src * nb + b] * kPageFloats + slot;
+    const float* pg = pool + page_off(geom, pt[(int64_t)src * nb + b]) + slot;
     float* r = rows + (int64_t)i * row_stride;
-#pragma unroll
-    for (int p = 0; p < 5; ++p) r[(int64_t)p * plane_stride + l] = pg[p * kPage];
+    for (int p = 0; p < geom.planes; ++p) r[(int64_t)p * plane_stride + l] = pg[p * kPage];
+}
+
+// split session on pages -> rows of five planes (one workgroup per output row)
+__global__ __launch_bounds__(256) void rows_from_split_pages_kernel(const float* __restrict__ pool, PageGeom geom,
+                                                                    const int32_t* __restrict__ pt, int nb, const float* __restrict__ cov,
+                                                                    const int32_t* __restrict__ cls, int Lp, const int32_t* __restrict__ idx,
+                                                                    int count, float* __restrict__ rows, int64_t row_stride,
+                                                                    int plane_stride, int nlandmarks)
+{
+    const int k = blockIdx.x;
+    if (k >= count) return;
+    const int src = idx ? idx[k] : k;
+    const int32_t* tab = pt + (int64_t)src * nb;
+    const float* cr = cov + (int64_t)cls[src] * 3 * Lp;
+    float* r = rows + (int64_t)k * row_stride;
+    for (int l = threadIdx.x; l < nlandmarks; l += 256) {
+        const float* pg = pool + page_off(geom, tab[l / kPage]) + l % kPage;
+        r[l] = pg[0];
+        r[(int64_t)plane_stride + l] = pg[kPage];
+        r[2 * (int64_t)plane_stride + l] = cr[l];
+        r[3 * (int64_t)plane_stride + l] = cr[Lp + l];
+        r[4 * (int64_t)plane_stride + l] = cr[2 * Lp + l];
+    }
 }
 
 // every particle starts on ONE shared page of landmarks "not seen yet" (page 0), the rest of the pool is free
 __global__ __launch_bounds__(256) void pages_reset_kernel(float* __restrict__ pool, int32_t* __restrict__ pt, int64_t nentries,
                                                           int32_t* __restrict__ freelist, int npages,
-                                                          int32_t* __restrict__ pool_state)
+                                                          int32_t* __restrict__ pool_state, int planes)
 {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx < kPageFloats) pool[idx] = (idx / kPage == 2) ? -1.0f : 0.0f;
+    if (idx < planes * kPage) pool[idx] = (idx / kPage == 2) ? -1.0f : 0.0f;
     if (idx < nentries) pt[idx] = 0;
     if (idx < npages - 1) freelist[idx] = (int32_t)idx + 1;
     if (idx == 0) {
@@ -645,14 +726,21 @@ hipError_t launch_ekf_paged(hipStream_t stream, const PagedEkfArgs& a, const Eve
     // with that many pages the LDS image costs more wavefronts in flight than the list form saves (measured, 64k x 500 with
     // 128 observed / 64k x 5000 with 512: 120 / 460 us page-wide against 123 / 474 us at best).
     const int pg = pg_env > 0 ? pg_env : (touched_hint > 0 ? touched_hint : 6);
-    if (form == 0 || !a.ol.id || (pg_env <= 0 && touched_hint > 6)) ekf_paged_kernel<<<grid, kWaves * 64, 0, stream>>>(a);
-    else if (pg <= 1) ekf_paged_lds_kernel<1><<<grid, kWaves * 64, 0, stream>>>(a);
-    else if (pg == 2) ekf_paged_lds_kernel<2><<<grid, kWaves * 64, 0, stream>>>(a);
-    else if (pg == 3) ekf_paged_lds_kernel<3><<<grid, kWaves * 64, 0, stream>>>(a);
-    else if (pg == 4) ekf_paged_lds_kernel<4><<<grid, kWaves * 64, 0, stream>>>(a);
-    else if (pg == 5) ekf_paged_lds_kernel<5><<<grid, kWaves * 64, 0, stream>>>(a);
-    else if (pg == 6) ekf_paged_lds_kernel<6><<<grid, kWaves * 64, 0, stream>>>(a);
-    else ekf_paged_lds_kernel<8><<<grid, kWaves * 64, 0, stream>>>(a);
+    const bool wide = form == 0 || !a.ol.id || (pg_env <= 0 && touched_hint > 6);
+#define SLAM_PAGED(SP_)                                                                              \
+    do {                                                                                             \
+        if (wide) ekf_paged_kernel<SP_><<<grid, kWaves * 64, 0, stream>>>(a);                        \
+        else if (pg <= 1) ekf_paged_lds_kernel<1, SP_><<<grid, kWaves * 64, 0, stream>>>(a);         \
+        else if (pg == 2) ekf_paged_lds_kernel<2, SP_><<<grid, kWaves * 64, 0, stream>>>(a);         \
+        else if (pg == 3) ekf_paged_lds_kernel<3, SP_><<<grid, kWaves * 64, 0, stream>>>(a);         \
+        else if (pg == 4) ekf_paged_lds_kernel<4, SP_><<<grid, kWaves * 64, 0, stream>>>(a);         \
+        else if (pg == 5) ekf_paged_lds_kernel<5, SP_><<<grid, kWaves * 64, 0, stream>>>(a);         \
+        else if (pg == 6) ekf_paged_lds_kernel<6, SP_><<<grid, kWaves * 64, 0, stream>>>(a);         \
+        else ekf_paged_lds_kernel<8, SP_><<<grid, kWaves * 64, 0, stream>>>(a);                      \
+    } while (0)
+    if (a.geom.planes == 2) SLAM_PAGED(true);
+    else SLAM_PAGED(false);
+#undef SLAM_PAGED
     if (ev) (void)hipEventRecord(ev->stop, stream);
     return hipGetLastError();
 }
@@ -699,10 +787,10 @@ hipError_t launch_migrate_unpack_paged(hipStream_t stream, const float* in, int 
 
 hipError_t launch_pages_from_rows(hipStream_t stream, const float* rows, int64_t row_stride, int plane_stride, int nlandmarks,
                                   int nb, int n, float* pool, int32_t* pt, int32_t* freelist, int npages, int32_t* pool_state,
-                                  int page_base)
+                                  int page_base, const PageGeom& geom)
 {
     pages_from_rows_kernel<<<blocks256((int64_t)n * nb * kPage), 256, 0, stream>>>(rows, row_stride, plane_stride, nlandmarks, nb, n,
-                                                                                  pool, pt, page_base);
+                                                                                  pool, pt, page_base, geom);
     const int used = n * nb;   // the tables name pages page_base .. page_base + n * nb - 1: the rest is free
     const int after = page_base + used;
     free_iota_kernel<<<blocks256(npages > used ? npages - used : 1), 256, 0, stream>>>(freelist, page_base, after, npages - after,
@@ -711,19 +799,29 @@ hipError_t launch_pages_from_rows(hipStream_t stream, const float* rows, int64_t
 }
 
 hipError_t launch_rows_from_pages(hipStream_t stream, const float* pool, const int32_t* pt, int nb, const int32_t* anc, int n,
-                                  float* rows, int64_t row_stride, int plane_stride, int nlandmarks)
+                                  float* rows, int64_t row_stride, int plane_stride, int nlandmarks, const PageGeom& geom)
 {
     rows_from_pages_kernel<<<blocks256((int64_t)n * nb * kPage), 256, 0, stream>>>(pool, pt, nb, anc, n, rows, row_stride,
-                                                                                  plane_stride, nlandmarks);
+                                                                                  plane_stride, nlandmarks, geom);
+    return hipGetLastError();
+}
+
+hipError_t launch_rows_from_split_pages(hipStream_t stream, const float* pool, const PageGeom& geom, const int32_t* pt, int nb,
+                                        const float* cov, const int32_t* cls, int Lp, const int32_t* idx, int count, float* rows,
+                                        int64_t row_stride, int plane_stride, int nlandmarks)
+{
+    if (count <= 0) return hipSuccess;
+    rows_from_split_pages_kernel<<<count, 256, 0, stream>>>(pool, geom, pt, nb, cov, cls, Lp, idx, count, rows, row_stride, plane_stride,
+                                                           nlandmarks);
     return hipGetLastError();
 }
 
 hipError_t launch_pages_reset(hipStream_t stream, float* pool, int32_t* pt, int64_t nentries, int32_t* freelist, int npages,
-                              int32_t* pool_state)
+                              int32_t* pool_state, const PageGeom& geom)
 {
     const int64_t m = nentries > npages ? nentries : npages;
     pages_reset_kernel<<<blocks256(m > kPageFloats ? m : kPageFloats), 256, 0, stream>>>(pool, pt, nentries, freelist, npages,
-                                                                                     pool_state);
+                                                                                     pool_state, geom.planes);
     return hipGetLastError();
 }
 

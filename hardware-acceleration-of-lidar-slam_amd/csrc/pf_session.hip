@@ -410,6 +410,21 @@ void place_split(slam_pf* pf, int base)
 
 int32_t* split_h_live(slam_pf* pf) { return reinterpret_cast<int32_t*>(pf->d_hres) + 22; }   // {classes in use, epoch}
 
+// ---- SPLIT PAGES (paged && split): the means on copy-on-write pages of two planes (256 bytes), the covariances per class as
+// on the split layout.  The pages live in the session's two mean buffers (2 x cap x nb pages, exactly their size), which are
+// not neighbours in the store: pages below cap x nb in the buffer at the lower address, the others in the other one.
+float* split_pool(const slam_pf* pf) { return pf->mean[0] < pf->mean[1] ? pf->mean[0] : pf->mean[1]; }
+PageGeom split_geom(const slam_pf* pf)
+{
+    PageGeom g;
+    g.planes = 2;
+    g.half_pages = (int64_t)pf->cap * pf->nb;
+    const float *lo = split_pool(pf), *hi = pf->mean[0] < pf->mean[1] ? pf->mean[1] : pf->mean[0];
+    g.gap = (hi - lo) - g.half_pages * 2 * kPageLandmarks;
+    return g;
+}
+bool split_pages(const slam_pf* pf) { return pf->paged && pf->split; }
+
 // a new set of classes is about to be made (set_map, reset, rows -> split): lists and counters start afresh
 void split_new_epoch(slam_pf* pf)
 {
@@ -466,6 +481,53 @@ int convert_split_to_rows(slam_pf* pf)
     return SLAM_OK;
 }
 
+// split -> split pages: the means of the current buffer become pages in the OTHER mean buffer (identity tables, shifted),
+// the buffer they came from becomes free pages; classes and covariances stay where they are.  One stream-ordered launch.
+int convert_split_to_split_pages(slam_pf* pf)
+{
+    slam_engine* e = pf->e;
+    const float* src = pf->mean[pf->sp_cur];
+    const float* dst = pf->mean[1 - pf->sp_cur];
+    const int page_base = dst == split_pool(pf) ? 0 : pf->cap * pf->nb;
+    pf->pt_cur = 0;
+    SLAM_HIP_TRY(e, launch_pages_from_rows(e->stream, src, 2 * (int64_t)pf->Lp, pf->Lp, pf->L, pf->nb, pf->n, split_pool(pf), pf->pt[0],
+                                           pf->freelist, pf->npages, pf->page_scratch, page_base, split_geom(pf)));
+    pf->paged = true;
+    pf->conversions++;
+    return SLAM_OK;
+}
+
+// split pages -> split: the pages lie anywhere in the two mean buffers, so the rows are put together in the scratch buffer of
+// convert_to_rows first and copied into mean[0]
+int convert_split_pages_to_split(slam_pf* pf)
+{
+    slam_engine* e = pf->e;
+    const size_t used = 2 * (size_t)pf->Lp * (size_t)pf->n;
+    if (pf->conv_floats < used) {
+        if (pf->conv_tmp) {
+            SLAM_HIP_TRY(e, hipStreamSynchronize(e->stream));
+            (void)hipFree(pf->conv_tmp);
+        }
+        pf->conv_tmp = nullptr;
+        pf->conv_floats = 0;
+        if (hipMalloc((void**)&pf->conv_tmp, used * 4) != hipSuccess) {
+            (void)hipGetLastError();
+            pf->conv_tmp = nullptr;
+            pf->auto_stuck = true;
+            return SLAM_OK;
+        }
+        pf->conv_floats = used;
+    }
+    SLAM_HIP_TRY(e, launch_rows_from_pages(e->stream, split_pool(pf), pf->pt[pf->pt_cur], pf->nb, nullptr, pf->n, pf->conv_tmp,
+                                           2 * (int64_t)pf->Lp, pf->Lp, pf->L, split_geom(pf)));
+    SLAM_HIP_TRY(e, hipMemcpyAsync(pf->mean[0], pf->conv_tmp, used * 4, hipMemcpyDeviceToDevice, e->stream));
+    if (pf->sp_cur == 1) SLAM_HIP_TRY(e, hipMemcpyAsync(pf->cls[0], pf->cls[1], (size_t)pf->n * 4, hipMemcpyDeviceToDevice, e->stream));
+    pf->sp_cur = 0;
+    pf->paged = false;
+    pf->conversions++;
+    return SLAM_OK;
+}
+
 // SLAM_MAP_AUTO, at the start of a frame: look at the counts that have arrived since the last look (no waiting) and move
 // when the last three agree.  Pages pay when a frame observes at most a quarter of the landmarks (a resampling frame on
 // rows rewrites every row in full); rows pay when it observes more than half (every page is touched anyway and the row
@@ -491,11 +553,13 @@ int auto_layout(slam_pf* pf)
     pf->votes_pages = h[3];   // samples in a row (counted on the device, so none is missed however far the host runs ahead)
     pf->votes_rows = h[4];
     if (!pf->paged && pf->votes_pages >= 3) {
+        if (pf->split && !pf->comm) return convert_split_to_split_pages(pf);   // the means go onto pages, the classes stay
         if (pf->split)
             if (int rc = convert_split_to_rows(pf)) return rc;
         return convert_to_pages(pf);
     }
     if (pf->paged && pf->votes_rows >= 3) {
+        if (pf->split) return convert_split_pages_to_split(pf);
         if (int rc = convert_to_rows(pf)) return rc;
         if (!pf->paged && pf->dense_split) return convert_rows_to_split(pf);
     }
@@ -505,8 +569,12 @@ int auto_layout(slam_pf* pf)
 int create_common(slam_engine* e, const slam_pf_config* cfg, slam_comm* comm, int recv_capacity, slam_pf** out)
 {
     if (!e || !cfg || !out || cfg->n_particles <= 0 || cfg->n_landmarks < 0 || !(cfg->meas_var > 0.0f) ||
-        cfg->map_layout < SLAM_MAP_AUTO || cfg->map_layout > SLAM_MAP_SPLIT)
+        cfg->map_layout < SLAM_MAP_AUTO || cfg->map_layout > SLAM_MAP_SPLIT_PAGES)
         return SLAM_ERR_INVALID_ARG;
+    if (comm && cfg->map_layout == SLAM_MAP_SPLIT_PAGES) {
+        snprintf(e->err, sizeof e->err, "SLAM_MAP_SPLIT_PAGES: one GPU only (a sharded session's AUTO uses pages of whole landmarks)");
+        return SLAM_ERR_INVALID_ARG;
+    }
 
     *out = nullptr;
     if (e->live_sessions > 0) {   // the stages keep per-population state in the engine (gate, carried weights, exchange plan)
@@ -538,7 +606,7 @@ int create_common(slam_engine* e, const slam_pf_config* cfg, slam_comm* comm, in
     bool ok = true;
     // slam_pf_paged_set(e, 1) turns an AUTO request into PAGES (sessions made while it is set stay on pages)
     pf->layout_cfg = cfg->map_layout == SLAM_MAP_AUTO && e->pf_paged ? (int)SLAM_MAP_PAGES : cfg->map_layout;
-    pf->paged = pf->L > 0 && pf->layout_cfg == SLAM_MAP_PAGES;
+    pf->paged = pf->L > 0 && (pf->layout_cfg == SLAM_MAP_PAGES || pf->layout_cfg == SLAM_MAP_SPLIT_PAGES);
     pf->nb = pf->Lp / kPageLandmarks;
     {
         const int64_t np = 2 * (int64_t)pf->cap * pf->nb;   // table rows (with the staging tail) never name more than half
@@ -557,9 +625,10 @@ int create_common(slam_engine* e, const slam_pf_config* cfg, slam_comm* comm, in
     if (L) ok = alloc_store(pf);
     // the split layout: asked for, or what AUTO keeps a session that resamples every frame on while its frames observe most
     // landmarks (a gated one updates in place, which rows do)
-    if (L && ok && (pf->layout_cfg == SLAM_MAP_SPLIT || (pf->layout_cfg == SLAM_MAP_AUTO && !pf->gated))) {
+    const bool want_split = pf->layout_cfg == SLAM_MAP_SPLIT || pf->layout_cfg == SLAM_MAP_SPLIT_PAGES;
+    if (L && ok && (want_split || (pf->layout_cfg == SLAM_MAP_AUTO && !pf->gated))) {
         const bool have = alloc_split_tables(pf);
-        if (!have && pf->layout_cfg == SLAM_MAP_SPLIT) ok = false;
+        if (!have && want_split) ok = false;
         pf->dense_split = have && pf->layout_cfg == SLAM_MAP_AUTO;
         pf->split = have;
         if (have) place_split(pf, 0);
@@ -675,6 +744,9 @@ int slam_pf_reset(slam_pf* pf, const float pose[3])
         split_new_epoch(pf);
         SLAM_HIP_TRY(pf->e, launch_split_reset(pf->e->stream, pf->mean[pf->sp_cur], pf->cov, pf->covx, pf->cls[pf->sp_cur], pf->Lp, pf->n,
                                                pf->live[0], pf->cov_cnt, 0, pf->cstamp, pf->cstamp_now, split_h_live(pf), pf->cls_epoch));
+        if (pf->paged)   // split pages: every particle names ONE shared page of zero means, the rest of the pool is free
+            SLAM_HIP_TRY(pf->e, launch_pages_reset(pf->e->stream, split_pool(pf), pf->pt[pf->pt_cur], (int64_t)pf->n * pf->nb, pf->freelist,
+                                                   pf->npages, pf->page_scratch, split_geom(pf)));
         if (int rc = slam_engine_sync(pf->e)) return rc;
     } else if (pf->paged) {   // every particle names ONE shared page of landmarks not seen yet
         SLAM_HIP_TRY(pf->e, launch_pages_reset(pf->e->stream, pf->pool, pf->pt[pf->pt_cur], (int64_t)pf->n * pf->nb, pf->freelist,
@@ -739,6 +811,14 @@ int slam_pf_set_map_dev(slam_pf* pf, const float* d_rows, int64_t row_stride, in
     if (pf->has_anc) return SLAM_ERR_NOT_READY;   // set poses / reset first: a gather is pending
     slam_engine* e = pf->e;
     SLAM_HIP_TRY(e, hipSetDevice(e->device));
+    if (pf->split && pf->paged) {   // split pages: classes and mean rows first, then the means onto pages
+        pf->paged = false;
+        pf->sp_cur = 0;
+        if (int rc = split_from_rows(pf, d_rows, row_stride, plane_stride, pf->n)) return rc;
+        if (int rc = convert_split_to_split_pages(pf)) return rc;
+        pf->conversions--;
+        return SLAM_OK;
+    }
     if (pf->split) return split_from_rows(pf, d_rows, row_stride, plane_stride, pf->n);
     if (pf->paged) {
         SLAM_HIP_TRY(e, launch_pages_from_rows(e->stream, d_rows, row_stride, plane_stride, pf->L, pf->nb, pf->n, pf->pool,
@@ -910,7 +990,7 @@ static int pf_step_impl(slam_pf* pf, int slot, const float dp[3], int use_observ
     const bool ekf = L > 0 && use_observations;
     const int mc = pf->map_cur, mn = 1 - mc;
     float* d_max = comm ? pf->d_max : nullptr;
-    if (pf->split && L > 0) {
+    if (pf->split && !pf->paged && L > 0) {
         const int sc = pf->sp_cur;
         make_sio();   // (again: a layout move in front of the frame leaves other buffers than the ones the first look saw)
         if (ekf) {
@@ -975,6 +1055,17 @@ static int pf_step_impl(slam_pf* pf, int slot, const float dp[3], int use_observ
             a.tmask = tmask;
             a.tbase = tbase;
             a.pool = pf->pool;
+            if (pf->split) {   // split pages: mean pages of two planes, the covariances per class
+                a.geom = split_geom(pf);
+                a.pool = split_pool(pf);
+                a.cov = pf->cov;
+                a.covx = pf->covx;
+                a.plane_stride = pf->Lp;
+                a.cls_in = pf->cls[pf->sp_cur];
+                a.cls_out = pf->cls[1 - pf->sp_cur];
+                a.cstamp = pf->cstamp;
+                a.cstamp_now = pf->cstamp_now + 1;
+            }
             a.pt_in = pf->pt[pc];
             a.pt_out = pf->pt[1 - pc];
             a.nb = pf->nb;
@@ -1001,6 +1092,11 @@ static int pf_step_impl(slam_pf* pf, int slot, const float dp[3], int use_observ
                                              __atomic_load_n(reinterpret_cast<int32_t*>(pf->h_res) + 30, __ATOMIC_RELAXED)));
             e->ll_n = n;
             pf->pt_cur = 1 - pc;
+            if (pf->split) {   // the classes went with their particles; their covariances, once per class
+                pf->cstamp_now++;
+                pf->sp_cur = 1 - pf->sp_cur;
+                if ((rc = split_class_update(pf, L)) != SLAM_OK) return rc;
+            }
             rc = slam_logweight_ekf_dev(e, pf->score, pf->cfg.score_gain, n, pf->logw, d_max);
         } else {
             if (anc) {   // the tables follow their particles
@@ -1008,6 +1104,12 @@ static int pf_step_impl(slam_pf* pf, int slot, const float dp[3], int use_observ
                 SLAM_HIP_TRY(e, launch_page_table_gather(e->stream, pf->pt[pc], pf->pt[1 - pc], pf->nb, anc, n, pf->stamp,
                                                          ++pf->stamp_now));
                 pf->pt_cur = 1 - pc;
+                if (pf->split) {   // ... and so do the classes
+                    SLAM_HIP_TRY(e, launch_class_gather(e->stream, pf->cls[pf->sp_cur], pf->cls[1 - pf->sp_cur], anc, n, pf->cstamp,
+                                                        ++pf->cstamp_now));
+                    pf->sp_cur = 1 - pf->sp_cur;
+                    if ((rc = split_class_update(pf, 0)) != SLAM_OK) return rc;
+                }
             }
             rc = slam_logweight_dev(e, pf->score, nullptr, pf->cfg.score_gain, n, pf->logw, d_max);
         }
@@ -1093,13 +1195,13 @@ int slam_pf_device_view(slam_pf* pf, slam_pf_view* out)
 int slam_pf_layout(const slam_pf* pf)
 {
     if (!pf || !pf->L) return SLAM_MAP_ROWS;
-    return pf->paged ? SLAM_MAP_PAGES : pf->split ? SLAM_MAP_SPLIT : SLAM_MAP_ROWS;
+    return pf->paged ? (pf->split ? SLAM_MAP_SPLIT_PAGES : SLAM_MAP_PAGES) : pf->split ? SLAM_MAP_SPLIT : SLAM_MAP_ROWS;
 }
 
 int slam_pf_split_device_view(slam_pf* pf, slam_pf_split_view* out)
 {
     if (!pf || !out) return SLAM_ERR_INVALID_ARG;
-    if (!pf->split || !pf->L) return SLAM_ERR_NOT_READY;
+    if (!pf->split || pf->paged || !pf->L) return SLAM_ERR_NOT_READY;   // (split pages: the means are not rows)
     out->mean = pf->mean[pf->sp_cur];
     out->cov = pf->cov;
     out->cls = pf->cls[pf->sp_cur];
@@ -1113,7 +1215,7 @@ int slam_pf_split_device_view(slam_pf* pf, slam_pf_split_view* out)
 int slam_pf_paged_device_view(slam_pf* pf, slam_pf_paged_view* out)
 {
     if (!pf || !out) return SLAM_ERR_INVALID_ARG;
-    if (!pf->paged) return SLAM_ERR_NOT_READY;
+    if (!pf->paged || pf->split) return SLAM_ERR_NOT_READY;   // (split pages: pages of two planes in two buffers, not this view's shape)
     out->pool = pf->pool;
     out->table = pf->pt[pf->pt_cur];
     out->freelist = pf->freelist;
@@ -1260,7 +1362,9 @@ static int slam_pf_get_map_host_impl(slam_pf* pf, float* rows)
         if (hipMalloc((void**)&dense, 5 * Lp * n * 4) != hipSuccess) return SLAM_ERR_HIP;
         int rc = SLAM_OK;
         const int32_t* idx = pf->has_anc ? pf->anc[pf->cur] : nullptr;
-        if ((pf->split ? launch_rows_from_split(pf->e->stream, pf->mean[pf->sp_cur], pf->cov, pf->cls[pf->sp_cur], pf->Lp, idx, pf->n, dense,
+        if ((split_pages(pf) ? launch_rows_from_split_pages(pf->e->stream, split_pool(pf), split_geom(pf), pf->pt[pf->pt_cur], pf->nb, pf->cov,
+                                                            pf->cls[pf->sp_cur], pf->Lp, idx, pf->n, dense, 5 * (int64_t)Lp, pf->Lp, pf->L)
+             : pf->split ? launch_rows_from_split(pf->e->stream, pf->mean[pf->sp_cur], pf->cov, pf->cls[pf->sp_cur], pf->Lp, idx, pf->n, dense,
                                                 5 * (int64_t)Lp, pf->Lp, pf->L)
                        : launch_rows_from_pages(pf->e->stream, pf->pool, pf->pt[pf->pt_cur], pf->nb, idx, pf->n, dense, 5 * (int64_t)Lp,
                                                 pf->Lp, pf->L)) != hipSuccess)
@@ -1318,7 +1422,10 @@ static int slam_pf_get_map_rows_host_impl(slam_pf* pf, const int32_t* particle, 
     };
     if (ok(hipMemcpyAsync(sel, particle, sizeof(int32_t) * (size_t)count, hipMemcpyHostToDevice, e->stream), "copy of the particle list") &&
         ok(launch_compose_index(e->stream, sel, pf->has_anc ? pf->anc[pf->cur] : nullptr, count, src), "compose_index")) {
-        if (pf->split)
+        if (split_pages(pf))
+            ok(launch_rows_from_split_pages(e->stream, split_pool(pf), split_geom(pf), pf->pt[pf->pt_cur], pf->nb, pf->cov, pf->cls[pf->sp_cur],
+                                            pf->Lp, src, count, dense, 5 * (int64_t)Lp, pf->Lp, pf->L), "rows_from_split_pages");
+        else if (pf->split)
             ok(launch_rows_from_split(e->stream, pf->mean[pf->sp_cur], pf->cov, pf->cls[pf->sp_cur], pf->Lp, src, count, dense,
                                       5 * (int64_t)Lp, pf->Lp, pf->L), "rows_from_split");
         else if (pf->paged)

@@ -268,6 +268,17 @@ __global__ __launch_bounds__(256) void migrate_unpack_split_kernel(const float* 
     }
 }
 
+__global__ __launch_bounds__(256) void class_gather_kernel(const int32_t* __restrict__ cls_in, int32_t* __restrict__ cls_out,
+                                                           const int32_t* __restrict__ anc, int n, uint32_t* __restrict__ cstamp,
+                                                           uint32_t stamp_now)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int c = cls_in[anc ? anc[i] : i];
+    cls_out[i] = c;
+    cstamp[c] = stamp_now;
+}
+
 // ---- reset: every landmark of every particle "not seen yet" (P_xx = -1), one class
 __global__ __launch_bounds__(256) void split_reset_kernel(float* __restrict__ mean, float* __restrict__ cov, int32_t* __restrict__ cls,
                                                           int Lp, int n, int32_t* __restrict__ live, int32_t* __restrict__ cnt, int phase,
@@ -354,6 +365,14 @@ hipError_t launch_split_gather(hipStream_t stream, const float* mean_in, float* 
 {
     if (n <= 0) return hipSuccess;
     split_gather_kernel<<<n, 256, 0, stream>>>(mean_in, mean_out, cls_in, cls_out, Lp, anc, n, cstamp, stamp_now);
+    return hipGetLastError();
+}
+
+hipError_t launch_class_gather(hipStream_t stream, const int32_t* cls_in, int32_t* cls_out, const int32_t* anc, int n, uint32_t* cstamp,
+                               uint32_t stamp_now)
+{
+    if (n <= 0) return hipSuccess;
+    class_gather_kernel<<<blocks256(n), 256, 0, stream>>>(cls_in, cls_out, anc, n, cstamp, stamp_now);
     return hipGetLastError();
 }
 

@@ -430,7 +430,11 @@ typedef struct {
  * observes most landmarks) or COPY-ON-WRITE PAGES behind a page table per particle (a resampling frame copies table
  * entries and rewrites only the pages that hold an observed landmark: the fastest form when a frame observes few of
  * many).  Both give the same bits.  SLAM_MAP_AUTO lets the session choose and change its mind while it runs. */
-typedef enum { SLAM_MAP_AUTO = 0, SLAM_MAP_ROWS = 1, SLAM_MAP_PAGES = 2, SLAM_MAP_SPLIT = 3 } slam_map_layout;
+typedef enum { SLAM_MAP_AUTO = 0, SLAM_MAP_ROWS = 1, SLAM_MAP_PAGES = 2, SLAM_MAP_SPLIT = 3, SLAM_MAP_SPLIT_PAGES = 4 } slam_map_layout;
+/* SLAM_MAP_SPLIT_PAGES (round 4; one GPU): the split layout with the MEANS on copy-on-write pages of 32 landmarks x 2 planes
+ * (256 bytes) and the covariances per class as in SLAM_MAP_SPLIT — what SLAM_MAP_AUTO moves a single-GPU session to when its
+ * frames observe few of many landmarks: a resampling frame copies table entries, rewrites only the mean pages that hold an
+ * observed landmark and updates each class's covariances once.  The same bits. */
 /* SLAM_MAP_SPLIT (round 4): MEANS per particle, COVARIANCES per covariance class.  The landmark update is carried out in the
  * world frame (see slam_ekf_update_dev): the posterior covariance of a landmark depends on its prior covariance, on meas_var
  * and on whether the frame observes it — never on the particle's pose or on the measurement.  Particles whose covariances are
@@ -517,7 +521,7 @@ int slam_pf_set_map_dev(slam_pf *pf, const float *d_rows, int64_t row_stride, in
  * (as if created with SLAM_MAP_PAGES); 0 restores AUTO's own choice.  slam_pf_is_paged: the layout right now. */
 int slam_pf_paged_set(slam_engine *e, int on);
 int slam_pf_is_paged(const slam_pf *pf);
-/* the layout right now: SLAM_MAP_ROWS, SLAM_MAP_PAGES or SLAM_MAP_SPLIT */
+/* the layout right now: SLAM_MAP_ROWS, SLAM_MAP_PAGES, SLAM_MAP_SPLIT or SLAM_MAP_SPLIT_PAGES */
 int slam_pf_layout(const slam_pf *pf);
 /* one frame against grid `slot`; asynchronous */
 int slam_pf_step(slam_pf *pf, int slot, const float dp[3], int use_observations);

@@ -52,7 +52,7 @@ def _maps(n, L, lm, cov, seed=17):
     return x, y, th, mp
 
 
-def _run(layout, n, L, frames, cov="own", fused=True, form=-1, nbeams=None, skip_obs=(), inspect=False):
+def _run(layout, n, L, frames, cov="own", fused=True, form=-1, nbeams=None, skip_obs=(), inspect=False, sparse=0):
     import _shard_worker as W
 
     pkg = load_package()
@@ -80,6 +80,8 @@ def _run(layout, n, L, frames, cov="own", fused=True, form=-1, nbeams=None, skip
     rng = np.random.default_rng(5)
     for f in range(frames):
         ids = np.sort(rng.choice(L, size=(L if f % 3 else max(L // 3, 1)), replace=False)).astype(np.int32)   # all, or a third
+        if sparse and f % 4:   # `sparse` neighbours somewhere in the map on three frames of four
+            ids = np.unique((np.arange(sparse) + 37 * f) % L).astype(np.int32)
         z = lm[ids] + np.float32(0.01) * np.float32(f % 5)
         eng.obs_upload(ids, z[:, 0].copy(), z[:, 1].copy(), L)
         ses.step(0, [0.01, -0.005, 0.002], f not in skip_obs)
@@ -252,8 +254,56 @@ def test_sharded_auto_is_split_and_sharded_split_with_map_reads():
         assert np.array_equal(bits(got), bits(ref["frame_maps"][f])), f
 
 
+@pytest.mark.parametrize("n,L,cov,sparse,skip", [
+    (8192, 400, "own", 12, ()), (8192, 400, "shared", 12, (3, 4)), (5000, 513, "families", 40, (6,)), (3000, 1100, "families", 5, ()),
+    (4097, 31, "own", 3, (2,)), (20000, 96, "families", 0, ()),
+])
+def test_split_pages_give_the_bits_of_rows(n, L, cov, sparse, skip):
+    """SLAM_MAP_SPLIT_PAGES: the means on copy-on-write pages of two planes, the covariances per class.  Frames that observe
+    a few neighbours (the list form of the paged update), a third or all landmarks (its page-wide form) and nothing (tables
+    and classes follow their particles): the bits of a row session."""
+    kw = dict(cov=cov, sparse=sparse, skip_obs=skip)
+    pages = _run("split_pages", n, L, 11, **kw)
+    assert set(pages["layout"]) == {"split_pages"}
+    _same(pages, _run("rows", n, L, 11, **kw))
+
+
+def test_split_pages_map_io():
+    """set_map / map getters / reset on split pages; the views of the other layouts refuse."""
+    import _shard_worker as W
+
+    pkg = load_package()
+    n, L = 3000, 200
+    meta, edt, bx, by, lm = W.make_world(L=L)
+    x, y, th, mp = _maps(n, L, lm, "families")
+    eng = pkg.Engine(0)
+    ses = pkg.PfSession(eng, n, L, seed=3, sigma=(0.02, 0.02, 0.004), meas_var=0.02, score_gain=0.05, map_layout="split_pages")
+    assert ses.layout() == "split_pages" and ses.is_paged()
+    fresh = ses.maps()
+    assert np.all(fresh[:, 2] == -1.0) and np.all(fresh[:, [0, 1, 3, 4]] == 0.0)
+    ses.set_map(mp)
+    assert np.array_equal(bits(ses.maps()), bits(mp))
+    sel = np.array([5, 5, 2999, 0, 17], np.int32)
+    assert np.array_equal(bits(ses.map_rows(sel)), bits(mp[sel]))
+    with pytest.raises(pkg.SlamError):
+        ses.split_view()
+    with pytest.raises(pkg.SlamError):
+        ses.paged_view()
+    ses.reset([0.0, 0.0, 0.0])
+    assert np.array_equal(bits(ses.maps()), bits(fresh))
+    ses.close()
+    group = pkg.LocalGroup(1)   # a sharded session (even of one rank) is refused: its AUTO uses pages of whole landmarks
+    comm = pkg.Comm.local(eng, group, 0)
+    with pytest.raises(pkg.SlamError, match="one GPU only"):
+        pkg.PfSession(eng, n, L, comm=comm, map_layout="split_pages")
+    comm.close()
+    group.close()
+    eng.close()
+
+
 def test_auto_moves_between_split_and_pages_and_keeps_the_bits():
-    """The AUTO run of tests/test_gpu_auto_layout.py, looked at from this side: dense frames on split, sparse ones on pages."""
+    """The AUTO run of tests/test_gpu_auto_layout.py, looked at from this side: dense frames on split, sparse ones on split
+    pages (the means move onto pages, the classes stay)."""
     from test_gpu_auto_layout import _run as auto_run
 
     pkg = load_package()
@@ -269,8 +319,8 @@ def test_auto_moves_between_split_and_pages_and_keeps_the_bits():
         auto = auto_run("auto", 4096, 400, 44)
     finally:
         pkg.PfSession.step = step
-    assert seen[0] == "split" and "pages" in seen[:14] and "split" in seen[14:40], seen
-    assert "rows" not in seen
+    assert seen[0] == "split" and "split_pages" in seen[:14] and "split" in seen[14:40], seen
+    assert "rows" not in seen and "pages" not in seen
     rows = auto_run("rows", 4096, 400, 44)
     assert np.array_equal(bits(auto["pose"]), bits(rows["pose"]))
     for f, m in rows["maps"].items():
