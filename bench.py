@@ -759,7 +759,8 @@ def run_rank(args, ctx, inp, last=True):
         key = (f"{args.mode}:{n}:{args.beams}:{L}:{args.grid}" + (":paged" if paged_in_region else "") + (":split" if split_in_region else "")
                + (f":obs{L_obs}" if L_obs != L else "") + (f":ess{args.ess}" if 0 < args.ess < 1 else ""))
         rec = json.loads(tfile.read_text()).get(key, {})
-        if rec.get("kernel", kern).split("<")[0] == kern.split(" ")[0]:
+        rk = rec.get("kernel", kern).split("<")[0]   # (ekf_paged_kernel names the paged update in either of its forms)
+        if rk == kern.split(" ")[0] or (rk.startswith("ekf_paged") and kern.startswith("ekf_paged")):
             traffic, traffic_src = rec.get("bytes_per_launch"), rec.get("source")
             if rec.get("valu_instructions_per_launch"):   # the same record's vector-ALU counters (static, builder-run)
                 valu = {"instructions_per_launch": rec["valu_instructions_per_launch"], "busy_pct": rec.get("valu_busy_pct"),

@@ -546,7 +546,8 @@ class PfPagedView(C.Structure):
 
     _fields_ = [("pool", C.c_void_p), ("table", C.c_void_p), ("freelist", C.c_void_p), ("state", C.c_void_p),
                 ("stamp", C.c_void_p), ("stamp_now", C.c_uint32), ("page_landmarks", C.c_int32),
-                ("pages_per_particle", C.c_int32), ("table_rows", C.c_int32), ("npages", C.c_int64)]
+                ("pages_per_particle", C.c_int32), ("table_rows", C.c_int32), ("npages", C.c_int64),
+                ("planes", C.c_int32), ("reserved", C.c_int32), ("half_pages", C.c_int64), ("gap_floats", C.c_int64)]
 
 
 class DeviceArray:
@@ -677,7 +678,7 @@ class PfSession:
         """``slam_pf_split_device_view``: means, classes, class covariance rows and the list of classes in use."""
         v = PfSplitView()
         self.e._ck(self.e.lib.slam_pf_split_device_view(self.h, C.byref(v)), "pf_split_device_view")
-        return {"mean": DeviceArray(v.mean, (v.rows, 2, v.plane_stride), "<f4", self),
+        return {"mean": DeviceArray(v.mean, (v.rows, 2, v.plane_stride), "<f4", self) if v.mean else None,   # None: split pages
                 "cov": DeviceArray(v.cov, (v.rows, 3, v.plane_stride), "<f4", self),
                 "cls": DeviceArray(v.cls, (v.rows,), "<i4", self), "live": DeviceArray(v.live, (v.rows,), "<i4", self),
                 "live_count": DeviceArray(v.live_count, (1,), "<i4", self), "plane_stride": v.plane_stride}
@@ -687,7 +688,12 @@ class PfSession:
         v = PfPagedView()
         self.e._ck(self.e.lib.slam_pf_paged_device_view(self.h, C.byref(v)), "pf_paged_device_view")
         P, nb = int(v.npages), v.pages_per_particle
-        return {"pool": DeviceArray(v.pool, (P, 5, v.page_landmarks), "<f4", self),
+        if v.planes == 2:   # split pages: two buffers of half_pages pages of [2][page_landmarks] floats, gap_floats apart
+            H, pf_ = int(v.half_pages), 2 * v.page_landmarks
+            pool = [DeviceArray(v.pool + 4 * k * (H * pf_ + int(v.gap_floats)), (H, 2, v.page_landmarks), "<f4", self) for k in (0, 1)]
+        else:
+            pool = DeviceArray(v.pool, (P, 5, v.page_landmarks), "<f4", self)
+        return {"pool": pool, "planes": v.planes, "half_pages": int(v.half_pages),
                 "table": DeviceArray(v.table, (v.table_rows, nb), "<i4", self),
                 "freelist": DeviceArray(v.freelist, (P,), "<i4", self), "state": DeviceArray(v.state, (4,), "<i4", self),
                 "stamp": DeviceArray(v.stamp, (P,), "<i4", self), "stamp_now": int(v.stamp_now),

@@ -1201,8 +1201,8 @@ int slam_pf_layout(const slam_pf* pf)
 int slam_pf_split_device_view(slam_pf* pf, slam_pf_split_view* out)
 {
     if (!pf || !out) return SLAM_ERR_INVALID_ARG;
-    if (!pf->split || pf->paged || !pf->L) return SLAM_ERR_NOT_READY;   // (split pages: the means are not rows)
-    out->mean = pf->mean[pf->sp_cur];
+    if (!pf->split || !pf->L) return SLAM_ERR_NOT_READY;
+    out->mean = pf->paged ? nullptr : pf->mean[pf->sp_cur];   // split pages: the means are on pages (slam_pf_paged_device_view)
     out->cov = pf->cov;
     out->cls = pf->cls[pf->sp_cur];
     out->live = pf->live[pf->live_cur];
@@ -1215,8 +1215,13 @@ int slam_pf_split_device_view(slam_pf* pf, slam_pf_split_view* out)
 int slam_pf_paged_device_view(slam_pf* pf, slam_pf_paged_view* out)
 {
     if (!pf || !out) return SLAM_ERR_INVALID_ARG;
-    if (!pf->paged || pf->split) return SLAM_ERR_NOT_READY;   // (split pages: pages of two planes in two buffers, not this view's shape)
-    out->pool = pf->pool;
+    if (!pf->paged) return SLAM_ERR_NOT_READY;
+    const PageGeom g = pf->split ? split_geom(pf) : PageGeom();
+    out->pool = pf->split ? split_pool(pf) : pf->pool;
+    out->planes = g.planes;
+    out->reserved = 0;
+    out->half_pages = pf->split ? g.half_pages : (int64_t)pf->npages;
+    out->gap_floats = g.gap;
     out->table = pf->pt[pf->pt_cur];
     out->freelist = pf->freelist;
     out->state = pf->page_scratch;

@@ -576,7 +576,10 @@ int slam_pf_get_map_rows_host(slam_pf *pf, const int32_t *particle, int count, f
  *   pool[npages][5][page_landmarks]  the pages;  table[table_rows][pages_per_particle]: page of (particle, block) for the
  *   CURRENT particles before the pending gather (rows n_particles .. table_rows - 1: staging rows of a sharded session);
  *   stamp[npages]: pages named by the current tables carry stamp_now;  freelist[]: entries [state[1], state[0]) are pages
- *   nobody names, entries [state[3], state[1]) were handed out by the last update;  state = {free, used, renewed, base}. */
+ *   nobody names, entries [state[3], state[1]) were handed out by the last update;  state = {free, used, renewed, base}.
+ * SLAM_MAP_SPLIT_PAGES: planes = 2 (a page holds mu_x | mu_y of its 32 landmarks; the covariances are the class's:
+ * slam_pf_split_device_view), and the pool is two buffers: page p starts at float offset
+ * p * planes * page_landmarks + (p >= half_pages ? gap_floats : 0) from `pool`.  Joint pages: planes = 5, gap_floats = 0. */
 typedef struct {
     const float *pool;
     const int32_t *table, *freelist, *state;
@@ -584,13 +587,16 @@ typedef struct {
     uint32_t stamp_now;
     int32_t page_landmarks, pages_per_particle, table_rows;
     int64_t npages;
+    int32_t planes, reserved;
+    int64_t half_pages, gap_floats;
 } slam_pf_paged_view;
 int slam_pf_paged_device_view(slam_pf *pf, slam_pf_paged_view *out);
 
 /* Inspection of a session that is on the split layout right now (tests, debugging; SLAM_ERR_NOT_READY otherwise).  Device
  * pointers, valid until the next slam_pf_* call: mean[rows][2][plane_stride] and cls[rows] of the CURRENT particles before the
  * pending gather; cov[..][3][plane_stride]: row c = the covariance planes of class c; live[0 .. *live_count): the classes in use
- * as of the last landmark update (a superset of those the current particles name). */
+ * as of the last landmark update (a superset of those the current particles name).  SLAM_MAP_SPLIT_PAGES: mean == NULL (the
+ * means are on pages: slam_pf_paged_device_view), the rest as described. */
 typedef struct {
     const float *mean, *cov;
     const int32_t *cls, *live, *live_count;

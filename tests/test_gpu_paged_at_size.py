@@ -14,6 +14,11 @@ Whole-pool properties after every frame:
   * the rest of the free list names no page a table names, and a free list made anew holds exactly the pages that did not
     carry the previous frame's stamp: named + free = pool.
 Every run makes its free list anew at least once (asserted).
+
+Round 4: the same on SPLIT PAGES (SLAM_MAP_SPLIT_PAGES: the means on pages of two planes in the session's two mean buffers,
+the covariances in the rows of the particle's covariance class): the prior is put together from the mean pages through the
+table and from the class row through the particle's class number, both read before the step; the pool properties are those
+of the mean pages.
 """
 import numpy as np
 import pytest
@@ -32,12 +37,20 @@ def _tensor(a, dtype=None):
     return t if dtype is None else t.view(dtype)
 
 
-def _rows_through_tables(pv, slots):
-    """[len(slots)][5][nb * page] landmarks of table rows `slots`, assembled with torch from pool and table."""
-    table, pool = _tensor(pv["table"]), _tensor(pv["pool"])
+def _rows_through_tables(pv, slots, sv=None):
+    """[len(slots)][5][nb * page] landmarks of table rows `slots`, assembled with torch from pool and table (split pages:
+    means from the two halves of the pool, covariances from the class rows of `sv` = slam_pf_split_device_view)."""
+    table = _tensor(pv["table"])
     pages = table[slots.long()].long()                       # [S][nb]
-    r = pool[pages]                                          # [S][nb][5][page]
-    return r.permute(0, 2, 1, 3).reshape(len(slots), 5, -1)
+    if pv["planes"] == 5:
+        r = _tensor(pv["pool"])[pages]                       # [S][nb][5][page]
+        return r.permute(0, 2, 1, 3).reshape(len(slots), 5, -1)
+    H = pv["half_pages"]
+    lo, hi = (_tensor(b) for b in pv["pool"])
+    m = torch.where((pages < H)[:, :, None, None], lo[pages.clamp(max=H - 1)], hi[(pages - H).clamp(min=0)])   # [S][nb][2][page]
+    m = m.permute(0, 2, 1, 3).reshape(len(slots), 2, -1)
+    cov = _tensor(sv["cov"])[_tensor(sv["cls"])[slots.long()].long()]                                           # [S][3][Lp]
+    return torch.cat([m, cov], dim=1)
 
 
 def _observations(frame, L, K, rng):
@@ -52,7 +65,7 @@ def _observations(frame, L, K, rng):
     return ids, zx, zy
 
 
-def _paged_frames(orc, n, L, K, frames, nsample, snapshot):
+def _paged_frames(orc, n, L, K, frames, nsample, snapshot, layout="pages", family=1):
     import _shard_worker as W
 
     pkg = load_package()
@@ -60,8 +73,9 @@ def _paged_frames(orc, n, L, K, frames, nsample, snapshot):
     eng = pkg.Engine(0)
     eng.grid_set_dev(0, torch.from_numpy(edt).to(DEV), pkg.grid_meta(meta.rows, meta.cols, meta.ld, meta.pixel, meta.min_x, meta.min_y))
     eng.scan_upload(bx, by)
-    ses = pkg.PfSession(eng, n, L, seed=91, sigma=(0.02, 0.02, 0.004), meas_var=MEAS_VAR, score_gain=0.05, map_layout="pages")
-    assert ses.is_paged()
+    ses = pkg.PfSession(eng, n, L, seed=91, sigma=(0.02, 0.02, 0.004), meas_var=MEAS_VAR, score_gain=0.05, map_layout=layout)
+    assert ses.is_paged() and ses.layout() == layout
+    split = layout == "split_pages"
     rng = np.random.default_rng(n + L)
     ses.set_poses(*((s * rng.standard_normal(n)).astype(np.float32) for s in (0.3, 0.3, 0.05)))
     Lp = (L + 31) // 32 * 32
@@ -70,7 +84,8 @@ def _paged_frames(orc, n, L, K, frames, nsample, snapshot):
     for i0 in range(0, n, 32768):                                             # means N(0, 3), covariances A A^T + 0.02 I,
         i1 = min(i0 + 32768, n)                                               # every 10th landmark "not seen yet"
         m0[i0:i1, 0:2, :L] = 3.0 * torch.randn((i1 - i0, 2, L), device=DEV, generator=g)
-        a = 0.3 * torch.randn((i1 - i0, 4, L), device=DEV, generator=g)
+        a = 0.3 * torch.randn(((i1 - i0 + family - 1) // family, 4, L), device=DEV, generator=g)
+        a = a.repeat_interleave(family, dim=0)[:i1 - i0]    # `family` neighbouring particles share their covariances
         m0[i0:i1, 2, :L] = a[:, 0] * a[:, 0] + a[:, 1] * a[:, 1] + 0.02
         m0[i0:i1, 3, :L] = a[:, 0] * a[:, 2] + a[:, 1] * a[:, 3]
         m0[i0:i1, 4, :L] = a[:, 2] * a[:, 2] + a[:, 3] * a[:, 3] + 0.02
@@ -84,7 +99,11 @@ def _paged_frames(orc, n, L, K, frames, nsample, snapshot):
 
     pv = ses.paged_view()
     P, nb, page = pv["npages"], pv["pages_per_particle"], pv["page_landmarks"]
-    assert page * nb == Lp and P == 2 * n * nb
+    assert page * nb == Lp and P == 2 * n * nb and pv["planes"] == (2 if split else 5)
+
+    def pool_bits(pv):   # the whole pool as one [P][planes * page] int32 tensor (a copy)
+        bufs = pv["pool"] if split else [pv["pool"]]
+        return torch.cat([_tensor(b).reshape(-1, pv["planes"] * page).view(torch.int32) for b in bufs]).clone()
     renewals = 0
     for f in range(frames):
         s = np.arange(n) if nsample >= n else np.unique(np.concatenate(
@@ -92,11 +111,13 @@ def _paged_frames(orc, n, L, K, frames, nsample, snapshot):
         d_s = torch.from_numpy(s).to(DEV)
         v = ses.device_view()
         pv = ses.paged_view()
+        sv = ses.split_view() if split else None
+        assert sv is None or sv["mean"] is None
         src = d_s if v["anc"] is None else _tensor(v["anc"])[d_s.long()]      # the ancestors, read BEFORE the step
-        prior = _rows_through_tables(pv, src).cpu().numpy()
+        prior = _rows_through_tables(pv, src, sv).cpu().numpy()
         stamp_before = pv["stamp_now"]
         live_before = int((_tensor(pv["stamp"]) == int(stamp_before)).sum())
-        snap = _tensor(pv["pool"]).clone() if snapshot else None
+        snap = pool_bits(pv) if snapshot else None
         ids, zx, zy = _observations(f, L, K, rng)
         eng.obs_upload(ids, zx, zy, L)
         ses.step(0, [0.01, -0.005, 0.002], True)
@@ -105,8 +126,9 @@ def _paged_frames(orc, n, L, K, frames, nsample, snapshot):
         # ---- the sampled slots against the specification
         v = ses.device_view()
         pv = ses.paged_view()
+        sv = ses.split_view() if split else None
         pose = _tensor(v["pose"])[:, d_s.long()].cpu().numpy()
-        got = _rows_through_tables(pv, d_s).cpu().numpy()
+        got = _rows_through_tables(pv, d_s, sv).cpu().numpy()
         got_ll = _tensor(v["loglik"])[d_s.long()].cpu().numpy()
         want = np.full_like(prior, -777.0)
         want_ll = np.empty(len(s), np.float32)
@@ -136,8 +158,7 @@ def _paged_frames(orc, n, L, K, frames, nsample, snapshot):
         if snap is not None:
             written = torch.zeros(P, dtype=torch.bool, device=DEV)
             written[fresh] = True
-            pool = _tensor(pv["pool"])
-            assert bool(torch.equal(pool[~written].view(torch.int32), snap[~written].view(torch.int32))), "a page not handed out this frame changed"
+            assert bool(torch.equal(pool_bits(pv)[~written], snap[~written])), "a page not handed out this frame changed"
             del snap, written
         del counts, fresh
     assert renewals >= 1, "no frame made the free list anew"
@@ -146,24 +167,33 @@ def _paged_frames(orc, n, L, K, frames, nsample, snapshot):
     torch.cuda.empty_cache()
 
 
-def test_paged_small_population_every_particle_vs_specification(orc):
-    """2 048 x 200, 12 observed: every slot of every frame against the specification, pool snapshot compared."""
-    _paged_frames(orc, 2048, 200, 12, frames=10, nsample=1 << 30, snapshot=True)
+LAYOUTS = pytest.mark.parametrize("layout", ["pages", "split_pages"])
 
 
-def test_paged_64k_x_500_obs32(orc):
-    """BASELINE configs[1] with 32 observed landmarks (the size bench.py --paged --observed 32 is quoted on)."""
-    _paged_frames(orc, 65536, 500, 32, frames=6, nsample=4096, snapshot=True)
+@LAYOUTS
+def test_paged_small_population_every_particle_vs_specification(orc, layout):
+    """2 048 x 200, 12 observed: every slot of every frame against the specification, pool snapshot compared (split pages:
+    every particle starts in a covariance class of its own)."""
+    _paged_frames(orc, 2048, 200, 12, frames=10, nsample=1 << 30, snapshot=True, layout=layout)
 
 
-def test_paged_64k_x_5000_obs32(orc):
+@LAYOUTS
+def test_paged_64k_x_500_obs32(orc, layout):
+    """BASELINE configs[1] with 32 observed landmarks (the size bench.py --observed 32 is quoted on)."""
+    _paged_frames(orc, 65536, 500, 32, frames=6, nsample=4096, snapshot=True, layout=layout, family=16)
+
+
+@LAYOUTS
+def test_paged_64k_x_5000_obs32(orc, layout):
     """65 536 x 5 000 (157 pages per particle, a 20-million-page pool), 32 observed."""
-    _paged_frames(orc, 65536, 5000, 32, frames=12, nsample=4096, snapshot=False)
+    _paged_frames(orc, 65536, 5000, 32, frames=12, nsample=4096, snapshot=False, layout=layout, family=16)
 
 
-def test_paged_north_star_1m_x_1000_obs32(orc):
-    """The north-star size on pages: 1 048 576 x 1 000 (a 67-million-page pool, 43 GB), 32 observed."""
-    _paged_frames(orc, 1048576, 1000, 32, frames=4, nsample=4096, snapshot=False)
+@LAYOUTS
+def test_paged_north_star_1m_x_1000_obs32(orc, layout):
+    """The north-star size on pages: 1 048 576 x 1 000 (a 67-million-page pool, 43 GB; split pages: 17 GB of mean pages),
+    32 observed."""
+    _paged_frames(orc, 1048576, 1000, 32, frames=4, nsample=4096, snapshot=False, layout=layout, family=256)
 
 
 def test_map_rows_of_chosen_particles_and_frame_outputs():
