@@ -1017,7 +1017,7 @@ int slam_ekf_form_counts(slam_engine* e, int64_t counts[2])
 }
 
 static int logweight_common(slam_engine* e, const float* d_score, const float* d_loglik, float score_gain, int n,
-                            float* d_logw, float* d_max)
+                            float* d_logw, float* d_max, const CovArgs* cov = nullptr, int cov_bound = 0)
 {
     if (n <= 0 || !d_logw) return SLAM_ERR_INVALID_ARG;
     if (e->bmax_buf.cap < sizeof(float) * (size_t)logweight_scratch_floats()) {   // block maxima + a ticket word kept at zero
@@ -1028,7 +1028,7 @@ static int logweight_common(slam_engine* e, const float* d_score, const float* d
     // with a resample gate: the weights of a frame that did not resample carry into this one (device-side decision)
     const bool carry = e->gate_frac_q16 != 0 && e->carry_n == n;
     HIP_TRY(launch_logweight(e->stream, d_score, d_loglik, score_gain, n, d_logw, e->bmax_buf.as<float>(), d_max,
-                             carry ? e->carry_buf.as<float>() : nullptr, carry ? e->gate_buf.as<int32_t>() : nullptr));
+                             carry ? e->carry_buf.as<float>() : nullptr, carry ? e->gate_buf.as<int32_t>() : nullptr, cov, cov_bound));
     e->bmax_count = logweight_scratch_elems(n);
     e->bmax_n = n;
     return SLAM_OK;
@@ -1046,6 +1046,16 @@ int slam_logweight_ekf_dev(slam_engine* e, const float* d_score, float score_gai
     ENTER(e);
     if (e->ll_n != n) return SLAM_ERR_NOT_READY;   // needs slam_ekf_update_dev(…, n, …) on this engine first
     return logweight_common(e, d_score, e->ll_buf.as<float>(), score_gain, n, d_logw, d_max);
+}
+
+// the session's form: d_loglik == nullptr -> the log-likelihoods the last landmark update left in the engine (use_ekf) or none;
+// cov: a split session's covariance classes are brought up to date by workgroups of the same launch
+int slam_logweight_cov_dev(slam_engine* e, const float* d_score, bool use_ekf, float score_gain, int n, float* d_logw, float* d_max,
+                           const CovArgs* cov, int cov_bound)
+{
+    ENTER(e);
+    if (use_ekf && e->ll_n != n) return SLAM_ERR_NOT_READY;
+    return logweight_common(e, d_score, use_ekf ? e->ll_buf.as<float>() : nullptr, score_gain, n, d_logw, d_max, cov, cov_bound);
 }
 
 int slam_quantise_scan_dev(slam_engine* e, const float* d_logw, const float* d_max, int n, uint64_t* d_sum)

@@ -239,6 +239,10 @@ struct ProfScope {
 };
 
 // helpers implemented in engine.hip
+// slam_logweight_dev / slam_logweight_ekf_dev (use_ekf) with, optionally, a split session's covariance classes brought up to
+// date by workgroups of the same launch (launch_logweight)
+extern "C" int slam_logweight_cov_dev(slam_engine* e, const float* d_score, bool use_ekf, float score_gain, int n, float* d_logw, float* d_max,
+                           const slam::CovArgs* cov, int cov_bound);
 // slam_motion_score_dev + slam_ekf_update_dev (out of place, through the resample indices d_anc) as ONE launch
 // (launch_frame_front).  *launched = false: the shapes do not fit or fusion is off — nothing was issued, the caller makes
 // the two calls.  Used by the slam_pf session for single-GPU frames on rows.

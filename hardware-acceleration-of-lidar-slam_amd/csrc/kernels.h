@@ -329,7 +329,8 @@ hipError_t launch_migrate_unpack_paged(hipStream_t stream, const float* in, int 
 
 hipError_t launch_logweight(hipStream_t stream, const float* score, const float* loglik, float gain, int n,
                             float* logw, float* block_max_scratch, float* d_max, const float* carry = nullptr,
-                            const int32_t* prev_resampled = nullptr);
+                            const int32_t* prev_resampled = nullptr, const CovArgs* cov = nullptr, int cov_bound = 0);
+// (cov: the same launch carries launch_cov_update(cov, cov_bound) in workgroups of its own — cov_update_body.h)
 int logweight_scratch_elems(int n);
 int logweight_scratch_floats();   // size of block_max_scratch: block maxima + two words, zero-initialised once
 hipError_t launch_quantise_weights(hipStream_t stream, const float* logw, const float* d_max, int n, uint64_t* wq,

@@ -41,8 +41,9 @@ enum { kPoolFree = 0,    // entries in the free list
        kPoolUsed = 1,    // ... of which handed out already
        kPoolRenew = 2,   // this frame: the list is made anew before the update takes from it
        kPoolBase = 3,    // this frame: first entry the update takes
-       kPoolTicket = 4,  // workgroups of free_list_kernel that have added their share (left at zero)
-       kPoolShort = 5 }; // set (and never cleared) when a list made anew was shorter than what had been reserved from it
+       kPoolTicket = 4,  // (unused since round 4)
+       kPoolShort = 5,   // set (and never cleared) when a list made anew was shorter than what had been reserved from it
+       kPoolAcc = 6 };   // words 6-7, one 64-bit word: free_list_kernel's running {entries (high), workgroups done (low)}; left at zero
 
 // `want` fresh pages for whoever calls (one thread): they come from the part of the free list nobody has been given yet —
 // or, when that is too short, from a list made anew by free_list_kernel (launched behind the caller, it looks at the
@@ -565,7 +566,17 @@ __global__ __launch_bounds__(256) void free_list_kernel(const uint32_t* __restri
         woff += w < wave ? s_w[w] : 0;
         tot += s_w[w];
     }
-    if (threadIdx.x == 0) s_base = tot ? atomicAdd(&pool_state[kPoolFree], tot) : 0;
+    // ONE 64-bit atomic per workgroup carries its share of the list (high word) and "one more workgroup done" (low word); the
+    // last one to arrive knows the length of the list from what the atomic returned.  Nothing a workgroup wrote is read by
+    // another, so no fence is needed (round 3 took a ticket behind a __threadfence(): on this part an agent-scope release
+    // writes the L2 back, once per workgroup — the launch took 29 us at 2 million pages, profiles/r04_split_tuning.md section 9)
+    unsigned long long* acc = reinterpret_cast<unsigned long long*>(pool_state + kPoolAcc);
+    __shared__ int s_last;
+    if (threadIdx.x == 0) {
+        const unsigned long long old = atomicAdd(acc, ((unsigned long long)(unsigned)tot << 32) | 1ull);
+        s_base = (int)(old >> 32);
+        s_last = (unsigned)(old & 0xffffffffu) == gridDim.x - 1 ? 1 : 0;
+    }
     __syncthreads();
     int out = s_base + woff;
 #pragma unroll
@@ -574,16 +585,13 @@ __global__ __launch_bounds__(256) void free_list_kernel(const uint32_t* __restri
         if (m >> lane & 1ull) freelist[out + __popcll(m & ((1ull << lane) - 1ull))] = w0 + 64 * k + lane;
         out += __popcll(m);
     }
-    if (threadIdx.x == 0) {
-        __threadfence();
-        if (atomicAdd(&pool_state[kPoolTicket], 1) == (int)gridDim.x - 1) {   // every workgroup's share is in
-            __threadfence();
-            pool_state[kPoolTicket] = 0;
-            const int have = __hip_atomic_load(&pool_state[kPoolFree], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (have < pool_state[kPoolUsed]) {
-                pool_state[kPoolShort] = 1;
-                if (h_short) *h_short = 1;
-            }
+    if (threadIdx.x == 0 && s_last) {   // every workgroup's share is in
+        const int have = s_base + tot;
+        pool_state[kPoolFree] = have;
+        atomicExch(acc, 0ull);
+        if (have < pool_state[kPoolUsed]) {
+            pool_state[kPoolShort] = 1;
+            if (h_short) *h_short = 1;
         }
     }
 }
@@ -664,6 +672,7 @@ __global__ __launch_bounds__(256) void pages_reset_kernel(float* __restrict__ po
         pool_state[kPoolBase] = 0;
         pool_state[kPoolTicket] = 0;
         pool_state[kPoolShort] = 0;
+        pool_state[kPoolAcc] = pool_state[kPoolAcc + 1] = 0;
     }
 }
 
@@ -682,6 +691,7 @@ __global__ __launch_bounds__(256) void free_iota_kernel(int32_t* __restrict__ ou
         pool_state[kPoolBase] = 0;
         pool_state[kPoolTicket] = 0;
         pool_state[kPoolShort] = 0;
+        pool_state[kPoolAcc] = pool_state[kPoolAcc + 1] = 0;
     }
 }
 
@@ -753,7 +763,7 @@ hipError_t launch_page_table_gather(hipStream_t stream, const int32_t* pt_in, in
     return hipGetLastError();
 }
 
-int pool_state_words() { return 6; }
+int pool_state_words() { return 8; }
 
 hipError_t launch_compose_index(hipStream_t stream, const int32_t* sel, const int32_t* anc, int count, int32_t* out)
 {

@@ -17,6 +17,7 @@
 #include "det_math.h"
 #include "ekf_math.h"
 #include "score_body.h"
+#include "cov_update_body.h"
 #include "kernels.h"
 
 namespace slam {
@@ -1001,6 +1002,38 @@ __global__ __launch_bounds__(kBlock) void logweight_kernel(const float* __restri
     float m = -INFINITY;
     const bool add_carry = carry && *prev_resampled == 0;
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        const float ll = loglik ? loglik[i] : 0.0f;
+        const float sc = score ? score[i] * gain : 0.0f;
+        float lw = ll - sc;
+        if (add_carry) lw = carry[i] + lw;
+        logw[i] = lw;
+        m = lw > m ? lw : m;
+    }
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kBlock / 64; ++w) m = fmaxf(m, s_max[w]);
+        block_max[blockIdx.x] = m;
+    }
+}
+
+// The same launch with the covariance classes' update of a split session in workgroups of its own behind the first `nw`
+// (cov_update_body.h): the two have nothing to do with each other — which is the point, they need no launch each.
+__global__ __launch_bounds__(kBlock) void logweight_cov_kernel(const float* __restrict__ score, const float* __restrict__ loglik,
+                                                               float gain, int n, const float* __restrict__ carry,
+                                                               const int32_t* __restrict__ prev_resampled, float* __restrict__ logw,
+                                                               float* __restrict__ block_max, int nw, int ly, CovArgs cov)
+{
+    if ((int)blockIdx.x >= nw) {
+        const int j = (int)blockIdx.x - nw;
+        cov_update_body(cov, j / ly, j % ly);
+        return;
+    }
+    __shared__ float s_max[kBlock / 64];
+    float m = -INFINITY;
+    const bool add_carry = carry && *prev_resampled == 0;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += nw * kBlock) {
         const float ll = loglik ? loglik[i] : 0.0f;
         const float sc = score ? score[i] * gain : 0.0f;
         float lw = ll - sc;
@@ -2176,11 +2209,16 @@ hipError_t launch_ekf_sparse(hipStream_t stream, const EkfArgs& a_in, const int3
 
 hipError_t launch_logweight(hipStream_t stream, const float* score, const float* loglik, float gain, int n,
                             float* logw, float* block_max_scratch, float* d_max, const float* carry,
-                            const int32_t* prev_resampled)
+                            const int32_t* prev_resampled, const CovArgs* cov, int cov_bound)
 {
     if (n <= 0) return hipSuccess;
     const int nb = capped_blocks(n);
-    logweight_kernel<<<nb, kBlock, 0, stream>>>(score, loglik, gain, n, carry, prev_resampled, logw, block_max_scratch);
+    if (cov && cov_bound > 0) {   // + the covariance classes' update (launch_cov_update's grid, flattened)
+        const int ly = cov->nlandmarks > 0 ? (cov->nlandmarks + 255) / 256 : 1;
+        logweight_cov_kernel<<<nb + (int64_t)cov_bound * ly, kBlock, 0, stream>>>(score, loglik, gain, n, carry, prev_resampled, logw,
+                                                                               block_max_scratch, nb, ly, *cov);
+    } else
+        logweight_kernel<<<nb, kBlock, 0, stream>>>(score, loglik, gain, n, carry, prev_resampled, logw, block_max_scratch);
     if (d_max) max_finalize_kernel<<<1, kBlock, 0, stream>>>(block_max_scratch, nb, d_max);
     return hipGetLastError();
 }

@@ -839,7 +839,9 @@ int slam_pf_is_paged(const slam_pf* pf) { return pf && pf->paged ? 1 : 0; }
 // be at most: its length as of some earlier launch (mapped memory, read without waiting) plus the classes that arrived since
 // (sharded sessions) — the second word is the running count of arrivals as of that launch; it is read FIRST and written
 // last, so a torn pair only over-estimates; before anything of this epoch has arrived: every class there can be.
-static int split_class_update(slam_pf* pf, int nlandmarks)
+// the arguments and the width of the classes' update of this frame (and the session's bookkeeping moved on as if it had been
+// launched: the caller launches it, by itself or inside the launch of the weights)
+static void split_class_prepare(slam_pf* pf, int nlandmarks, CovArgs& ca, int& bound)
 {
     slam_engine* e = pf->e;
     const int32_t* hw = reinterpret_cast<const int32_t*>(pf->h_res);   // words 22-23: {count, epoch}; 18-19: {mark, epoch}
@@ -848,8 +850,7 @@ static int split_class_update(slam_pf* pf, int nlandmarks)
     const bool fresh = (uint32_t)(hl >> 32) == pf->cls_epoch && (uint32_t)hl > 0;
     const uint32_t mark = (uint32_t)(hm >> 32) == pf->cls_epoch ? (uint32_t)hm : 0u;   // (no launch of this epoch has said yet: 0)
     const int64_t upper = fresh ? (int64_t)(uint32_t)hl + (int64_t)(pf->cls_appended - mark) : (int64_t)pf->cap;
-    const int bound = upper < pf->cap ? (int)upper : pf->cap;
-    CovArgs ca;
+    bound = upper < pf->cap ? (int)upper : pf->cap;
     ca.cov = pf->cov;
     ca.cov_stride = 3 * (int64_t)pf->Lp;
     ca.covx = pf->covx;
@@ -869,10 +870,33 @@ static int split_class_update(slam_pf* pf, int nlandmarks)
     ca.h_mark = reinterpret_cast<int32_t*>(pf->d_hres) + 18;
     ca.epoch = pf->cls_epoch;
     ca.mark = pf->cls_appended;
-    SLAM_HIP_TRY(e, launch_cov_update(e->stream, ca, bound, e->prof_next(SLAM_PROF_PAGES)));
     pf->live_cur = 1 - pf->live_cur;
     pf->cov_phase = (pf->cov_phase + 1) % 3;
+}
+
+static int split_class_update(slam_pf* pf, int nlandmarks)
+{
+    CovArgs ca;
+    int bound = 0;
+    split_class_prepare(pf, nlandmarks, ca, bound);
+    SLAM_HIP_TRY(pf->e, launch_cov_update(pf->e->stream, ca, bound, pf->e->prof_next(SLAM_PROF_PAGES)));
     return SLAM_OK;
+}
+
+// the classes' update of the frame + the weights: ONE launch (SLAM_COV_MERGE=0: two, as round 4 first had them)
+static int weights_with_classes(slam_pf* pf, int nlandmarks, bool use_ekf, float* d_max)
+{
+    static const bool merge = !(getenv("SLAM_COV_MERGE") && atoi(getenv("SLAM_COV_MERGE")) == 0);
+    slam_engine* e = pf->e;
+    if (!merge) {
+        if (int rc = split_class_update(pf, nlandmarks)) return rc;
+        return use_ekf ? slam_logweight_ekf_dev(e, pf->score, pf->cfg.score_gain, pf->n, pf->logw, d_max)
+                       : slam_logweight_dev(e, pf->score, nullptr, pf->cfg.score_gain, pf->n, pf->logw, d_max);
+    }
+    CovArgs ca;
+    int bound = 0;
+    split_class_prepare(pf, nlandmarks, ca, bound);
+    return slam_logweight_cov_dev(e, pf->score, use_ekf, pf->cfg.score_gain, pf->n, pf->logw, d_max, &ca, bound);
 }
 
 static int pf_step_impl(slam_pf* pf, int slot, const float dp[3], int use_observations, bool* collective_verdict);
@@ -1006,17 +1030,16 @@ static int pf_step_impl(slam_pf* pf, int slot, const float dp[3], int use_observ
             pf->cstamp_now++;
             pf->sp_cur = 1 - sc;
             // ... then the classes' update, in place, once per class still in use
-            if ((rc = split_class_update(pf, L)) != SLAM_OK) return rc;
-            rc = slam_logweight_ekf_dev(e, pf->score, pf->cfg.score_gain, n, pf->logw, d_max);
+            rc = weights_with_classes(pf, L, true, d_max);
         } else {
             if (anc) {   // means and classes follow their particles
                 const ProfScope prof(e, SLAM_PROF_PAGES);
                 SLAM_HIP_TRY(e, launch_split_gather(e->stream, pf->mean[sc], pf->mean[1 - sc], pf->cls[sc], pf->cls[1 - sc], pf->Lp, anc, n,
                                                     pf->cstamp, ++pf->cstamp_now));
                 pf->sp_cur = 1 - sc;
-                if ((rc = split_class_update(pf, 0)) != SLAM_OK) return rc;   // no observations: the list of classes in use only
-            }
-            rc = slam_logweight_dev(e, pf->score, nullptr, pf->cfg.score_gain, n, pf->logw, d_max);
+                rc = weights_with_classes(pf, 0, false, d_max);   // no observations: the list of classes in use only
+            } else
+                rc = slam_logweight_dev(e, pf->score, nullptr, pf->cfg.score_gain, n, pf->logw, d_max);
         }
     } else if (pf->paged) {
         const int pc = pf->pt_cur;
@@ -1092,12 +1115,12 @@ static int pf_step_impl(slam_pf* pf, int slot, const float dp[3], int use_observ
                                              __atomic_load_n(reinterpret_cast<int32_t*>(pf->h_res) + 30, __ATOMIC_RELAXED)));
             e->ll_n = n;
             pf->pt_cur = 1 - pc;
-            if (pf->split) {   // the classes went with their particles; their covariances, once per class
+            if (pf->split) {   // the classes went with their particles; their covariances, once per class, with the weights
                 pf->cstamp_now++;
                 pf->sp_cur = 1 - pf->sp_cur;
-                if ((rc = split_class_update(pf, L)) != SLAM_OK) return rc;
-            }
-            rc = slam_logweight_ekf_dev(e, pf->score, pf->cfg.score_gain, n, pf->logw, d_max);
+                rc = weights_with_classes(pf, L, true, d_max);
+            } else
+                rc = slam_logweight_ekf_dev(e, pf->score, pf->cfg.score_gain, n, pf->logw, d_max);
         } else {
             if (anc) {   // the tables follow their particles
                 const ProfScope prof(e, SLAM_PROF_PAGES);
@@ -1108,10 +1131,10 @@ static int pf_step_impl(slam_pf* pf, int slot, const float dp[3], int use_observ
                     SLAM_HIP_TRY(e, launch_class_gather(e->stream, pf->cls[pf->sp_cur], pf->cls[1 - pf->sp_cur], anc, n, pf->cstamp,
                                                         ++pf->cstamp_now));
                     pf->sp_cur = 1 - pf->sp_cur;
-                    if ((rc = split_class_update(pf, 0)) != SLAM_OK) return rc;
                 }
             }
-            rc = slam_logweight_dev(e, pf->score, nullptr, pf->cfg.score_gain, n, pf->logw, d_max);
+            rc = anc && pf->split ? weights_with_classes(pf, 0, false, d_max)
+                                  : slam_logweight_dev(e, pf->score, nullptr, pf->cfg.score_gain, n, pf->logw, d_max);
         }
     } else if (ekf && in_place) {
         if (sample_obs) SLAM_HIP_TRY(e, launch_obs_count(e->stream, e->d_obs_zx, e->d_obs_zy, L, d_hobs, ++pf->obs_seq_issued, pf->votes));

@@ -26,6 +26,7 @@
 // update on this layout is ekf_split_body in pf_kernels.hip (it shares the grouped row kernel's machinery).
 
 #include "ekf_math.h"
+#include "cov_update_body.h"
 #include "kernels.h"
 
 namespace slam {
@@ -34,55 +35,9 @@ namespace {
 
 inline int blocks256(int64_t n) { return (int)((n + 255) / 256); }
 
-// {classes in use, epoch} to mapped host memory as ONE 8-byte store (8-byte aligned), so that the host never pairs the count of
-// one epoch with the number of another
-__device__ __forceinline__ void publish_live(int32_t* h_live, int count, uint32_t epoch)
-{
-    *reinterpret_cast<volatile unsigned long long*>(h_live) = (unsigned long long)(uint32_t)count | ((unsigned long long)epoch << 32);
-}
-
-// ---- the classes' update: workgroup (k, y) takes landmarks [256 y, 256 y + 256) of class live[k]
-__global__ __launch_bounds__(256) void cov_update_kernel(CovArgs a)
-{
-    const int k = blockIdx.x;
-    const int nlive = a.cnt[a.phase];
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
-        a.cnt[(a.phase + 2) % 3] = 0;   // the list after next: nobody reads or writes it during this launch
-        if (a.h_live) {
-            publish_live(a.h_live, nlive, a.epoch);
-            __threadfence_system();   // the count first: a host that pairs a newer count with an older mark over-estimates
-            publish_live(a.h_mark, (int)a.mark, a.epoch);
-        }
-    }
-    if (k >= nlive) return;
-    const int c = a.live_in[k];
-    if (a.cstamp[c] != a.stamp_now) return;   // its last particle is gone: the class leaves the list
-    if (blockIdx.y == 0 && threadIdx.x == 0) a.live_out[atomicAdd(&a.cnt[(a.phase + 1) % 3], 1)] = c;
-    const int l = blockIdx.y * 256 + threadIdx.x;
-    if (l >= a.nlandmarks) return;   // (the padding of a row is never observed: it stays as it is)
-    const float zx = a.obs_zx[l], zy = a.obs_zy[l];
-    if (!(zx == zx && zy == zy)) return;   // not observed: the prior stays
-    float* row = a.cov + (int64_t)c * a.cov_stride + l;
-    const float pxx = row[0], pxy = row[a.plane_stride], pyy = row[2 * (int64_t)a.plane_stride];
-    float o2 = a.meas_var, o3 = 0.0f, o4 = a.meas_var;   // a first sighting: q I
-    if (!(pxx < 0.0f)) {
-        // (the prior's determinant terms lie in covx; starting from them instead of recomputing them gives the same bits)
-        const float* xr = a.covx + (int64_t)c * a.covx_stride + l;
-        const EkfShared<float> h = ekf_shared_from<float>(pxx, pxy, pyy, a.meas_var, xr[0], xr[a.plane_stride]);
-        o2 = h.o2;
-        o3 = h.o3;
-        o4 = h.o4;
-    }
-    row[0] = o2;
-    row[a.plane_stride] = o3;
-    row[2 * (int64_t)a.plane_stride] = o4;
-    // what the next update of this landmark starts from
-    float idet, hl;
-    ekf_det_terms<float>(o2, o3, o4, a.meas_var, idet, hl);
-    float* xw = a.covx + (int64_t)c * a.covx_stride + l;
-    xw[0] = idet;
-    xw[a.plane_stride] = hl;
-}
+// ---- the classes' update: workgroup (k, y) takes landmarks [256 y, 256 y + 256) of class live[k] (cov_update_body.h; the frame
+// path carries it in the launch of the weights, this launch serves everybody else)
+__global__ __launch_bounds__(256) void cov_update_kernel(CovArgs a) { cov_update_body(a, (int)blockIdx.x, (int)blockIdx.y); }
 
 // the determinant terms of classes 0 .. *count - 1 from their covariance planes (after a conversion or a reset)
 __global__ __launch_bounds__(256) void cov_terms_kernel(const float* __restrict__ cov, float* __restrict__ covx, int Lp, int nlandmarks,
