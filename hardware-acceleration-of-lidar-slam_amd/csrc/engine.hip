@@ -701,17 +701,29 @@ int slam_motion_score_dev(slam_engine* e, int slot, const float* d_src_x, const 
                           const float dp[3], const float sigma[3], uint64_t seed, uint32_t frame, float* d_score,
                           int32_t* d_count)
 {
+    return slam_motion_score_rider_dev(e, slot, d_src_x, d_src_y, d_src_th, d_anc, d_x, d_y, d_th, n, first_id, dp, sigma, seed, frame,
+                                       d_score, d_count, nullptr, nullptr);
+}
+
+// ... with a paged session's free list in workgroups of the same launch (kernels.h: FreeListRider); *rode = false: the caller
+// launches the list by itself
+int slam_motion_score_rider_dev(slam_engine* e, int slot, const float* d_src_x, const float* d_src_y, const float* d_src_th,
+                                const int32_t* d_anc, float* d_x, float* d_y, float* d_th, int n, int64_t first_id,
+                                const float dp[3], const float sigma[3], uint64_t seed, uint32_t frame, float* d_score,
+                                int32_t* d_count, const FreeListRider* rider, bool* rode)
+{
     ENTER(e);
+    if (rode) *rode = false;
     if (n < 0 || first_id < 0 || !dp || !sigma ||
         (n > 0 && (!d_src_x || !d_src_y || !d_src_th || !d_x || !d_y || !d_th || !d_score || !d_count)))
         return SLAM_ERR_INVALID_ARG;
     if (d_src_x == d_x || d_src_y == d_y || d_src_th == d_th) return SLAM_ERR_INVALID_ARG;   // several lanes re-read src
     if (int rc = check_score_inputs(e, slot)) return rc;
-    MotionIO io{ d_src_x, d_src_y, d_src_th, d_anc, d_x, d_y, d_th };
+    MotionIO io{ d_src_x, d_src_y, d_src_th, d_anc, d_x, d_y, d_th, rider ? *rider : FreeListRider() };
     ScoreGrid sg;
     if (int rc = many_pose_grid(e, slot, n, &sg)) return rc;
     HIP_TRY(launch_motion_score(e->stream, sg, e->d_bx, e->d_by, e->nbeams, io, n, first_id, dp,
-                                sigma, seed, frame, d_score, d_count, e->prof_next(SLAM_PROF_SCORE)));
+                                sigma, seed, frame, d_score, d_count, e->prof_next(SLAM_PROF_SCORE), rode));
     return SLAM_OK;
 }
 
@@ -888,7 +900,7 @@ int slam_frame_front_dev(slam_engine* e, int slot, const float* d_src_x, const f
         a.cstamp = split->cstamp;
         a.stamp_now = split->stamp_now;
     }
-    MotionIO io{ d_src_x, d_src_y, d_src_th, d_anc, d_x, d_y, d_th };
+    MotionIO io{ d_src_x, d_src_y, d_src_th, d_anc, d_x, d_y, d_th, FreeListRider() };
     int lanes = 0;
     // one bracket for the whole launch: it counts as the frame's landmark update (the dominant stage)
     ScoreGrid sg;

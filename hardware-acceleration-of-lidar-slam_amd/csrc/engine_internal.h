@@ -243,6 +243,11 @@ struct ProfScope {
 // date by workgroups of the same launch (launch_logweight)
 extern "C" int slam_logweight_cov_dev(slam_engine* e, const float* d_score, bool use_ekf, float score_gain, int n, float* d_logw, float* d_max,
                            const slam::CovArgs* cov, int cov_bound);
+// slam_motion_score_dev with a rider (defined in engine.hip next to it)
+extern "C" int slam_motion_score_rider_dev(slam_engine* e, int slot, const float* d_src_x, const float* d_src_y, const float* d_src_th,
+                                           const int32_t* d_anc, float* d_x, float* d_y, float* d_th, int n, int64_t first_id,
+                                           const float dp[3], const float sigma[3], uint64_t seed, uint32_t frame, float* d_score,
+                                           int32_t* d_count, const slam::FreeListRider* rider, bool* rode);
 // slam_motion_score_dev + slam_ekf_update_dev (out of place, through the resample indices d_anc) as ONE launch
 // (launch_frame_front).  *launched = false: the shapes do not fit or fusion is off — nothing was issued, the caller makes
 // the two calls.  Used by the slam_pf session for single-GPU frames on rows.

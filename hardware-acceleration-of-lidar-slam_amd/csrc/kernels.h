@@ -40,15 +40,30 @@ hipError_t launch_score_poses(hipStream_t stream, const ScoreGrid& g, const floa
                               const float* x, const float* y, const float* th_or_ct, const float* st_or_null,
                               int nposes, float* score, int32_t* count, const EventPair* ev = nullptr);
 // motion sample fused in front of the score: pose' = motion(src[anc]), written to dst and scored
+// A launch_free_list (paged_kernels.hip: the free list of a paged session, its arguments below) that travels in workgroups of its
+// own behind those of a motion + score launch: neither needs anything from the other (free_list_body.h).
+struct FreeListRider {
+    const uint32_t* stamp = nullptr;   // nullptr: no rider
+    int npages = 0;
+    uint32_t live = 0;
+    int32_t* freelist = nullptr;
+    int32_t* pool_state = nullptr;
+    int32_t* h_short = nullptr;
+    int first_block = 0, nblocks = 0;   // filled in by the launcher
+};
 struct MotionIO {
     const float *sx, *sy, *sth;
     const int32_t* anc;
     float *x, *y, *th;
+    FreeListRider rider;
 };
+// rider (optional): *rode says whether the launch took it along (the one-wavefront-per-pose form of small batches does not:
+// the caller then launches the list by itself)
 hipError_t launch_motion_score(hipStream_t stream, const ScoreGrid& g, const float* bx, const float* by, int nbeams,
                                const MotionIO& io, int nposes, int64_t first_id, const float dp[3], const float sigma[3],
                                uint64_t seed, uint32_t frame, float* score, int32_t* count,
-                               const EventPair* ev = nullptr);
+                               const EventPair* ev = nullptr, bool* rode = nullptr);
+int free_list_blocks(int npages);
 hipError_t launch_pose_hits(hipStream_t stream, const ScoreGrid& g, const float* bx, const float* by, int nbeams,
                             const float* pose_xycs /*4 floats on device*/, float* hits, int32_t* count);
 

@@ -21,6 +21,7 @@
 
 #include "det_math.h"
 #include "ekf_math.h"
+#include "free_list_body.h"
 #include "kernels.h"
 
 namespace slam {
@@ -36,15 +37,6 @@ __device__ __forceinline__ int64_t page_off(const PageGeom& g, int64_t page)
     return page * (g.planes * kPage) + (page >= g.half_pages ? g.gap : 0);
 }
 constexpr int kWaves = 4;                      // wavefronts per workgroup (64 / kPage particles each)
-// PoolState (device, kPoolStateWords int32): bookkeeping of the free list between frames, all of it on the device
-enum { kPoolFree = 0,    // entries in the free list
-       kPoolUsed = 1,    // ... of which handed out already
-       kPoolRenew = 2,   // this frame: the list is made anew before the update takes from it
-       kPoolBase = 3,    // this frame: first entry the update takes
-       kPoolTicket = 4,  // (unused since round 4)
-       kPoolShort = 5,   // set (and never cleared) when a list made anew was shorter than what had been reserved from it
-       kPoolAcc = 6 };   // words 6-7, one 64-bit word: free_list_kernel's running {entries (high), workgroups done (low)}; left at zero
-
 // `want` fresh pages for whoever calls (one thread): they come from the part of the free list nobody has been given yet —
 // or, when that is too short, from a list made anew by free_list_kernel (launched behind the caller, it looks at the
 // flag); such a list always holds at least half the pool.
@@ -532,68 +524,11 @@ __global__ __launch_bounds__(256) void page_table_gather_kernel(const int32_t* _
 // and a frame takes n * T).  A workgroup counts the free pages of its tile, claims that many slots of the list with ONE
 // atomic add and fills them (the order of the list does not matter: page numbers are internal, results do not depend on
 // them).
-constexpr int kFreeTile = 8192;
-
-// The reservation is checked against the finished list by the last workgroup to arrive: tables never name more than half the
-// pool, so a new list always holds what a frame takes — if that invariant were ever broken the update would hand out pages
-// that are still in use, so the shortfall is reported (pool_state[kPoolShort] and, when given, a word in mapped host memory
-// that slam_pf_step turns into SLAM_ERR_CAPACITY) instead of passing silently.
-// A wavefront reads 64 consecutive stamps per step (one coalesced 256-byte access; one thread walking 32 consecutive stamps
-// took 0.6 ms for a 20-million-page pool) and a ballot gives the free ones in order.
 __global__ __launch_bounds__(256) void free_list_kernel(const uint32_t* __restrict__ stamp, int npages, uint32_t live,
                                                         int32_t* __restrict__ freelist, int32_t* __restrict__ pool_state,
                                                         int32_t* __restrict__ h_short)
 {
-    __shared__ int s_w[4];
-    __shared__ int s_base;
-    if (pool_state[kPoolRenew] == 0) return;
-    constexpr int kSteps = kFreeTile / 256;   // 64-page steps per wavefront
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int w0 = blockIdx.x * kFreeTile + wave * (kFreeTile / 4);   // this wavefront's pages: w0 .. w0 + 2047
-    unsigned long long mask[kSteps];
-    int c = 0;
-#pragma unroll
-    for (int k = 0; k < kSteps; ++k) {
-        const int p = w0 + 64 * k + lane;
-        const bool fr = p < npages && stamp[p < npages ? p : npages - 1] != live;
-        mask[k] = __ballot(fr);
-        c += __popcll(mask[k]);   // wave-uniform
-    }
-    if (lane == 0) s_w[wave] = c;
-    __syncthreads();
-    int woff = 0, tot = 0;
-    for (int w = 0; w < 4; ++w) {
-        woff += w < wave ? s_w[w] : 0;
-        tot += s_w[w];
-    }
-    // ONE 64-bit atomic per workgroup carries its share of the list (high word) and "one more workgroup done" (low word); the
-    // last one to arrive knows the length of the list from what the atomic returned.  Nothing a workgroup wrote is read by
-    // another, so no fence is needed (round 3 took a ticket behind a __threadfence(): on this part an agent-scope release
-    // writes the L2 back, once per workgroup — the launch took 29 us at 2 million pages, profiles/r04_split_tuning.md section 9)
-    unsigned long long* acc = reinterpret_cast<unsigned long long*>(pool_state + kPoolAcc);
-    __shared__ int s_last;
-    if (threadIdx.x == 0) {
-        const unsigned long long old = atomicAdd(acc, ((unsigned long long)(unsigned)tot << 32) | 1ull);
-        s_base = (int)(old >> 32);
-        s_last = (unsigned)(old & 0xffffffffu) == gridDim.x - 1 ? 1 : 0;
-    }
-    __syncthreads();
-    int out = s_base + woff;
-#pragma unroll
-    for (int k = 0; k < kSteps; ++k) {
-        const unsigned long long m = mask[k];
-        if (m >> lane & 1ull) freelist[out + __popcll(m & ((1ull << lane) - 1ull))] = w0 + 64 * k + lane;
-        out += __popcll(m);
-    }
-    if (threadIdx.x == 0 && s_last) {   // every workgroup's share is in
-        const int have = s_base + tot;
-        pool_state[kPoolFree] = have;
-        atomicExch(acc, 0ull);
-        if (have < pool_state[kPoolUsed]) {
-            pool_state[kPoolShort] = 1;
-            if (h_short) *h_short = 1;
-        }
-    }
+    free_list_body(stamp, npages, live, freelist, pool_state, h_short, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // ---- rows <-> pages (set / get of whole maps; not on the frame path)
@@ -764,6 +699,7 @@ hipError_t launch_page_table_gather(hipStream_t stream, const int32_t* pt_in, in
 }
 
 int pool_state_words() { return 8; }
+int free_list_blocks(int npages) { return (npages + kFreeTile - 1) / kFreeTile; }
 
 hipError_t launch_compose_index(hipStream_t stream, const int32_t* sel, const int32_t* anc, int count, int32_t* out)
 {

@@ -953,6 +953,43 @@ static int pf_step_impl(slam_pf* pf, int slot, const float dp[3], int use_observ
         sio.stamp_now = pf->cstamp_now + 1;
     };
     if (pf->split) make_sio();
+    // Paged maps: the frame's page list (touched pages, observation list, where the fresh pages come from) and, when that asked
+    // for one, a new free list.  Neither needs anything from the motion + score launch nor the other way round: on one GPU the
+    // page list goes out first and the free list travels in workgroups of the scorer's launch (free_list_body.h); a sharded
+    // session issues both behind its exchange, which takes pages from the same list first.
+    int32_t *pstate = pf->page_scratch, *count = pstate + pool_state_words(), *tpage = count + 1, *tindex = tpage + pf->nb,
+            *tmask = tindex + pf->nb, *tbase = tmask + pf->nb, *lst = tbase + pf->nb + 1;
+    // the list form (one lane per observation) whenever a list can be made; SLAM_PAGED_FORM=0 keeps the page-wide form
+    static const int env_form = getenv("SLAM_PAGED_FORM") ? atoi(getenv("SLAM_PAGED_FORM")) : 1;
+    const int form = env_form != 0 && L <= kObsListMaxLandmarks ? 1 : 0;
+    ObsListOut lo;
+    if (form && pf->paged) {
+        lo.id = lst;
+        lo.zx = reinterpret_cast<float*>(lst + pf->Lp);
+        lo.zy = reinterpret_cast<float*>(lst + 2 * pf->Lp);
+        lo.round = lst + 3 * pf->Lp;
+        lo.count = lst + 4 * pf->Lp;
+    }
+    auto issue_page_list = [&]() -> int {
+        const ProfScope prof(e, SLAM_PROF_PAGES);
+        SLAM_HIP_TRY(e, launch_page_list(e->stream, e->d_obs_zx, e->d_obs_zy, L, pf->nb, tpage, tindex, tmask, tbase, count, n, pstate,
+                                         sample_obs ? d_hobs : nullptr, sample_obs ? ++pf->obs_seq_issued : 0,
+                                         sample_obs ? pf->votes : nullptr, reinterpret_cast<int32_t*>(pf->d_hres) + 30, lo));
+        return SLAM_OK;
+    };
+    static const bool ride = !(getenv("SLAM_FREE_LIST_RIDER") && atoi(getenv("SLAM_FREE_LIST_RIDER")) == 0);
+    bool paged_listed = false;
+    FreeListRider rider;
+    if (ride && !comm && pf->paged && L > 0 && use_observations && e->obs_nlandmarks == L) {
+        if (int rc1 = issue_page_list()) return rc1;
+        rider.stamp = pf->stamp;
+        rider.npages = pf->npages;
+        rider.live = pf->stamp_now;
+        rider.freelist = pf->freelist;
+        rider.pool_state = pstate;
+        rider.h_short = reinterpret_cast<int32_t*>(pf->d_hres) + 20;
+        paged_listed = true;
+    }
     if (comm && pf->split && pf->has_anc && !pf->gated && anc && L > 0 && use_observations && e->obs_nlandmarks == L) {
         // Sharded, split maps: the front launch scores every particle (its ancestor's pose comes out of the all-gathered poses)
         // and updates the groups of particles whose ancestors are all rows of this rank; the groups with an ancestor in the
@@ -989,8 +1026,14 @@ static int pf_step_impl(slam_pf* pf, int slot, const float dp[3], int use_observ
         rc = slam_motion_score_dev(e, slot, pa, pa + sn, pa + 2 * sn, pf->pose_idx[cur], dst, dst + sn, dst + 2 * sn, n,
                                    first_id, dp, pf->cfg.sigma, pf->cfg.seed, pf->frame, pf->score, pf->count);
     } else {
-        rc = slam_motion_score_dev(e, slot, src, src + sn, src + 2 * sn, anc, dst, dst + sn, dst + 2 * sn, n, first_id, dp,
-                                   pf->cfg.sigma, pf->cfg.seed, pf->frame, pf->score, pf->count);
+        bool rode = false;
+        rc = slam_motion_score_rider_dev(e, slot, src, src + sn, src + 2 * sn, anc, dst, dst + sn, dst + 2 * sn, n, first_id, dp,
+                                         pf->cfg.sigma, pf->cfg.seed, pf->frame, pf->score, pf->count, paged_listed ? &rider : nullptr,
+                                         &rode);
+        if (rc == SLAM_OK && paged_listed && !rode) {   // (a small population: its scorer has no room for a rider)
+            const ProfScope prof(e, SLAM_PROF_PAGES);
+            SLAM_HIP_TRY(e, launch_free_list(e->stream, rider.stamp, rider.npages, rider.live, rider.freelist, rider.pool_state, rider.h_short));
+        }
     }
     if (rc != SLAM_OK) return rc;
     // Resample gate: did the previous frame keep its population?  (Its verdict was made on the device; the host looks at it
@@ -1047,25 +1090,10 @@ static int pf_step_impl(slam_pf* pf, int slot, const float dp[3], int use_observ
             // touched pages of this frame's observation table, the update into fresh pages, the next frame's free list
             if (e->obs_nlandmarks != L) return SLAM_ERR_NOT_READY;
             SLAM_HIP_TRY(e, e->ll_buf.ensure(sizeof(float) * sn));
-            int32_t *pstate = pf->page_scratch, *count = pstate + pool_state_words(), *tpage = count + 1, *tindex = tpage + pf->nb,
-                    *tmask = tindex + pf->nb, *tbase = tmask + pf->nb, *lst = tbase + pf->nb + 1;
-            // the list form (one lane per observation) whenever a list can be made; SLAM_PAGED_FORM=0 keeps the page-wide form
-            static const int env_form = getenv("SLAM_PAGED_FORM") ? atoi(getenv("SLAM_PAGED_FORM")) : 1;
-            const int form = env_form != 0 && L <= kObsListMaxLandmarks ? 1 : 0;
-            ObsListOut lo;
-            if (form) {
-                lo.id = lst;
-                lo.zx = reinterpret_cast<float*>(lst + pf->Lp);
-                lo.zy = reinterpret_cast<float*>(lst + 2 * pf->Lp);
-                lo.round = lst + 3 * pf->Lp;
-                lo.count = lst + 4 * pf->Lp;
-            }
-            {
-                const ProfScope prof(e, SLAM_PROF_PAGES);
-                SLAM_HIP_TRY(e, launch_page_list(e->stream, e->d_obs_zx, e->d_obs_zy, L, pf->nb, tpage, tindex, tmask, tbase, count, n, pstate,
-                                                 sample_obs ? d_hobs : nullptr, sample_obs ? ++pf->obs_seq_issued : 0,
-                                                 sample_obs ? pf->votes : nullptr, reinterpret_cast<int32_t*>(pf->d_hres) + 30, lo));
+            if (!paged_listed) {
+                if (int rc1 = issue_page_list()) return rc1;
                 // a new free list when the old one runs short (decided on the device; the pages in use carry the last stamp)
+                const ProfScope prof(e, SLAM_PROF_PAGES);
                 SLAM_HIP_TRY(e, launch_free_list(e->stream, pf->stamp, pf->npages, pf->stamp_now, pf->freelist, pstate,
                                                  reinterpret_cast<int32_t*>(pf->d_hres) + 20));
             }

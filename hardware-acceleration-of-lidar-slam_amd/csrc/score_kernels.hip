@@ -21,6 +21,7 @@
 #include <stdlib.h>
 
 #include "det_math.h"
+#include "free_list_body.h"
 #include "kernels.h"
 #include "score_body.h"
 
@@ -39,6 +40,13 @@ __global__ __launch_bounds__(kScoreBlock) void score_poses_kernel(ScoreGrid g, c
                                                                    MotionParams mpar)
 {
     extern __shared__ float4 s_pair[];
+    if constexpr (MOTION) {   // the workgroups behind the scorer's: a paged session's free list (kernels.h: FreeListRider)
+        if (mio.rider.stamp && (int)blockIdx.x >= mio.rider.first_block) {
+            free_list_body(mio.rider.stamp, mio.rider.npages, mio.rider.live, mio.rider.freelist, mio.rider.pool_state, mio.rider.h_short,
+                           (int)blockIdx.x - mio.rider.first_block, mio.rider.nblocks);
+            return;
+        }
+    }
     score_poses_body<HAS_CS, LPP, DEPTH, MOTION, PACKED>(g, bx, by, nbeams, px, py, p2, p3, nposes, score, count, mio, mpar,
                                                          (int)blockIdx.x, s_pair);
 }
@@ -287,9 +295,12 @@ namespace {
 template <bool MOTION>
 hipError_t launch_score_any(hipStream_t stream, const ScoreGrid& g, const float* bx, const float* by, int nbeams,
                             float* x, float* y, float* th_or_ct, const float* st_or_null, int nposes, float* score,
-                            int32_t* count, const MotionIO& mio, const MotionParams& mpar, const EventPair* ev)
+                            int32_t* count, const MotionIO& mio_in, const MotionParams& mpar, const EventPair* ev,
+                            bool* rode = nullptr)
 {
+    if (rode) *rode = false;
     if (nposes <= 0) return hipSuccess;
+    MotionIO mio = mio_in;
     // tuning knobs for measurements (pose counts below which the wave / quad lane mappings are used)
     static const int wave_max = getenv("SLAM_SCORE_WAVE_MAX") ? atoi(getenv("SLAM_SCORE_WAVE_MAX")) : kWaveMaxPoses;
     static const int quad_max = getenv("SLAM_SCORE_QUAD_MAX") ? atoi(getenv("SLAM_SCORE_QUAD_MAX")) : kQuadMaxPoses;
@@ -308,7 +319,14 @@ hipError_t launch_score_any(hipStream_t stream, const ScoreGrid& g, const float*
     }
     const bool quad = nposes < quad_max;
     const long threads = quad ? 4L * nposes : nposes;
-    const int blocks = (int)((threads + kScoreBlock - 1) / kScoreBlock);
+    const int score_blocks = (int)((threads + kScoreBlock - 1) / kScoreBlock);
+    int blocks = score_blocks;
+    if (MOTION && mio.rider.stamp) {   // + the rider's workgroups
+        mio.rider.first_block = score_blocks;
+        mio.rider.nblocks = free_list_blocks(mio.rider.npages);
+        blocks += mio.rider.nblocks;
+        if (rode) *rode = true;
+    }
     const bool packed = g.packed != nullptr;   // the byte-per-cell copy of the grid (launch_edt_pack) + 1 KB of LDS for its table
     const size_t lds = sizeof(float2) * (size_t)(nbeams + (quad ? 4 * kQuadDepth : kLaneDepth)) + (packed ? 1024 : 0);
     if (ev) (void)hipEventRecord(ev->start, stream);
@@ -345,10 +363,10 @@ hipError_t launch_score_poses(hipStream_t stream, const ScoreGrid& g, const floa
 
 hipError_t launch_motion_score(hipStream_t stream, const ScoreGrid& g, const float* bx, const float* by, int nbeams,
                                const MotionIO& io, int nposes, int64_t first_id, const float dp[3], const float sigma[3],
-                               uint64_t seed, uint32_t frame, float* score, int32_t* count, const EventPair* ev)
+                               uint64_t seed, uint32_t frame, float* score, int32_t* count, const EventPair* ev, bool* rode)
 {
     return launch_score_any<true>(stream, g, bx, by, nbeams, io.x, io.y, io.th, nullptr, nposes, score, count, io,
-                                  make_motion_params(first_id, dp, sigma, seed, frame), ev);
+                                  make_motion_params(first_id, dp, sigma, seed, frame), ev, rode);
 }
 
 // ---- the packed copy of a grid (kernels.h: ScoreGrid::packed).  Two passes: the grid's largest value (the cap, wherever a cell
