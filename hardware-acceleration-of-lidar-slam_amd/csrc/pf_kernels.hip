@@ -556,6 +556,14 @@ __device__ __forceinline__ void split_apply_one(const SplitBatch<NB>& b, int g, 
     if constexpr (SPECIAL) asm volatile("" : "+v"(zx));
     const EkfParticle<v2f> u = ekf_particle<v2f>(b.sh[g], b.mx[g], b.my[g], zx, b.zy[g], w.s, w.c, w.px, w.py);
     v2f r0 = u.o0, r1 = u.o1, ll = u.ll;
+    if constexpr (!SPECIAL) {
+        // The two landmarks of a lane are stored one by one, and left to itself the compiler pushes the two extracts up through
+        // the whole expression and then packs each landmark's w00 * dx + w01 * dy as ONE product pair + a horizontal add — with
+        // two register moves per pair to line the operands up: 20 instructions for the four new means where 8 packed ones do
+        // (counted in the ISA, profiles/r04_split_tuning.md section 10).  The packed values are made opaque before the extracts.
+        asm("" : "+v"(r0));
+        asm("" : "+v"(r1));
+    }
     if constexpr (SPECIAL) {
 #pragma unroll
         for (int t = 0; t < 2; ++t) {   // obs ? (first ? the observed point : the update) : the prior
