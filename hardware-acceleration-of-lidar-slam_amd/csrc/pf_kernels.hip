@@ -774,12 +774,21 @@ __device__ __forceinline__ void ekf_split_body(const EkfArgs& a, int bid, float 
             s_acc[wave][k][lane + 64] = acc[1];
         }
     }
-    for (int k = 0; k < nslots; ++k) {
-        const float total = wave_xor_tree_sum(s_acc[wave][k][lane] + s_acc[wave][k][lane + 64]);
-        if (lane == 0) {
-            a.loglik[g0 + k] = total;
-            if (a.loglik_user) a.loglik_user[g0 + k] = total;
-        }
+    // the G sums side by side (wave_xor_tree_sum for every particle, the steps interleaved: one after the other they were 6 G
+    // dependent cross-lane round trips at the end of every wavefront's life); slots beyond nslots hold zeros
+    float tot[G];
+#pragma unroll
+    for (int k = 0; k < G; ++k) tot[k] = s_acc[wave][k][lane] + s_acc[wave][k][lane + 64];
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1)
+#pragma unroll
+        for (int k = 0; k < G; ++k) tot[k] = tot[k] + __shfl_xor(tot[k], s, 64);
+    float total = 0.0f;   // lane k: the sum of particle g0 + k (every lane holds all of them)
+#pragma unroll
+    for (int k = 0; k < G; ++k) total = (int)lane == k ? tot[k] : total;
+    if ((int)lane < nslots) {
+        a.loglik[g0 + (int)lane] = total;
+        if (a.loglik_user) a.loglik_user[g0 + (int)lane] = total;
     }
 }
 
