@@ -28,19 +28,23 @@ line local_2ranks $Q --gpus 2 --transport local --particles 32768
 line obs32_rows $Q --observed 32 --map-layout rows
 line obs32_split $Q --observed 32 --map-layout split
 line obs32_paged $Q --observed 32 --paged
+line obs32_split_pages $Q --observed 32 --map-layout split_pages
 line obs32_auto $Q --observed 32
 line obs32_ess0.3 $Q --observed 32 --ess 0.3 --map-layout rows --steps 120
 line obs32_ess0.1 $Q --observed 32 --ess 0.1 --map-layout rows --steps 120
 line obs128_rows $Q --observed 128 --map-layout rows
 line obs128_split $Q --observed 128 --map-layout split
 line obs128_paged $Q --observed 128 --paged
+line obs128_split_pages $Q --observed 128 --map-layout split_pages
 line 5000_obs32_rows $Q --landmarks 5000 --observed 32 --map-layout rows --steps 40
 line 5000_obs32_split $Q --landmarks 5000 --observed 32 --map-layout split --steps 40
 line 5000_obs32_paged $Q --landmarks 5000 --observed 32 --paged
+line 5000_obs32_auto $Q --landmarks 5000 --observed 32
 line north_star $Q --scaling strong --particles-total 1048576 --landmarks 1000 --steps 30
 line north_star_rows $Q --scaling strong --particles-total 1048576 --landmarks 1000 --steps 30 --map-layout rows
 line north_star_obs32_split $Q --scaling strong --particles-total 1048576 --landmarks 1000 --observed 32 --map-layout split --steps 30
 line north_star_obs32_paged $Q --scaling strong --particles-total 1048576 --landmarks 1000 --observed 32 --paged --steps 30
+line north_star_obs32_auto $Q --scaling strong --particles-total 1048576 --landmarks 1000 --observed 32 --steps 30
 line ekf_sweep_1m $Q --mode ekf --particles 1048576 --landmarks 1000 --steps 30
 line score_config3 $Q --mode score --particles 1048576 --grid 2048
 SLAM_SCORE_PACKED=0 line score_config3_float_grid $Q --mode score --particles 1048576 --grid 2048

@@ -268,6 +268,21 @@ def test_split_pages_give_the_bits_of_rows(n, L, cov, sparse, skip):
     _same(pages, _run("rows", n, L, 11, **kw))
 
 
+def test_split_pages_in_a_gated_session():
+    """An explicit SLAM_MAP_SPLIT_PAGES session with ESS-gated resampling (AUTO would keep a gated session on rows): frames that
+    keep their population update through the identity index; the bits of a gated row session."""
+    from test_gpu_auto_layout import _run as auto_run
+
+    rows = auto_run("rows", 4096, 400, 30, ess=0.3)
+    pages = auto_run("split_pages", 4096, 400, 30, ess=0.3)
+    assert all(pages["paged"]) and pages["changes"] == 0
+    assert np.array_equal(bits(pages["pose"]), bits(rows["pose"]))
+    for f, m in rows["maps"].items():
+        assert np.array_equal(bits(pages["maps"][f]), bits(m)), f
+    for a, b in zip(pages["best"], rows["best"]):
+        assert a[2] == b[2] and a[1] == b[1] and np.array_equal(bits(a[0]), bits(b[0]))
+
+
 def test_split_pages_map_io():
     """set_map / map getters / reset on split pages."""
     import _shard_worker as W
