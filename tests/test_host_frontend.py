@@ -57,6 +57,66 @@ def test_frontend_matches_oracle_and_reference_under_sanitizers(orc, golden, tmp
         assert np.array_equal(i32(f"grid{k}").reshape(ld, ld), grid)
 
 
+def _parse_both(tmp_path, text, n, tag):
+    """(conversions, stream position, floats) of n fields of `text`: with fscanf("%f,") and with fe_read_frame."""
+    exe = tmp_path / "parse_driver"
+    if not exe.exists():
+        subprocess.run(["gcc", "-O1", "-g", "-std=gnu11", "-ffp-contract=off", "-fsanitize=address,undefined",
+                        "-fno-sanitize-recover=undefined", "-o", str(exe), str(ROOT / "tests" / "parse_driver.c"),
+                        str(PKG_DIR / "host" / "slam_frontend.c"), "-lm"], check=True)
+    src, out = tmp_path / f"{tag}.csv", tmp_path / f"{tag}.bin"
+    src.write_text(text)
+    subprocess.run([str(exe), str(src), str(n), str(out)], check=True)
+    raw = out.read_bytes()
+    ok_a, ok_b = struct.unpack_from("<ii", raw, 0)
+    pos_a, pos_b = struct.unpack_from("<qq", raw, 8)
+    v = np.frombuffer(raw, np.float32, offset=24)
+    return (ok_a, pos_a, v[:n]), (ok_b, pos_b, v[n:2 * n])
+
+
+def test_frame_reader_equals_fscanf_on_every_kind_of_field(tmp_path):
+    """fe_read_frame does not go through fscanf (main.c:26-29 does): it must convert the same fields to the same floats and
+    leave the stream where fscanf leaves it — the plain decimals "%f" prints (its own fast path: one exact float division),
+    values too long or too large for that path, exponents, inf / nan, hexadecimal floats, signs, missing integer or fraction
+    parts, white space and line breaks between fields, a missing last comma, end of file inside a frame."""
+    rng = np.random.default_rng(11)
+    fields = []
+    for scale in (1e-6, 1e-3, 1.0, 10.0, 16.0, 17.0, 100.0, 1e4, 1e7, 1e12):
+        x = (rng.random(300) * scale).astype(np.float64)
+        fields += [f"{v:f}" for v in x[:100]] + [f"{v:.3f}" for v in x[100:150]] + [f"{v:.9g}" for v in x[150:200]]
+        fields += [f"{v:e}" for v in x[200:230]] + [f"{-v:f}" for v in x[230:260]] + [f"{v:.12f}" for v in x[260:300]]
+    fields += ["16777215.000000", "16777216.000000", "16777217.000000", "16777217.500000", "33554433.000000", "0.000000", "-0.000000",
+               "+1.500000", ".5", "5.", "-.25", "007.250000", "1e5", "1E-3", "2.5e+2", "inf", "-inf", "INF", "nan", "-nan", "NaN",
+               "infinity", "0x1.8p3", "0X1P-2", "123456789012345678901234567890.5", "0.12345678901234567890123456789",
+               "4294967296.000000", "9.999999", "24.000001", "0.023000", "3.4028235e38", "1e39", "1e-46", "1.17549435e-38"]
+    # every tie between two neighbouring floats near 1 and near 20, written out in full: the correctly rounded result is the even one
+    for base in (1.0, 19.5):
+        f0 = np.float32(base)
+        for k in range(40):
+            f1 = np.nextafter(f0, np.float32(np.inf), dtype=np.float32)
+            mid = (float(f0) + float(f1)) / 2.0
+            fields += [f"{mid:.30f}", f"{np.nextafter(mid, 0.0):.30f}", f"{np.nextafter(mid, 100.0):.30f}"]
+            f0 = f1
+    order = rng.permutation(len(fields))
+    fields = [fields[i] for i in order]
+    seps = [",", ", ", ",\n", ",  ", ",\t", ",\r\n"]   # (white space BEFORE a comma stops the reference's reader for good: below)
+    text = "".join(f + seps[i % len(seps)] for i, f in enumerate(fields))
+    n = len(fields)
+    a, b = _parse_both(tmp_path, text, n, "mixed")
+    assert a[0] == n and b[0] == n and a[1] == b[1]
+    assert np.array_equal(bits(a[2]), bits(b[2])), np.nonzero(bits(a[2]) != bits(b[2]))[0][:10]
+    # no comma behind the last field; fewer fields than asked for (end of file inside the frame): the rest keeps its content
+    a, b = _parse_both(tmp_path, "1.250000,2.500000,3.750000", 5, "short")
+    assert a[0] == b[0] == 3 and np.array_equal(bits(a[2]), bits(b[2]))
+    a, b = _parse_both(tmp_path, "", 3, "empty")
+    assert a[0] == b[0] == 0 and np.array_equal(bits(a[2]), bits(b[2]))
+    # a field that is no number stops both readers for good: same count, same floats
+    a, b = _parse_both(tmp_path, "1.5,2.5,abc,3.5,4.5,", 5, "garbage")
+    assert a[0] == b[0] == 2 and np.array_equal(bits(a[2]), bits(b[2]))
+    a, b = _parse_both(tmp_path, "1.5 ,2.5,3.5,", 4, "space_before_comma")
+    assert a[0] == b[0] == 1 and np.array_equal(bits(a[2]), bits(b[2]))
+
+
 def test_oracle_whole_program_under_sanitizers(orc, tmp_path):
     """ASan/UBSan build of the CPU restatement over 200 frames (GPU sanitizers are unavailable on the pool)."""
     subprocess.run(["make", "-s", "-C", str(ROOT / "oracle"), "_build/main_cpu_asan"], check=True)
