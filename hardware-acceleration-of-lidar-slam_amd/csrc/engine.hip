@@ -127,7 +127,7 @@ void philox_host(uint32_t c[4], uint32_t k0, uint32_t k1)
 static hipError_t engine_host_block(slam_engine* e)
 {
     auto up = [](size_t b) { return (b + 255) / 256 * 256; };
-    const size_t b_fm = up(sizeof(float) * (kFmIn + kFmOut + 4)), b_plan = up(sizeof(int32_t) * (SLAM_PLAN_WORDS(kMaxRanks) + 1)),
+    const size_t b_fm = up(sizeof(float) * (kFmIn + kFmOut + 4 + kFmPair)), b_plan = up(sizeof(int32_t) * (SLAM_PLAN_WORDS(kMaxRanks) + 1)),
                  b_small = 256, b_res = 256, b_stage = up(sizeof(float) * kStageSlots * kStageFloats);
     const size_t total = b_fm + b_plan + 3 * b_small + b_res + b_stage;
     hipError_t err = hipHostMalloc(&e->h_block, total, hipHostMallocMapped);
@@ -213,7 +213,7 @@ int slam_engine_create(int device, slam_engine** out)
         slam_engine_destroy(e);
         return SLAM_ERR_NO_DEVICE;
     }
-    memset(e->h_fm, 0, sizeof(float) * (kFmIn + kFmOut + 4));   // arrival flag starts at 0, sequence numbers at 1
+    memset(e->h_fm, 0, sizeof(float) * (kFmIn + kFmOut + 4 + kFmPair));   // arrival flag starts at 0, sequence numbers at 1
     memset(e->h_plan, 0, sizeof(int32_t) * (SLAM_PLAN_WORDS(kMaxRanks) + 1));
     e->h_gate[0] = 1;
     e->h_gate[1] = 0;
@@ -665,6 +665,108 @@ int slam_engine_fastmatch(slam_engine* e, int slot, const float* d_bx, const flo
     memcpy(&maxc, h_out + 2 * kLattice, sizeof maxc);
     if (maxc > 0 && best_hits) memcpy(best_hits, h_out + 2 * kLattice + 1, sizeof(float) * (size_t)maxc);
     if (best_score) *best_score = best;
+    return SLAM_OK;
+}
+
+// main.c:901-924 as ONE round trip: FastMatch(pose, res1) on grid slot1, then FastMatch2(its result, res2) on grid slot2 — the
+// second call's lattice is laid out on the device around the first call's best candidate, so the host waits once instead of
+// twice (a call is bound by that wait: 30 us, of which the kernels are a third).  What the reference computes with libm
+// stays on the host: the first call's best heading is one of three values, so the second call's three headings are among
+// NINE known before the launch; the host sends the cosines and sines of all nine and the device picks its three.  The
+// candidates' x and y are one float add / subtract each, the same on the device.  The host repeats both arg-min decisions
+// on the scores it receives (strict '<', the first of equals; nothing below +inf: the input pose and the previous size) —
+// the device's choice of the first call's winner is the same computation on the same floats.
+int slam_engine_fastmatch_pair(slam_engine* e, int slot1, int slot2, const float* d_bx, const float* d_by, int nbeams_max,
+                               const int32_t* d_nbeams, const float pose[3], const float res1[3], const float res2[3],
+                               float out_pose[3], int32_t* best_hits_size, float* d_hits_persist)
+{
+    const float t1 = res1[0], r1 = res1[2], t2 = res2[0], r2 = res2[2];
+    const float th1[3] = { pose[2] - r1, pose[2], pose[2] + r1 };
+    const float xs[3] = { pose[0] - t1, pose[0], pose[0] + t1 };
+    const float ys[3] = { pose[1] - t1, pose[1], pose[1] + t1 };
+    float* h_in = e->h_fm;
+    float* h_out2 = e->h_fm + kFmIn;
+    float* h_pair_in = e->h_fm + kFmIn + kFmOut + 4;
+    float* h_out1 = h_pair_in + kFmPairIn;
+    float th2[3][3];
+    for (int a = 0; a < 3; ++a) {
+        const float c = cosf(th1[a]), s = sinf(th1[a]);
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) {
+                const int k = (a * 3 + i) * 3 + j;   // evaluation order theta, x, y (main.c:443-487)
+                h_in[k] = xs[i];
+                h_in[kLattice + k] = ys[j];
+                h_in[2 * kLattice + k] = c;
+                h_in[3 * kLattice + k] = s;
+            }
+        th2[a][0] = th1[a] - r2;
+        th2[a][1] = th1[a];
+        th2[a][2] = th1[a] + r2;
+        for (int b = 0; b < 3; ++b) {
+            h_pair_in[a * 3 + b] = cosf(th2[a][b]);
+            h_pair_in[9 + a * 3 + b] = sinf(th2[a][b]);
+        }
+    }
+    h_pair_in[18] = t2;
+    float* d_cand2 = e->fm_buf.as<float>();   // the second call's candidates (the device's own copy of the table: 4 x 27 floats)
+    float* d_out = e->fm_buf.as<float>() + kFmIn;
+    volatile uint32_t* h_flag = reinterpret_cast<volatile uint32_t*>(e->h_fm + kFmIn + kFmOut);
+    const uint32_t seq = ++e->fm_seq;
+    LatticeChain chain;
+    chain.cand1 = e->d_hfm;
+    chain.pair_in = e->d_hfm + kFmIn + kFmOut + 4;
+    chain.cand2 = d_cand2;
+    HIP_TRY(launch_lattice(e->stream, score_grid(e->grid[slot1]), d_bx, d_by, nbeams_max, d_nbeams, e->d_hfm, e->fm_work.as<float>(), d_out,
+                           d_hits_persist, e->d_hfm + kFmIn + kFmOut + 4 + kFmPairIn, nullptr, 0, &chain));
+    HIP_TRY(launch_lattice(e->stream, score_grid(e->grid[slot2]), d_bx, d_by, nbeams_max, d_nbeams, d_cand2, e->fm_work.as<float>(), d_out,
+                           d_hits_persist, e->d_hfm + kFmIn, reinterpret_cast<uint32_t*>(e->d_hfm + kFmIn + kFmOut), seq));
+    {
+        bool arrived = false;
+        for (long spin = 0; spin < 400000000L; ++spin) {   // bounded: a few seconds at most
+            if (__atomic_load_n(h_flag, __ATOMIC_ACQUIRE) == seq) { arrived = true; break; }
+        }
+        if (!arrived) {
+            HIP_TRY(hipStreamSynchronize(e->stream));
+            if (__atomic_load_n(h_flag, __ATOMIC_ACQUIRE) != seq) return fail_hip(e, hipErrorUnknown, "lattice result flag");
+        }
+    }
+    // the first call (main.c:549-563): strict '<' keeps the first of equal scores; nothing below +inf: the input pose, size untouched
+    float best = INFINITY;
+    int k1 = -1;
+    for (int k = 0; k < kLattice; ++k)
+        if (h_out1[k] < best) {
+            best = h_out1[k];
+            k1 = k;
+        }
+    float p1[3] = { pose[0], pose[1], pose[2] };
+    int a1 = 1;
+    if (k1 >= 0) {
+        p1[0] = h_in[k1];
+        p1[1] = h_in[kLattice + k1];
+        a1 = k1 / 9;
+        p1[2] = th1[a1];
+        memcpy(best_hits_size, h_out1 + kLattice + k1, sizeof(int32_t));
+    }
+    // the second call, laid out around p1 (the device built the same table around the same candidate)
+    const float xs2[3] = { p1[0] - t2, p1[0], p1[0] + t2 };
+    const float ys2[3] = { p1[1] - t2, p1[1], p1[1] + t2 };
+    best = INFINITY;
+    int k2 = -1;
+    for (int k = 0; k < kLattice; ++k)
+        if (h_out2[k] < best) {
+            best = h_out2[k];
+            k2 = k;
+        }
+    if (k2 >= 0) {
+        out_pose[0] = xs2[(k2 / 3) % 3];
+        out_pose[1] = ys2[k2 % 3];
+        out_pose[2] = th2[a1][k2 / 9];
+        memcpy(best_hits_size, h_out2 + kLattice + k2, sizeof(int32_t));
+    } else {
+        out_pose[0] = p1[0];
+        out_pose[1] = p1[1];
+        out_pose[2] = p1[2];
+    }
     return SLAM_OK;
 }
 

@@ -54,6 +54,10 @@ constexpr int kLattice = 27;
 //   out: SCORE[27] COUNT[27] NLAST[1] HITS[SLAM_MAX_BEAMS]
 constexpr int kFmIn = 4 * kLattice + 4;
 constexpr int kFmOut = 2 * kLattice + 1 + SLAM_MAX_BEAMS;
+// the chained pair of FastMatch calls (slam_engine_fastmatch_pair), behind the arrival flag's 4 words: in — the nine headings of
+// the second call's lattices as cos[9] | sin[9], its step, a spare word; out — the first call's scores and counts
+constexpr int kFmPairIn = 20;
+constexpr int kFmPair = kFmPairIn + 2 * kLattice;
 constexpr unsigned kStageSlots = 8;
 constexpr size_t kStageFloats = 3 * SLAM_MAX_OBS > 2 * SLAM_MAX_BEAMS ? 3 * SLAM_MAX_OBS : 2 * SLAM_MAX_BEAMS;
 
@@ -268,6 +272,10 @@ slam::ScoreGrid slam_engine_score_grid(const slam_engine* e, int slot);
 int slam_engine_fastmatch(slam_engine* e, int slot, const float* d_bx, const float* d_by, int nbeams_max,
                           const int32_t* d_nbeams, const float pose[3], const float res[3], float out_pose[3],
                           float* best_hits, int32_t* best_hits_size, float* best_score, float* d_hits_persist);
+// ... and FastMatch(pose, res1) on slot1 followed by FastMatch2(its result, res2) on slot2 as ONE round trip (engine.hip)
+int slam_engine_fastmatch_pair(slam_engine* e, int slot1, int slot2, const float* d_bx, const float* d_by, int nbeams_max,
+                               const int32_t* d_nbeams, const float pose[3], const float res1[3], const float res2[3],
+                               float out_pose[3], int32_t* best_hits_size, float* d_hits_persist);
 
 // slam_migrate_pack_dev for a session with paged maps (d_pt: page tables of nb entries, d_map: the page pool)
 extern "C" int slam_migrate_pack_paged(slam_engine* e, int n_local, int rank, int world, const int32_t* plan, const float* d_pose,

@@ -75,9 +75,19 @@ hipError_t launch_pose_hits(hipStream_t stream, const ScoreGrid& g, const float*
 // d_nbeams (optional): the beam count lives on the device (<= nbeams, which then is the capacity / row stride).
 // persist (optional): device mirror of the caller's persistent hit scratch, updated like the host copy.
 // host_out / host_flag / seq (optional): also deliver `out` to mapped pinned host memory and release `seq`.
+// chain (optional; the first call of a chained pair, engine.hip: slam_engine_fastmatch_pair): host_out then receives the scores
+// and counts only (no merged hits, no flag), and the launch also lays out the NEXT call's candidates in cand2: the lattice
+// around this call's best candidate (strict '<' from +inf, the first of equals; none: the middle candidate = the input pose)
+// with step pair_in[18] and the headings' cos[9] | sin[9] of pair_in, row = this call's best heading.
+struct LatticeChain {
+    const float* cand1 = nullptr;     // this call's candidate table
+    const float* pair_in = nullptr;
+    float* cand2 = nullptr;
+};
 hipError_t launch_lattice(hipStream_t stream, const ScoreGrid& g, const float* bx, const float* by, int nbeams,
                           const int32_t* d_nbeams, const float* cand_xycs /* X[27] Y[27] CT[27] ST[27] */, float* work,
-                          float* out, float* persist, float* host_out, uint32_t* host_flag, uint32_t seq);
+                          float* out, float* persist, float* host_out, uint32_t* host_flag, uint32_t seq,
+                          const LatticeChain* chain = nullptr);
 
 // ---- mapper_kernels.hip (reference: main.c:71-198, 271-354, 941-953)
 hipError_t launch_clean_scan(hipStream_t s, const float* range, const float* cos_tab, const float* sin_tab, int nbeams,

@@ -223,13 +223,22 @@ int slam_mapper_next_frame(slam_mapper* m, const float* ranges, float pose_out[3
     float guess[3];   // main.c:875-898
     for (int a = 0; a < 3; ++a) guess[a] = m->frame > 1 ? m->pose[a] + (m->pose[a] - m->prev[a]) : m->pose[a];
     // main.c:901-918 (coarse step on the fine grid when the map was not just rebuilt)
+    // both calls as one round trip (SLAM_FASTMATCH_PAIR=0: one after the other, the host in between)
+    static const bool pair = !(getenv("SLAM_FASTMATCH_PAIR") && atoi(getenv("SLAM_FASTMATCH_PAIR")) == 0);
     float m1[3], m2[3];
-    int rc = slam_engine_fastmatch(m->e, m->mini_updated ? 0 : 1, m->d_bx, m->d_by, m->nbeams, m->d_counts + 0, guess,
+    int rc;
+    if (pair) {
+        rc = slam_engine_fastmatch_pair(m->e, m->mini_updated ? 0 : 1, 1, m->d_bx, m->d_by, m->nbeams, m->d_counts + 0, guess, coarse,
+                                        fine, m2, &m->nhits, m->d_hits);
+        if (rc != SLAM_OK) return rc;
+    } else {
+        rc = slam_engine_fastmatch(m->e, m->mini_updated ? 0 : 1, m->d_bx, m->d_by, m->nbeams, m->d_counts + 0, guess,
                                    coarse, m1, nullptr, &m->nhits, nullptr, m->d_hits);
-    if (rc != SLAM_OK) return rc;
-    rc = slam_engine_fastmatch(m->e, 1, m->d_bx, m->d_by, m->nbeams, m->d_counts + 0, m1, fine, m2, nullptr, &m->nhits,
-                               nullptr, m->d_hits);
-    if (rc != SLAM_OK) return rc;
+        if (rc != SLAM_OK) return rc;
+        rc = slam_engine_fastmatch(m->e, 1, m->d_bx, m->d_by, m->nbeams, m->d_counts + 0, m1, fine, m2, nullptr, &m->nhits,
+                                   nullptr, m->d_hits);
+        if (rc != SLAM_OK) return rc;
+    }
     memcpy(m->prev, m->pose, sizeof m->prev);
     memcpy(m->pose, m2, sizeof m->pose);
     // main.c:928-961

@@ -252,7 +252,7 @@ __global__ __launch_bounds__(64) void lattice_kernel(ScoreGrid g, const float* _
 __global__ __launch_bounds__(256) void lattice_merge_kernel(const float* __restrict__ work, int nbeams,
                                                             float* __restrict__ out, float* __restrict__ persist,
                                                             float* __restrict__ host_out,
-                                                            uint32_t* __restrict__ host_flag, uint32_t seq)
+                                                            uint32_t* __restrict__ host_flag, uint32_t seq, LatticeChain chain)
 {
     __shared__ int s_cnt[kLatticeN];
     const int32_t* cnt = reinterpret_cast<const int32_t*>(out) + kLatticeN;
@@ -268,7 +268,32 @@ __global__ __launch_bounds__(256) void lattice_merge_kernel(const float* __restr
         const float v = work[(size_t)c * nbeams + j];
         merged[j] = v;
         if (persist) persist[j] = v;   // device-resident copy of the caller's persistent hit scratch
-        if (host_out) host_out[2 * kLatticeN + 1 + j] = v;
+        if (host_out && !chain.cand2) host_out[2 * kLatticeN + 1 + j] = v;
+    }
+    if (chain.cand2) {
+        // the first call of a chained pair (kernels.h: LatticeChain): scores and counts to the host (the second call's launch
+        // releases the flag), the winner, and the next call's lattice around it
+        if (threadIdx.x < 2 * kLatticeN && host_out) host_out[threadIdx.x] = out[threadIdx.x];
+        if (threadIdx.x < kLatticeN) {
+            float best = INFINITY;
+            int bk = -1;
+            for (int k = 0; k < kLatticeN; ++k)   // main.c:549-563: strict '<' keeps the first of equal scores
+                if (out[k] < best) {
+                    best = out[k];
+                    bk = k;
+                }
+            if (bk < 0) bk = kLatticeN / 2;   // nothing below +inf: the input pose = the middle candidate (heading 1, x 1, y 1)
+            const float x = chain.cand1[bk], y = chain.cand1[kLatticeN + bk], t = chain.pair_in[18];
+            const int a = bk / 9, k = threadIdx.x, b = k / 9, i = (k / 3) % 3, j = k % 3;
+            const float xs = i == 0 ? x - t : (i == 1 ? x : x + t);
+            const float ys = j == 0 ? y - t : (j == 1 ? y : y + t);
+            chain.cand2[k] = xs;
+            chain.cand2[kLatticeN + k] = ys;
+            chain.cand2[2 * kLatticeN + k] = chain.pair_in[a * 3 + b];
+            chain.cand2[3 * kLatticeN + k] = chain.pair_in[9 + a * 3 + b];
+        }
+        __threadfence_system();   // (the scores for the host: complete before the launch ends, whatever the memory's caching)
+        return;
     }
     if (host_out) {
         if (threadIdx.x < 2 * kLatticeN) host_out[threadIdx.x] = out[threadIdx.x];   // scores and counts (bit copies)
@@ -283,11 +308,11 @@ __global__ __launch_bounds__(256) void lattice_merge_kernel(const float* __restr
 
 hipError_t launch_lattice(hipStream_t stream, const ScoreGrid& g, const float* bx, const float* by, int nbeams,
                           const int32_t* d_nbeams, const float* cand_xycs, float* work, float* out, float* persist,
-                          float* host_out, uint32_t* host_flag, uint32_t seq)
+                          float* host_out, uint32_t* host_flag, uint32_t seq, const LatticeChain* chain)
 {
     const size_t lds = sizeof(float) * (size_t)(nbeams > 0 ? nbeams : 1);
     lattice_kernel<<<kLatticeN, 64, lds, stream>>>(g, bx, by, nbeams, d_nbeams, cand_xycs, work, out);
-    lattice_merge_kernel<<<1, 256, 0, stream>>>(work, nbeams, out, persist, host_out, host_flag, seq);
+    lattice_merge_kernel<<<1, 256, 0, stream>>>(work, nbeams, out, persist, host_out, host_flag, seq, chain ? *chain : LatticeChain());
     return hipGetLastError();
 }
 
