@@ -95,14 +95,16 @@ typedef enum {
     SLAM_PROF_SCORE = 0,        /* score_poses_kernel (with or without the motion sample), lattice kernels */
     SLAM_PROF_EDT = 1,          /* edt kernels */
     SLAM_PROF_EKF = 2,          /* the landmark update of a frame, whichever kernel runs it (rows, grouped, list, pages) */
-    SLAM_PROF_WEIGHTS = 3,      /* log-weights + block maxima (+ the maximum's finalize launch on several GPUs) */
+    SLAM_PROF_WEIGHTS = 3,      /* log-weights + block maxima (+ the maximum's finalize launch on several GPUs); a split session's
+                                   covariance classes are brought up to date by workgroups of the same launch */
     SLAM_PROF_SCAN = 4,         /* quantise + prefix sum (+ ESS sums) */
     SLAM_PROF_ANCESTORS = 5,    /* offspring offsets / ancestor search (single GPU: one launch) */
     SLAM_PROF_PLAN = 6,         /* several GPUs: global ancestor search, flag scans, exchange plan, local gather index */
     SLAM_PROF_PACK = 7,         /* several GPUs: migrating rows into the send buffer */
     SLAM_PROF_UNPACK = 8,       /* several GPUs: received rows into the staging tail */
     SLAM_PROF_COLLECTIVES = 9,  /* every exchange between ranks (all-reduce, all-gathers, send/recv), as the stream sees them */
-    SLAM_PROF_PAGES = 10,       /* map bookkeeping: paged maps' touched-page list, free list, table gathers; split maps' class update */
+    SLAM_PROF_PAGES = 10,       /* map bookkeeping: paged maps' touched-page list, table gathers, the free list where it is a launch of
+                                   its own (one GPU: it travels in the scorer's launch); split maps' gathers on frames without observations */
     SLAM_PROF_EKF_TAIL = 11,    /* several GPUs, split maps: the part of the landmark update that waits for the exchange (the
                                    groups with an ancestor in the staging tail); the rest went out with the score (SLAM_PROF_EKF) */
     SLAM_PROF_COUNT = 12
