@@ -32,6 +32,9 @@ line obs32_split_pages $Q --observed 32 --map-layout split_pages
 line obs32_auto $Q --observed 32
 line obs32_ess0.3 $Q --observed 32 --ess 0.3 --map-layout rows --steps 120
 line obs32_ess0.1 $Q --observed 32 --ess 0.1 --map-layout rows --steps 120
+line obs32_ess0.3_auto $Q --observed 32 --ess 0.3 --steps 120
+line ess0.3_auto $Q --ess 0.3 --steps 120
+line ess0.3_rows $Q --ess 0.3 --steps 120 --map-layout rows
 line obs128_rows $Q --observed 128 --map-layout rows
 line obs128_split $Q --observed 128 --map-layout split
 line obs128_paged $Q --observed 128 --paged

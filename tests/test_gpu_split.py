@@ -268,6 +268,33 @@ def test_split_pages_give_the_bits_of_rows(n, L, cov, sparse, skip):
     _same(pages, _run("rows", n, L, 11, **kw))
 
 
+@pytest.mark.parametrize("ess", [0.3, 0.05])
+def test_split_in_a_gated_session(ess):
+    """ESS-gated resampling on the split layout: a frame that keeps its population updates through the identity index (the
+    split update has no in-place form), the weights carry over; dense and sparse frames; the bits of a gated row session."""
+    from test_gpu_auto_layout import _run as auto_run
+
+    rows = auto_run("rows", 4096, 400, 30, ess=ess)
+    split = auto_run("split", 4096, 400, 30, ess=ess)
+    assert not any(split["paged"]) and split["changes"] == 0
+    assert np.array_equal(bits(split["pose"]), bits(rows["pose"]))
+    for f, m in rows["maps"].items():
+        assert np.array_equal(bits(split["maps"][f]), bits(m)), f
+    for a, b in zip(split["best"], rows["best"]):
+        assert a[2] == b[2] and a[1] == b[1] and np.array_equal(bits(a[0]), bits(b[0]))
+
+
+def test_sharded_split_in_a_gated_session():
+    """... and sharded: 3 ranks on one card, gated, split layout, against one gated rank on rows."""
+    from test_gpu_configs import _run_c_session_ranks
+
+    n_total, L, frames = 3072, 100, 14
+    ref = _run_c_session_ranks(1, n_total, L, frames, transport=None, ess=0.4)[0]
+    many = _run_c_session_ranks(3, n_total, L, frames, layout="split", ess=0.4)
+    assert np.array_equal(bits(np.concatenate([p["pose"] for p in many], axis=1)), bits(ref["pose"]))
+    assert np.array_equal(bits(np.concatenate([p["map"] for p in many], axis=0)), bits(ref["map"]))
+
+
 def test_split_pages_in_a_gated_session():
     """An explicit SLAM_MAP_SPLIT_PAGES session with ESS-gated resampling (AUTO would keep a gated session on rows): frames that
     keep their population update through the identity index; the bits of a gated row session."""
