@@ -267,8 +267,9 @@ int slam_ekf_form_counts(slam_engine *e, int64_t counts[2]);
  * main.c:459-518, for every particle) and the out-of-place landmark update — goes out as ONE launch whose scoring and
  * updating workgroups are dealt out interleaved: the scorer's gathers (texture addresser, L2) run in the shadow of the
  * update's row stores (HBM).  Same bits as the two launches.  on = 1 (the initial state) / 0: two launches (stage timers,
- * measurements; the environment variable SLAM_FRAME_FUSION overrides).  Sharded, gated and paged sessions, short rows and
- * small populations always take the two launches, and so does every frame while SLAM_PROF_SCORE is being timed
+ * measurements; the environment variable SLAM_FRAME_FUSION overrides).  Paged sessions, gated sessions on rows, sharded sessions
+ * on rows, short rows and small populations always take the two launches (a sharded session on the split layout fuses the
+ * score with the update of the groups whose ancestors are local), and so does every frame while SLAM_PROF_SCORE is being timed
  * (slam_profile_enable: a fused launch is bracketed as SLAM_PROF_EKF).  slam_frame_fusion_count: fused launches of this engine so far. */
 int slam_frame_fusion_set(slam_engine *e, int on);
 int slam_frame_fusion_count(slam_engine *e, int64_t *launches);
@@ -444,10 +445,12 @@ typedef enum { SLAM_MAP_AUTO = 0, SLAM_MAP_ROWS = 1, SLAM_MAP_PAGES = 2, SLAM_MA
  * they share ONE row of covariance planes, updated once per frame, while every particle keeps its own two planes of means:
  * a resampling frame that observes every landmark reads 8 and writes 8 bytes per (particle, landmark) instead of 20 and 20.
  * Classes are found when maps come in (slam_pf_set_map_*: neighbouring particles with bit-identical covariance planes share a
- * class) and die with their last particle.  The same bits as rows and pages; one GPU only (SLAM_ERR_INVALID_ARG for a sharded
- * session).  slam_pf_device_view gives map = NULL while a session is split, like pages. */
-/* SLAM_MAP_AUTO keeps a single-GPU session that resamples every frame on the SPLIT layout instead of rows (sharded and gated
- * sessions: rows), and otherwise works as described here, "rows" meaning that dense layout.
+ * class) and die with their last particle.  The same bits as rows and pages, on one GPU and sharded (classes are local to a
+ * rank; a migrating particle becomes a class of its own where it arrives).  slam_pf_device_view gives map = NULL while a
+ * session is split, like pages. */
+/* SLAM_MAP_AUTO keeps a session on the SPLIT layout instead of rows (single-GPU or sharded, resampling every frame or
+ * ESS-gated), and otherwise works as described here, "rows" meaning that dense layout and "pages" SLAM_MAP_SPLIT_PAGES for a
+ * single-GPU session (a sharded one goes through rows to SLAM_MAP_PAGES).
  * SLAM_MAP_AUTO starts on rows and watches how many landmarks the frames observe (a count the update kernels leave in
  * mapped host memory: every frame at the start and while they speak against the current layout, every 8th frame otherwise;
  * read without waiting, except in a session's first four frames, which wait for the count of the frame before so that the
