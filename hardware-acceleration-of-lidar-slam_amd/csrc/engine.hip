@@ -1403,18 +1403,19 @@ int slam_migrate_pack_dev(slam_engine* e, int n_local, int rank, int world, cons
                           float* d_out)
 {
     return slam_migrate_pack_paged(e, n_local, rank, world, plan, d_pose, pose_ld, d_map, row_stride, plane_stride, nlandmarks,
-                                   d_out, nullptr, 0);
+                                   d_out, nullptr, 0, nullptr, nullptr, nullptr);
 }
 
 // d_pt != nullptr: d_map is a page pool and the particles' landmarks sit behind page tables of nb entries (pf_session.hip)
 int slam_migrate_pack_paged(slam_engine* e, int n_local, int rank, int world, const int32_t* plan, const float* d_pose,
                             int64_t pose_ld, const float* d_map, int64_t row_stride, int plane_stride, int nlandmarks,
-                            float* d_out, const int32_t* d_pt, int nb, const float* d_split_cov, const int32_t* d_split_cls)
+                            float* d_out, const int32_t* d_pt, int nb, const float* d_split_cov, const int32_t* d_split_cls,
+                            const slam::PageGeom* geom)
 {
     ENTER(e);
     if (n_local <= 0 || world < 1 || world > kMaxRanks || rank < 0 || rank >= world || !plan || nlandmarks < 0 ||
         !d_pose || (nlandmarks > 0 && (!d_map || plane_stride < nlandmarks || row_stride < (d_split_cls ? 2 : 5) * (int64_t)plane_stride)) ||
-        (d_split_cls && !d_split_cov))
+        (d_split_cls && !d_split_cov) || (d_split_cls && d_pt && !geom))
         return SLAM_ERR_INVALID_ARG;
     if (e->shard_n != n_local) return SLAM_ERR_NOT_READY;   // needs slam_ancestors_sharded_dev(n_local) of this frame
     MigratePlan mp;
@@ -1424,7 +1425,7 @@ int slam_migrate_pack_paged(slam_engine* e, int n_local, int rank, int world, co
     if (mp.off[world] > 0 && !d_out) return SLAM_ERR_INVALID_ARG;
     const ProfScope prof(e, SLAM_PROF_PACK);
     HIP_TRY(launch_migrate_pack(e->stream, e->shard_buf.as<int32_t>(), n_local, mp, d_pose, pose_ld, d_map, row_stride,
-                                plane_stride, nlandmarks, d_out, d_pt, nb, d_split_cov, d_split_cls));
+                                plane_stride, nlandmarks, d_out, d_pt, nb, d_split_cov, d_split_cls, geom ? *geom : PageGeom()));
     return SLAM_OK;
 }
 

@@ -281,7 +281,8 @@ int slam_engine_fastmatch_pair(slam_engine* e, int slot1, int slot2, const float
 extern "C" int slam_migrate_pack_paged(slam_engine* e, int n_local, int rank, int world, const int32_t* plan, const float* d_pose,
                             int64_t pose_ld, const float* d_map, int64_t row_stride, int plane_stride, int nlandmarks,
                             float* d_out, const int32_t* d_pt, int nb, const float* d_split_cov = nullptr,
-                            const int32_t* d_split_cls = nullptr);   // split layout: d_map = the means (row_stride >= 2 planes)
+                            const int32_t* d_split_cls = nullptr,   // split layout: d_map = the means (row_stride >= 2 planes)
+                            const slam::PageGeom* geom = nullptr);   // split pages (d_pt and d_split_cls): d_map = the pool of mean pages
 
 #define SLAM_HIP_TRY(e, call)                                                     \
     do {                                                                          \

@@ -348,6 +348,13 @@ hipError_t launch_rows_from_split_pages(hipStream_t stream, const float* pool, c
 // whether launch_free_list, to be called behind it, has to make a new list first), and the unpack itself: record p of
 // `in` (pose + 5 x nlandmarks floats, as launch_migrate_pack writes them) -> table row n + p on fresh pages, stamped `live`
 hipError_t launch_pool_reserve(hipStream_t stream, int32_t* pool_state, int64_t want);
+// ... for a session on SPLIT PAGES: record p -> its means on fresh pages of two planes behind table row n + p, its covariances (and
+// their determinant terms, meas_var) as class cls_free[cls_first + p] of its own, appended to the list of classes in use
+hipError_t launch_migrate_unpack_split_pages(hipStream_t stream, const float* in, int total, int n, float* pose, int64_t pose_ld,
+                                             float* pool, const PageGeom& geom, int32_t* pt, int nb, int nlandmarks,
+                                             const int32_t* freelist, const int32_t* pool_state, uint32_t* stamp, uint32_t live,
+                                             float* cov, float* covx, int32_t* cls, int Lp, float meas_var, const int32_t* cls_free,
+                                             int cls_first, uint32_t* cstamp, uint32_t cstamp_now, int32_t* live_list, int32_t* live_cnt);
 hipError_t launch_migrate_unpack_paged(hipStream_t stream, const float* in, int total, int n, float* pose, int64_t pose_ld,
                                        float* pool, int32_t* pt, int nb, int nlandmarks, const int32_t* freelist,
                                        const int32_t* pool_state, uint32_t* stamp, uint32_t live);
@@ -419,7 +426,8 @@ hipError_t launch_migrate_pack(hipStream_t stream, const int32_t* scratch, int n
                                const float* pose, int64_t pose_ld, const float* map, int64_t row_stride,
                                int plane_stride, int nlandmarks, float* out,
                                const int32_t* pt = nullptr, int nb = 0,
-                               const float* split_cov = nullptr, const int32_t* split_cls = nullptr);
+                               const float* split_cov = nullptr, const int32_t* split_cls = nullptr,
+                               const PageGeom& geom = PageGeom());   // pt AND split_cls: split pages (means behind pt in pages of geom)
 hipError_t launch_migrate_unpack(hipStream_t stream, const float* in, const MigratePlan& plan, int n, float* pose,
                                  int64_t pose_ld, float* map, int64_t row_stride, int plane_stride, int nlandmarks);
 hipError_t launch_argmax(hipStream_t stream, const float* v, int n, int32_t* idx_out, float* val_out);

@@ -232,6 +232,53 @@ __global__ __launch_bounds__(256) void migrate_unpack_paged_kernel(const float* 
                 l < nlandmarks ? rec[3 + pl * nlandmarks + l] : (pl == 2 ? -1.0f : 0.0f);
 }
 
+// ... on split pages: the means on fresh pages of two planes, the covariances as a class of its own (what
+// migrate_unpack_split_kernel of split_kernels.hip does with them)
+__global__ __launch_bounds__(256) void migrate_unpack_split_pages_kernel(const float* __restrict__ in, int total, int n,
+                                                                         float* __restrict__ pose, int64_t pose_ld,
+                                                                         float* __restrict__ pool, PageGeom geom, int32_t* __restrict__ pt,
+                                                                         int nb, int nlandmarks, const int32_t* __restrict__ freelist,
+                                                                         const int32_t* __restrict__ pool_state,
+                                                                         uint32_t* __restrict__ stamp, uint32_t live, float* __restrict__ cov,
+                                                                         float* __restrict__ covx, int32_t* __restrict__ cls, int Lp, float q,
+                                                                         const int32_t* __restrict__ cls_free, int cls_first,
+                                                                         uint32_t* __restrict__ cstamp, uint32_t cstamp_now,
+                                                                         int32_t* __restrict__ live_list, int32_t* __restrict__ live_cnt)
+{
+    const int p = blockIdx.x;
+    if (p >= total) return;
+    const float* __restrict__ rec = in + (int64_t)(3 + 5 * nlandmarks) * p;
+    if (threadIdx.x < 3) pose[threadIdx.x * pose_ld + n + p] = rec[threadIdx.x];
+    const int32_t* __restrict__ mine = freelist + pool_state[kPoolBase] + (int64_t)p * nb;
+    for (int b = threadIdx.x; b < nb; b += 256) {
+        pt[(int64_t)(n + p) * nb + b] = mine[b];
+        stamp[mine[b]] = live;
+    }
+    const int c = cls_free[cls_first + p];
+    float* __restrict__ cr = cov + (int64_t)c * 3 * Lp;
+    float* __restrict__ xr = covx + (int64_t)c * 2 * Lp;
+    for (int l = threadIdx.x; l < nb * kPage; l += 256) {   // (nb * kPage = Lp; the tail of the last page: landmarks that do not exist)
+        const bool in_row = l < nlandmarks;
+        float* __restrict__ pg = pool + page_off(geom, mine[l / kPage]) + l % kPage;
+        pg[0] = in_row ? rec[3 + l] : 0.0f;
+        pg[kPage] = in_row ? rec[3 + nlandmarks + l] : 0.0f;
+        const float pxx = in_row ? rec[3 + 2 * nlandmarks + l] : 1.0f, pxy = in_row ? rec[3 + 3 * nlandmarks + l] : 0.0f,
+                    pyy = in_row ? rec[3 + 4 * nlandmarks + l] : 1.0f;
+        cr[l] = pxx;
+        cr[Lp + l] = pxy;
+        cr[2 * Lp + l] = pyy;
+        float idet = 1.0f, hl = 0.0f;
+        if (in_row && !(pxx < 0.0f)) ekf_det_terms<float>(pxx, pxy, pyy, q, idet, hl);
+        xr[l] = idet;
+        xr[Lp + l] = hl;
+    }
+    if (threadIdx.x == 0) {
+        cls[n + p] = c;
+        cstamp[c] = cstamp_now;
+        live_list[atomicAdd(live_cnt, 1)] = c;
+    }
+}
+
 // HALF a wavefront = one particle (32 lanes = the 32 landmarks of a page).  (1) its new page-table row: the ancestor's
 // entries, fresh pages for the touched ones, every named page stamped; (2) the touched pages one after the other.  A
 // particle's work is a handful of dependent round trips (ancestor -> table -> page -> store) and little else, so the
@@ -728,6 +775,19 @@ hipError_t launch_migrate_unpack_paged(hipStream_t stream, const float* in, int 
     if (total <= 0) return hipSuccess;
     migrate_unpack_paged_kernel<<<total, 256, 0, stream>>>(in, total, n, pose, pose_ld, pool, pt, nb, nlandmarks, freelist,
                                                           pool_state, stamp, live);
+    return hipGetLastError();
+}
+
+hipError_t launch_migrate_unpack_split_pages(hipStream_t stream, const float* in, int total, int n, float* pose, int64_t pose_ld,
+                                             float* pool, const PageGeom& geom, int32_t* pt, int nb, int nlandmarks,
+                                             const int32_t* freelist, const int32_t* pool_state, uint32_t* stamp, uint32_t live,
+                                             float* cov, float* covx, int32_t* cls, int Lp, float meas_var, const int32_t* cls_free,
+                                             int cls_first, uint32_t* cstamp, uint32_t cstamp_now, int32_t* live_list, int32_t* live_cnt)
+{
+    if (total <= 0) return hipSuccess;
+    migrate_unpack_split_pages_kernel<<<total, 256, 0, stream>>>(in, total, n, pose, pose_ld, pool, geom, pt, nb, nlandmarks, freelist,
+                                                                 pool_state, stamp, live, cov, covx, cls, Lp, meas_var, cls_free, cls_first,
+                                                                 cstamp, cstamp_now, live_list, live_cnt);
     return hipGetLastError();
 }
 

@@ -1825,7 +1825,7 @@ __global__ __launch_bounds__(kBlock) void migrate_pack_kernel(const int32_t* __r
                                                               int64_t row_stride, int plane_stride, int nlandmarks,
                                                               float* __restrict__ out, const int32_t* __restrict__ pt,
                                                               int nb, const float* __restrict__ split_cov,
-                                                              const int32_t* __restrict__ split_cls)
+                                                              const int32_t* __restrict__ split_cls, PageGeom geom)
 {
     const int p = blockIdx.x;
     int d = 0;
@@ -1839,6 +1839,18 @@ __global__ __launch_bounds__(kBlock) void migrate_pack_kernel(const int32_t* __r
     const int loc = lo;
     float* __restrict__ rec = out + (int64_t)(3 + 5 * nlandmarks) * p;
     if (threadIdx.x < 3) rec[threadIdx.x] = pose[threadIdx.x * pose_ld + loc];
+    if (pt && split_cls) {   // split pages: the means behind the page table (pages of two planes, kernels.h: PageGeom), the
+        const int32_t* __restrict__ tab = pt + (int64_t)loc * nb;   // covariance planes in the class's rows
+        const float* __restrict__ crow = split_cov + (int64_t)split_cls[loc] * 3 * plane_stride;
+        for (int pl = 0; pl < 5; ++pl)
+            for (int l = threadIdx.x; l < nlandmarks; l += kBlock) {
+                const int64_t page = tab[l / kPageLandmarks];
+                rec[3 + pl * nlandmarks + l] =
+                    pl < 2 ? map[page * (2 * kPageLandmarks) + (page >= geom.half_pages ? geom.gap : 0) + pl * kPageLandmarks + l % kPageLandmarks]
+                           : crow[(pl - 2) * plane_stride + l];
+            }
+        return;
+    }
     if (pt) {   // paged maps: `map` is the page pool, the particle's landmarks sit behind its page table (paged_kernels.hip)
         const int32_t* __restrict__ tab = pt + (int64_t)loc * nb;
         for (int pl = 0; pl < 5; ++pl)
@@ -2363,7 +2375,7 @@ hipError_t launch_ancestors_sharded(hipStream_t stream, const int32_t* first_all
 hipError_t launch_migrate_pack(hipStream_t stream, const int32_t* scratch, int n, const MigratePlan& plan,
                                const float* pose, int64_t pose_ld, const float* map, int64_t row_stride,
                                int plane_stride, int nlandmarks, float* out, const int32_t* pt, int nb, const float* split_cov,
-                               const int32_t* split_cls)
+                               const int32_t* split_cls, const PageGeom& geom)
 {
     const int total = plan.off[plan.world];
     if (total <= 0) return hipSuccess;
@@ -2371,7 +2383,7 @@ hipError_t launch_migrate_pack(hipStream_t stream, const int32_t* scratch, int n
     const int32_t* pfx = scratch + n;
     const int32_t* boff = pfx + 2 * (int64_t)n;
     migrate_pack_kernel<<<total, kBlock, 0, stream>>>(pfx, boff, ntiles, n, plan, pose, pose_ld, map, row_stride,
-                                                     plane_stride, nlandmarks, out, pt, nb, split_cov, split_cls);
+                                                     plane_stride, nlandmarks, out, pt, nb, split_cov, split_cls, geom);
     return hipGetLastError();
 }
 

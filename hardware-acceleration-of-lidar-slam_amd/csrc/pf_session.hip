@@ -117,7 +117,6 @@ namespace {
 
 hipError_t dev_alloc(void** p, size_t bytes) { return hipMalloc(p, bytes ? bytes : 4); }
 
-int convert_split_to_rows(slam_pf* pf);
 int convert_rows_to_split(slam_pf* pf);
 
 int grow(slam_pf* pf, float** buf, size_t* have, size_t want)
@@ -137,6 +136,9 @@ int grow(slam_pf* pf, float** buf, size_t* have, size_t want)
     *have = cap;
     return SLAM_OK;
 }
+
+float* split_pool(const slam_pf* pf);
+PageGeom split_geom(const slam_pf* pf);
 
 // Map rows (and poses) of ancestors that live on another rank -> the staging tail of the current buffers, where
 // the next EKF's fused gather picks them up.  pack (one launch) -> one grouped send/recv -> unpack (one launch).
@@ -167,12 +169,13 @@ int migrate(slam_pf* pf)
     pf->rows_received = (int)rtot;
     if (int rc = grow(pf, &pf->sbuf, &pf->sbuf_floats, (size_t)(rec * stot))) return rc;
     if (int rc = grow(pf, &pf->rbuf, &pf->rbuf_floats, (size_t)(rec * rtot))) return rc;
-    const bool split = L && pf->split;
-    const float* mp = L ? (pf->paged ? pf->pool : split ? pf->mean[pf->sp_cur] : pf->map[pf->map_cur]) : nullptr;
+    const bool split = L && pf->split, spages = split && pf->paged;   // (split pages: the means on pages of two planes, the classes as on split)
+    const PageGeom geom = spages ? split_geom(pf) : PageGeom();
+    const float* mp = L ? (spages ? split_pool(pf) : pf->paged ? pf->pool : split ? pf->mean[pf->sp_cur] : pf->map[pf->map_cur]) : nullptr;
     if (stot)
         if (int rc = slam_migrate_pack_paged(e, n, pf->rank, G, plan, pf->pose[pf->cur], n, mp, (split ? 2 : 5) * (int64_t)pf->Lp, pf->Lp, L,
                                              pf->sbuf, pf->paged ? pf->pt[pf->pt_cur] : nullptr, pf->nb, split ? pf->cov : nullptr,
-                                             split ? pf->cls[pf->sp_cur] : nullptr))
+                                             split ? pf->cls[pf->sp_cur] : nullptr, spages ? &geom : nullptr))
             return rc;
     if (int rc = comm_all_to_all_f32(pf->comm, pf->sbuf, sfl, pf->rbuf, rfl)) return rc;
     if (rtot && split) {
@@ -186,10 +189,21 @@ int migrate(slam_pf* pf)
             SLAM_HIP_TRY(e, launch_class_free_list(e->stream, pf->cstamp, pf->cap, pf->cstamp_now, pf->cls_free, pf->cls_fs));
             pf->cls_cursor = 0;
         }
-        SLAM_HIP_TRY(e, launch_migrate_unpack_split(e->stream, pf->rbuf, (int)rtot, n, pf->pose_stage, pf->cap, pf->mean[pf->sp_cur], pf->cov,
-                                                    pf->covx, pf->cls[pf->sp_cur], pf->Lp, L, pf->cfg.meas_var, pf->cls_free,
-                                                    (int)pf->cls_cursor, pf->cstamp, pf->cstamp_now, pf->live[pf->live_cur],
-                                                    pf->cov_cnt + pf->cov_phase));
+        if (spages) {   // the means onto fresh pages (a new free list first if the old one runs short), table rows n .. n + rtot - 1
+            int32_t* pstate = pf->page_scratch;
+            SLAM_HIP_TRY(e, launch_pool_reserve(e->stream, pstate, rtot * pf->nb));
+            SLAM_HIP_TRY(e, launch_free_list(e->stream, pf->stamp, pf->npages, pf->stamp_now, pf->freelist, pstate,
+                                             reinterpret_cast<int32_t*>(pf->d_hres) + 20));
+            SLAM_HIP_TRY(e, launch_migrate_unpack_split_pages(e->stream, pf->rbuf, (int)rtot, n, pf->pose_stage, pf->cap, split_pool(pf), geom,
+                                                              pf->pt[pf->pt_cur], pf->nb, L, pf->freelist, pstate, pf->stamp, pf->stamp_now,
+                                                              pf->cov, pf->covx, pf->cls[pf->sp_cur], pf->Lp, pf->cfg.meas_var, pf->cls_free,
+                                                              (int)pf->cls_cursor, pf->cstamp, pf->cstamp_now, pf->live[pf->live_cur],
+                                                              pf->cov_cnt + pf->cov_phase));
+        } else
+            SLAM_HIP_TRY(e, launch_migrate_unpack_split(e->stream, pf->rbuf, (int)rtot, n, pf->pose_stage, pf->cap, pf->mean[pf->sp_cur], pf->cov,
+                                                        pf->covx, pf->cls[pf->sp_cur], pf->Lp, L, pf->cfg.meas_var, pf->cls_free,
+                                                        (int)pf->cls_cursor, pf->cstamp, pf->cstamp_now, pf->live[pf->live_cur],
+                                                        pf->cov_cnt + pf->cov_phase));
         pf->cls_cursor += rtot;
         pf->cls_appended += (uint32_t)rtot;
     } else if (rtot && pf->paged) {
@@ -460,27 +474,6 @@ int convert_rows_to_split(slam_pf* pf)
     return SLAM_OK;
 }
 
-// split -> rows: into the half of the store that does not hold mean[0] and cov (the current means move to mean[0] first when
-// they sit in mean[1], which starts that half)
-int convert_split_to_rows(slam_pf* pf)
-{
-    slam_engine* e = pf->e;
-    const int nrows = rows_to_convert(pf);   // sharded: the staging tail moves along when the exchange has been completed already
-    const size_t n = (size_t)nrows, Lp = (size_t)pf->Lp;
-    if (pf->sp_cur == 1) {
-        SLAM_HIP_TRY(e, hipMemcpyAsync(pf->mean[0], pf->mean[1], 2 * Lp * n * 4, hipMemcpyDeviceToDevice, e->stream));
-        SLAM_HIP_TRY(e, hipMemcpyAsync(pf->cls[0], pf->cls[1], n * 4, hipMemcpyDeviceToDevice, e->stream));
-        pf->sp_cur = 0;
-    }
-    const int target = 1 - pf->sp_base;
-    SLAM_HIP_TRY(e, launch_rows_from_split(e->stream, pf->mean[0], pf->cov, pf->cls[0], pf->Lp, nullptr, nrows, pf->map[target],
-                                           5 * (int64_t)Lp, pf->Lp, pf->L));
-    pf->map_cur = target;
-    pf->split = false;
-    pf->conversions++;
-    return SLAM_OK;
-}
-
 // split -> split pages: the means of the current buffer become pages in the OTHER mean buffer (identity tables, shifted),
 // the buffer they came from becomes free pages; classes and covariances stay where they are.  One stream-ordered launch.
 int convert_split_to_split_pages(slam_pf* pf)
@@ -490,8 +483,9 @@ int convert_split_to_split_pages(slam_pf* pf)
     const float* dst = pf->mean[1 - pf->sp_cur];
     const int page_base = dst == split_pool(pf) ? 0 : pf->cap * pf->nb;
     pf->pt_cur = 0;
-    SLAM_HIP_TRY(e, launch_pages_from_rows(e->stream, src, 2 * (int64_t)pf->Lp, pf->Lp, pf->L, pf->nb, pf->n, split_pool(pf), pf->pt[0],
-                                           pf->freelist, pf->npages, pf->page_scratch, page_base, split_geom(pf)));
+    // (sharded: rows_to_convert takes the staging tail along when the exchange of the last frame has been completed already)
+    SLAM_HIP_TRY(e, launch_pages_from_rows(e->stream, src, 2 * (int64_t)pf->Lp, pf->Lp, pf->L, pf->nb, rows_to_convert(pf), split_pool(pf),
+                                           pf->pt[0], pf->freelist, pf->npages, pf->page_scratch, page_base, split_geom(pf)));
     pf->paged = true;
     pf->conversions++;
     return SLAM_OK;
@@ -502,10 +496,15 @@ int convert_split_to_split_pages(slam_pf* pf)
 int convert_split_pages_to_split(slam_pf* pf)
 {
     slam_engine* e = pf->e;
-    const size_t used = 2 * (size_t)pf->Lp * (size_t)pf->n;
+    const int nrows = rows_to_convert(pf);
+    const size_t used = 2 * (size_t)pf->Lp * (size_t)nrows;
     if (pf->conv_floats < used) {
         if (pf->conv_tmp) {
-            SLAM_HIP_TRY(e, hipStreamSynchronize(e->stream));
+            if (pf->comm) {
+                if (int rc = comm_wait_stream(pf->comm)) return rc;
+            } else {
+                SLAM_HIP_TRY(e, hipStreamSynchronize(e->stream));
+            }
             (void)hipFree(pf->conv_tmp);
         }
         pf->conv_tmp = nullptr;
@@ -518,10 +517,10 @@ int convert_split_pages_to_split(slam_pf* pf)
         }
         pf->conv_floats = used;
     }
-    SLAM_HIP_TRY(e, launch_rows_from_pages(e->stream, split_pool(pf), pf->pt[pf->pt_cur], pf->nb, nullptr, pf->n, pf->conv_tmp,
+    SLAM_HIP_TRY(e, launch_rows_from_pages(e->stream, split_pool(pf), pf->pt[pf->pt_cur], pf->nb, nullptr, nrows, pf->conv_tmp,
                                            2 * (int64_t)pf->Lp, pf->Lp, pf->L, split_geom(pf)));
     SLAM_HIP_TRY(e, hipMemcpyAsync(pf->mean[0], pf->conv_tmp, used * 4, hipMemcpyDeviceToDevice, e->stream));
-    if (pf->sp_cur == 1) SLAM_HIP_TRY(e, hipMemcpyAsync(pf->cls[0], pf->cls[1], (size_t)pf->n * 4, hipMemcpyDeviceToDevice, e->stream));
+    if (pf->sp_cur == 1) SLAM_HIP_TRY(e, hipMemcpyAsync(pf->cls[0], pf->cls[1], (size_t)nrows * 4, hipMemcpyDeviceToDevice, e->stream));
     pf->sp_cur = 0;
     pf->paged = false;
     pf->conversions++;
@@ -553,9 +552,7 @@ int auto_layout(slam_pf* pf)
     pf->votes_pages = h[3];   // samples in a row (counted on the device, so none is missed however far the host runs ahead)
     pf->votes_rows = h[4];
     if (!pf->paged && pf->votes_pages >= 3) {
-        if (pf->split && !pf->comm) return convert_split_to_split_pages(pf);   // the means go onto pages, the classes stay
-        if (pf->split)
-            if (int rc = convert_split_to_rows(pf)) return rc;
+        if (pf->split) return convert_split_to_split_pages(pf);   // the means go onto pages, the classes stay
         return convert_to_pages(pf);
     }
     if (pf->paged && pf->votes_rows >= 3) {
@@ -571,10 +568,6 @@ int create_common(slam_engine* e, const slam_pf_config* cfg, slam_comm* comm, in
     if (!e || !cfg || !out || cfg->n_particles <= 0 || cfg->n_landmarks < 0 || !(cfg->meas_var > 0.0f) ||
         cfg->map_layout < SLAM_MAP_AUTO || cfg->map_layout > SLAM_MAP_SPLIT_PAGES)
         return SLAM_ERR_INVALID_ARG;
-    if (comm && cfg->map_layout == SLAM_MAP_SPLIT_PAGES) {
-        snprintf(e->err, sizeof e->err, "SLAM_MAP_SPLIT_PAGES: one GPU only (a sharded session's AUTO uses pages of whole landmarks)");
-        return SLAM_ERR_INVALID_ARG;
-    }
 
     *out = nullptr;
     if (e->live_sessions > 0) {   // the stages keep per-population state in the engine (gate, carried weights, exchange plan)
@@ -992,7 +985,7 @@ static int pf_step_impl(slam_pf* pf, int slot, const float dp[3], int use_observ
         rider.h_short = reinterpret_cast<int32_t*>(pf->d_hres) + 20;
         paged_listed = true;
     }
-    if (comm && pf->split && pf->has_anc && !pf->gated && anc && L > 0 && use_observations && e->obs_nlandmarks == L) {
+    if (comm && pf->split && !pf->paged && pf->has_anc && !pf->gated && anc && L > 0 && use_observations && e->obs_nlandmarks == L) {
         // Sharded, split maps: the front launch scores every particle (its ancestor's pose comes out of the all-gathered poses)
         // and updates the groups of particles whose ancestors are all rows of this rank; the groups with an ancestor in the
         // staging tail follow behind the exchange (below).  Like the motion + score launch it replaces, it needs nothing from

@@ -434,8 +434,8 @@ typedef struct {
  * entries and rewrites only the pages that hold an observed landmark: the fastest form when a frame observes few of
  * many).  Both give the same bits.  SLAM_MAP_AUTO lets the session choose and change its mind while it runs. */
 typedef enum { SLAM_MAP_AUTO = 0, SLAM_MAP_ROWS = 1, SLAM_MAP_PAGES = 2, SLAM_MAP_SPLIT = 3, SLAM_MAP_SPLIT_PAGES = 4 } slam_map_layout;
-/* SLAM_MAP_SPLIT_PAGES (round 4; one GPU): the split layout with the MEANS on copy-on-write pages of 32 landmarks x 2 planes
- * (256 bytes) and the covariances per class as in SLAM_MAP_SPLIT — what SLAM_MAP_AUTO moves a single-GPU session to when its
+/* SLAM_MAP_SPLIT_PAGES (round 4): the split layout with the MEANS on copy-on-write pages of 32 landmarks x 2 planes
+ * (256 bytes) and the covariances per class as in SLAM_MAP_SPLIT — what SLAM_MAP_AUTO moves a session to when its
  * frames observe few of many landmarks: a resampling frame copies table entries, rewrites only the mean pages that hold an
  * observed landmark and updates each class's covariances once.  The same bits. */
 /* SLAM_MAP_SPLIT (round 4): MEANS per particle, COVARIANCES per covariance class.  The landmark update is carried out in the
@@ -449,8 +449,7 @@ typedef enum { SLAM_MAP_AUTO = 0, SLAM_MAP_ROWS = 1, SLAM_MAP_PAGES = 2, SLAM_MA
  * rank; a migrating particle becomes a class of its own where it arrives).  slam_pf_device_view gives map = NULL while a
  * session is split, like pages. */
 /* SLAM_MAP_AUTO keeps a session on the SPLIT layout instead of rows (single-GPU or sharded, resampling every frame or
- * ESS-gated), and otherwise works as described here, "rows" meaning that dense layout and "pages" SLAM_MAP_SPLIT_PAGES for a
- * single-GPU session (a sharded one goes through rows to SLAM_MAP_PAGES).
+ * ESS-gated), and otherwise works as described here, "rows" meaning that dense layout and "pages" SLAM_MAP_SPLIT_PAGES.
  * SLAM_MAP_AUTO starts on rows and watches how many landmarks the frames observe (a count the update kernels leave in
  * mapped host memory: every frame at the start and while they speak against the current layout, every 8th frame otherwise;
  * read without waiting, except in a session's first four frames, which wait for the count of the frame before so that the

@@ -331,13 +331,29 @@ def test_split_pages_map_io():
     ses.reset([0.0, 0.0, 0.0])
     assert np.array_equal(bits(ses.maps()), bits(fresh))
     ses.close()
-    group = pkg.LocalGroup(1)   # a sharded session (even of one rank) is refused: its AUTO uses pages of whole landmarks
-    comm = pkg.Comm.local(eng, group, 0)
-    with pytest.raises(pkg.SlamError, match="one GPU only"):
-        pkg.PfSession(eng, n, L, comm=comm, map_layout="split_pages")
-    comm.close()
-    group.close()
     eng.close()
+
+
+@pytest.mark.parametrize("world,n_total,L,frames", [(2, 4096, 70, 12), (3, 3072, 100, 14), (4, 8192, 130, 10), (2, 16384, 200, 8)])
+def test_sharded_split_pages_ranks_on_one_card_equal_one_rank_on_rows(world, n_total, L, frames, monkeypatch):
+    """Sharded sessions on split pages: a migrating particle is packed from its mean pages and its class's covariance rows and
+    unpacked onto fresh mean pages as a class of its own (class numbers recycled from short lists); frames that observe a few
+    landmarks; map reads between the frames (they complete the exchange early); against one rank on rows, frame by frame.  The
+    last case has ranks large enough for the fused front of sharded SPLIT sessions, which a session on split pages must not
+    take (it works on mean rows)."""
+    from test_gpu_configs import _run_c_session_ranks
+
+    monkeypatch.setenv("SLAM_SPLIT_CLASS_ROOM", "64")
+    kw = dict(sparse_obs=True, maps_every_frame=True)
+    ref = _run_c_session_ranks(1, n_total, L, frames, transport=None, **kw)[0]
+    many = _run_c_session_ranks(world, n_total, L, frames, layout="split_pages", **kw)
+    assert all(set(p["layouts"]) == {"split_pages"} for p in many), [p["layouts"] for p in many]
+    assert any(sum(p["rows"]) > 0 for p in many), "nothing migrated"
+    assert np.array_equal(bits(np.concatenate([p["pose"] for p in many], axis=1)), bits(ref["pose"]))
+    assert np.array_equal(bits(np.concatenate([p["map"] for p in many], axis=0)), bits(ref["map"]))
+    for f in range(frames):
+        got = np.concatenate([p["frame_maps"][f] for p in many], axis=0)
+        assert np.array_equal(bits(got), bits(ref["frame_maps"][f])), f
 
 
 def test_auto_moves_between_split_and_pages_and_keeps_the_bits():
