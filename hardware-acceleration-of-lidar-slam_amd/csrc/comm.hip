@@ -31,6 +31,7 @@ struct slam_local_group {
     const void* send[kMaxRanks] = {};
     int64_t cnt[kMaxRanks][kMaxRanks] = {};   // all-to-all: cnt[src][dst] floats
     float fmax[kMaxRanks][4] = {};
+    std::vector<float> fbig[kMaxRanks];   // all-reduce MAX of longer arrays (the ranks' block maxima of the log-weights)
 
     // reusable barrier; false when a rank failed to arrive within the time limit (the group is then broken for good)
     bool barrier()
@@ -232,8 +233,25 @@ int comm_all_reduce_max_f32(slam_comm* c, float* d_buf, int count)
     if (c->dead) return dead_fail(c);
     const ProfScope prof(c->e, SLAM_PROF_COLLECTIVES);
     if (count <= 0) return SLAM_OK;
+    if (c->group && count > 4) {   // (the same exchange through per-rank vectors)
+        slam_local_group* g = c->group;
+        std::vector<float>& mine = g->fbig[c->rank];
+        mine.resize((size_t)count);
+        LHIP_TRY(c, hipMemcpyAsync(mine.data(), d_buf, sizeof(float) * count, hipMemcpyDeviceToHost, c->e->stream));
+        LHIP_TRY(c, hipStreamSynchronize(c->e->stream));
+        if (!g->barrier()) return local_fail(c, "all_reduce");
+        std::vector<float> out(mine);
+        for (int q = 0; q < c->world; ++q) {
+            if ((int)g->fbig[q].size() != count) return local_fail(c, "all_reduce (counts differ)");
+            for (int k = 0; k < count; ++k)
+                if (g->fbig[q][k] > out[k]) out[k] = g->fbig[q][k];
+        }
+        if (!g->barrier()) return local_fail(c, "all_reduce");   // everybody has read everybody's vector
+        LHIP_TRY(c, hipMemcpyAsync(d_buf, out.data(), sizeof(float) * count, hipMemcpyHostToDevice, c->e->stream));
+        LHIP_TRY(c, hipStreamSynchronize(c->e->stream));   // `out` is a local buffer
+        return SLAM_OK;
+    }
     if (c->group) {
-        if (count > 4) return SLAM_ERR_INVALID_ARG;
         slam_local_group* g = c->group;
         float mine[4];
         LHIP_TRY(c, hipMemcpyAsync(mine, d_buf, sizeof(float) * count, hipMemcpyDeviceToHost, c->e->stream));

@@ -1053,7 +1053,12 @@ static int pf_step_impl(slam_pf* pf, int slot, const float dp[3], int use_observ
     // 3. per-landmark EKF (+ fused gather); the log-likelihood stays inside the engine for step 4
     const bool ekf = L > 0 && use_observations;
     const int mc = pf->map_cur, mn = 1 - mc;
-    float* d_max = comm ? pf->d_max : nullptr;
+    // Sharded: the ranks all-reduce the BLOCK maxima the weights' launch leaves in the engine (element by element: a few hundred
+    // floats cost the wire what one costs) and the scan takes their maximum itself, as it does on one GPU — the maximum of the
+    // same set of values, and one single-workgroup launch less per frame than reducing them to one float first
+    // (SLAM_MAX_FINALIZE=1: that launch and a one-float all-reduce, as before).
+    static const bool finalize = getenv("SLAM_MAX_FINALIZE") && atoi(getenv("SLAM_MAX_FINALIZE")) != 0;
+    float* d_max = comm && finalize ? pf->d_max : nullptr;
     if (pf->split && !pf->paged && L > 0) {
         const int sc = pf->sp_cur;
         make_sio();   // (again: a layout move in front of the frame leaves other buffers than the ones the first look saw)
@@ -1186,7 +1191,14 @@ static int pf_step_impl(slam_pf* pf, int slot, const float dp[3], int use_observ
     }
     if (rc != SLAM_OK) return rc;
     // 4. weights: the maximum over all ranks, then fixed-point weights scanned as they are produced
-    if (comm && (rc = comm_all_reduce_max_f32(comm, pf->d_max, 1)) != SLAM_OK) return rc;
+    if (comm) {
+        if (d_max) {
+            if ((rc = comm_all_reduce_max_f32(comm, pf->d_max, 1)) != SLAM_OK) return rc;
+        } else {
+            if (e->bmax_n != n || e->bmax_count <= 0) return SLAM_ERR_NOT_READY;
+            if ((rc = comm_all_reduce_max_f32(comm, e->bmax_buf.as<float>(), e->bmax_count)) != SLAM_OK) return rc;
+        }
+    }
     if ((rc = slam_quantise_scan_dev(e, pf->logw, d_max, n, comm ? pf->d_sum : nullptr)) != SLAM_OK) return rc;
     // 5. resample on the integer CDF
     if (!comm) {
