@@ -775,15 +775,22 @@ def run_rank(args, ctx, inp, last=True):
     # update out of L2, read and rewritten once by cov_update_kernel).  A static PMC record that is far off this model was
     # taken on another filter state (or another kernel) and is flagged.
     traffic_model = None
-    if (args.mode == "pf" and L and not paged_in_region and distinct_frac is not None and not 0 < args.ess < 1
-            and kern.startswith(("frame_front", "ekf_update", "ekf_split"))):   # (a gated session's in-place frames rewrite nothing)
+    gated = 0 < args.ess < 1
+    # (a gated session on ROWS updates the frames that keep their population in place: no model for that mix; on the split layout
+    # such a frame goes through the identity index out of place — every row written, every row read)
+    if (args.mode == "pf" and L and not paged_in_region and distinct_frac is not None and (not gated or split_in_region)
+            and kern.startswith(("frame_front", "ekf_update", "ekf_split"))):
         per = 8 if split_in_region else 20
         written = per * n * Lp
-        read = distinct_frac * per * n * Lp + (24 * Lp * classes_in_use if split_in_region else 0)
+        f_res = pf.frames_resampled() / max(args.warmup + args.steps + off + extra, 1) if gated else 1.0   # share of frames that resampled
+        f_res = min(max(f_res, 0.0), 1.0)
+        read = (f_res * distinct_frac + (1.0 - f_res)) * per * n * Lp + (24 * Lp * (classes_in_use or 1) if split_in_region else 0)
         traffic_model = {"bytes_written": written, "bytes_read": read, "bytes": written + read,
                          "basis": f"{per} B x n x Lp written + distinct_ancestor_frac x {per} B x n x Lp read"
+                                  + (" (frames that kept their population: every row read)" if gated else "")
                                   + (" + 24 B x Lp x classes in use" if split_in_region else ""),
-                         "distinct_ancestor_frac": distinct_frac, "classes_in_use": classes_in_use}
+                         "distinct_ancestor_frac": distinct_frac, "classes_in_use": classes_in_use,
+                         "frames_resampled_frac": f_res if gated else None}
         if traffic:
             traffic_model["record_over_model"] = traffic / (written + read)
             traffic_model["record_suspect"] = bool(abs(traffic / (written + read) - 1.0) > 0.15)

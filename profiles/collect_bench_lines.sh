@@ -24,6 +24,8 @@ line default_rows $Q --map-layout rows
 line default_event_every_frame $Q --event-every 1
 line force_collectives $Q --force-collectives
 line force_collectives_rows $Q --force-collectives --map-layout rows
+line force_collectives_obs32 $Q --force-collectives --observed 32
+line force_collectives_obs32_paged $Q --force-collectives --observed 32 --paged
 line local_2ranks $Q --gpus 2 --transport local --particles 32768
 line obs32_rows $Q --observed 32 --map-layout rows
 line obs32_split $Q --observed 32 --map-layout split
