@@ -311,7 +311,7 @@ struct PagedEkfArgs {
 // been handed out, whether launch_free_list (to be called behind this launcher every frame) has to make a new one first
 int pool_state_words();
 // h_obs + votes (optional): the launch also takes SLAM_MAP_AUTO's sample — votes[2] (device): samples in a row with at most
-// a quarter / more than three eighths of the landmarks observed; h_obs (mapped host memory): {observed, L, seq, votes[0], votes[1]}
+// two sevenths / more than three eighths of the landmarks observed; h_obs (mapped host memory): {observed, L, seq, votes[0], votes[1]}
 hipError_t launch_page_list(hipStream_t stream, const float* zx, const float* zy, int L, int nb, int32_t* tpage, int32_t* tindex,
                             int32_t* tmask, int32_t* tbase, int32_t* count, int n, int32_t* pool_state, int32_t* h_obs = nullptr,
                             uint32_t seq = 0, int32_t* votes = nullptr, int32_t* h_touched = nullptr,

@@ -53,14 +53,14 @@ __device__ __forceinline__ void pool_reserve(int32_t* __restrict__ pool_state, i
 // The pages a frame touches: page b is touched when one of its landmarks has an observation (table form: NaN = none).
 // One workgroup, one landmark per thread and step: a page is kPage neighbouring lanes of a wavefront, "touched" a ballot.
 // tpage[0 .. T) ascending, tindex[b] = position of page b in tpage or -1, count[0] = T.
-// What SLAM_MAP_AUTO decides the layout from: votes[0] counts the samples in a row with at most a quarter of the landmarks
+// What SLAM_MAP_AUTO decides the layout from: votes[0] counts the samples in a row with at most two sevenths of the landmarks
 // observed, votes[1] those in a row with more than three eighths (device memory, kept by the kernels that take a sample); the
 // mirror in mapped host memory holds {observed, L, seq, votes[0], votes[1]}.
 __device__ __forceinline__ void publish_obs_count(int nobs, int L, int32_t* __restrict__ votes, int32_t* __restrict__ h_obs,
                                                   uint32_t seq)
 {
     int vp = votes[0], vr = votes[1];
-    if (4 * (int64_t)nobs <= L) {
+    if (7 * (int64_t)nobs <= 2 * (int64_t)L) {   // (two sevenths: below the measured change-over at every size tried)
         vp = vp < 1000000 ? vp + 1 : vp;
         vr = 0;
     } else if (8 * (int64_t)nobs > 3 * (int64_t)L) {   // (three eighths: r04_split_tuning.md section 8, the measured change-over is at 0.28-0.33)

@@ -528,7 +528,7 @@ int convert_split_pages_to_split(slam_pf* pf)
 }
 
 // SLAM_MAP_AUTO, at the start of a frame: look at the counts that have arrived since the last look (no waiting) and move
-// when the last three agree.  Pages pay when a frame observes at most a quarter of the landmarks (a resampling frame on
+// when the last three agree.  Pages pay when a frame observes at most two sevenths of the landmarks (a resampling frame on
 // rows rewrites every row in full); rows / split maps pay when it observes more than three eighths (most pages are touched
 // anyway and the row kernels are faster at that; the measured change-over is at 0.28-0.33).  Results do not depend on the layout, so the ranks of a sharded session may decide apart.
 int auto_layout(slam_pf* pf)

@@ -454,7 +454,7 @@ typedef enum { SLAM_MAP_AUTO = 0, SLAM_MAP_ROWS = 1, SLAM_MAP_PAGES = 2, SLAM_MA
  * mapped host memory: every frame at the start and while they speak against the current layout, every 8th frame otherwise;
  * read without waiting, except in a session's first four frames, which wait for the count of the frame before so that the
  * layout is settled by then): three counts in a row of at most
- * a quarter of the landmarks move the maps to pages, three in a row of more than three eighths move them back (measured: split pages win
+ * two sevenths of the landmarks move the maps to pages, three in a row of more than three eighths move them back (measured: split pages win
  * below 0.28-0.33 of the landmarks observed, rows and split maps above).  A move costs one
  * pass over the maps and, while it runs, half as much memory again as the steady state (one row buffer beside the pool);
  * when that is not to be had the session stays where it is.  Sessions with at most 32 landmarks stay on rows. */

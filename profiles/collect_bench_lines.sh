@@ -41,6 +41,7 @@ line obs128_rows $Q --observed 128 --map-layout rows
 line obs128_split $Q --observed 128 --map-layout split
 line obs128_paged $Q --observed 128 --paged
 line obs128_split_pages $Q --observed 128 --map-layout split_pages
+line obs128_auto $Q --observed 128
 line 5000_obs32_rows $Q --landmarks 5000 --observed 32 --map-layout rows --steps 40
 line 5000_obs32_split $Q --landmarks 5000 --observed 32 --map-layout split --steps 40
 line 5000_obs32_paged $Q --landmarks 5000 --observed 32 --paged
