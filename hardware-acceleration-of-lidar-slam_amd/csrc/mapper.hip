@@ -35,7 +35,9 @@ struct slam_mapper {
     float pose[3] = { 0, 0, 0 }, prev[3] = { 0, 0, 0 }, map_pose[3] = { 0, 0, 0 };
     int mini_updated = 1, frame = 0;
     int32_t nhits = 0;
-    float* h_range = nullptr;   // pinned
+    float* h_range = nullptr;   // pinned and mapped: TWO frames of raw ranges, used in turn; the clean-up kernel reads them in place
+    float* d_hrange = nullptr;  // ... as the device sees them
+    int range_slot = 0;
 };
 
 namespace {
@@ -45,11 +47,17 @@ namespace {
 int upload_ranges(slam_mapper* m, const float* ranges)
 {
     hipStream_t st = m->e->stream;
-    MP_TRY(hipStreamSynchronize(st));   // the previous frame's copy out of the pinned block has finished long ago
-    memcpy(m->h_range, ranges, sizeof(float) * (size_t)m->nbeams);
-    MP_TRY(hipMemcpyAsync(m->d_range, m->h_range, sizeof(float) * (size_t)m->nbeams, hipMemcpyHostToDevice, st));
+    // Zero copy: the raw ranges go into pinned memory the clean-up kernel reads directly (one 4 KB pass; a host-to-device copy
+    // command in front of it cost the frame's launch chain more than the kernel itself).  Two slots used in turn: the kernel
+    // that read a slot two frames ago has finished — every frame ends with the host holding its matcher result, which is
+    // behind that frame's clean-up in the stream — so no synchronisation is needed before the slot is written again.
+    const size_t nb = (size_t)m->nbeams;
+    float* h = m->h_range + (size_t)m->range_slot * nb;
+    const float* d = m->d_hrange + (size_t)m->range_slot * nb;
+    m->range_slot ^= 1;
+    memcpy(h, ranges, sizeof(float) * nb);
     // main.c:863 readAScan(24): range_min 0.023 (main.c:50), usable range 24
-    MP_TRY(launch_clean_scan(st, m->d_range, m->d_cos, m->d_sin, m->nbeams, m->par.range_min, m->par.usable_range, m->d_bx,
+    MP_TRY(launch_clean_scan(st, d, m->d_cos, m->d_sin, m->nbeams, m->par.range_min, m->par.usable_range, m->d_bx,
                              m->d_by, m->d_counts + 0));
     return SLAM_OK;
 }
@@ -131,7 +139,8 @@ int slam_mapper_create_ex(slam_engine* e, int nbeams, float angle_min, float ang
                           (size_t)kFineLd * kFineLd;
     const size_t ints = (size_t)kCoarseLd * kCoarseLd + (size_t)kFineLd * kFineLd + 16;
     if (m->buf.ensure(4 * (floats + ints) + 2 * sizeof(slam_grid_meta) + 64) != hipSuccess ||
-        hipHostMalloc((void**)&m->h_range, 4 * nb, hipHostMallocDefault) != hipSuccess) {
+        hipHostMalloc((void**)&m->h_range, 2 * 4 * nb, hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer((void**)&m->d_hrange, m->h_range, 0) != hipSuccess) {
         (void)hipGetLastError();
         slam_mapper_destroy(m);
         return SLAM_ERR_HIP;
