@@ -202,7 +202,7 @@ int slam_engine_create(int device, slam_engine** out)
     e->device = device;
     if (hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking) != hipSuccess ||
         e->fm_buf.ensure(sizeof(float) * (kFmIn + kFmOut)) != hipSuccess ||
-        e->fm_work.ensure(sizeof(float) * kLattice * SLAM_MAX_BEAMS) != hipSuccess ||
+        e->fm_work.ensure(sizeof(float) * 2 * kLattice * SLAM_MAX_BEAMS) != hipSuccess ||   // (the hits of two sweeps: the chained pair)
         engine_host_block(e) != hipSuccess ||
         e->gate_buf.ensure(kGateBufWords * sizeof(int32_t)) != hipSuccess ||   // flag | ticket | accumulators: see kernels.h
         e->heads_buf.ensure(2 * sizeof(int32_t)) != hipSuccess ||
@@ -708,18 +708,16 @@ int slam_engine_fastmatch_pair(slam_engine* e, int slot1, int slot2, const float
         }
     }
     h_pair_in[18] = t2;
-    float* d_cand2 = e->fm_buf.as<float>();   // the second call's candidates (the device's own copy of the table: 4 x 27 floats)
-    float* d_out = e->fm_buf.as<float>() + kFmIn;
+    float* d_out1 = e->fm_buf.as<float>();           // the first call's scores | counts | maxcount (kFmIn floats are room enough)
+    float* d_out2 = e->fm_buf.as<float>() + kFmIn;   // the second call's
+    float* work1 = e->fm_work.as<float>();
+    float* work2 = work1 + (size_t)kLattice * SLAM_MAX_BEAMS;
     volatile uint32_t* h_flag = reinterpret_cast<volatile uint32_t*>(e->h_fm + kFmIn + kFmOut);
     const uint32_t seq = ++e->fm_seq;
-    LatticeChain chain;
-    chain.cand1 = e->d_hfm;
-    chain.pair_in = e->d_hfm + kFmIn + kFmOut + 4;
-    chain.cand2 = d_cand2;
-    HIP_TRY(launch_lattice(e->stream, score_grid(e->grid[slot1]), d_bx, d_by, nbeams_max, d_nbeams, e->d_hfm, e->fm_work.as<float>(), d_out,
-                           d_hits_persist, e->d_hfm + kFmIn + kFmOut + 4 + kFmPairIn, nullptr, 0, &chain));
-    HIP_TRY(launch_lattice(e->stream, score_grid(e->grid[slot2]), d_bx, d_by, nbeams_max, d_nbeams, d_cand2, e->fm_work.as<float>(), d_out,
-                           d_hits_persist, e->d_hfm + kFmIn, reinterpret_cast<uint32_t*>(e->d_hfm + kFmIn + kFmOut), seq));
+    HIP_TRY(launch_lattice_pair(e->stream, score_grid(e->grid[slot1]), score_grid(e->grid[slot2]), d_bx, d_by, nbeams_max, d_nbeams, e->d_hfm,
+                                e->d_hfm + kFmIn + kFmOut + 4, work1, work2, d_out1, d_out2, d_hits_persist,
+                                e->d_hfm + kFmIn + kFmOut + 4 + kFmPairIn, e->d_hfm + kFmIn,
+                                reinterpret_cast<uint32_t*>(e->d_hfm + kFmIn + kFmOut), seq));
     {
         bool arrived = false;
         for (long spin = 0; spin < 400000000L; ++spin) {   // bounded: a few seconds at most

@@ -75,19 +75,19 @@ hipError_t launch_pose_hits(hipStream_t stream, const ScoreGrid& g, const float*
 // d_nbeams (optional): the beam count lives on the device (<= nbeams, which then is the capacity / row stride).
 // persist (optional): device mirror of the caller's persistent hit scratch, updated like the host copy.
 // host_out / host_flag / seq (optional): also deliver `out` to mapped pinned host memory and release `seq`.
-// chain (optional; the first call of a chained pair, engine.hip: slam_engine_fastmatch_pair): host_out then receives the scores
-// and counts only (no merged hits, no flag), and the launch also lays out the NEXT call's candidates in cand2: the lattice
-// around this call's best candidate (strict '<' from +inf, the first of equals; none: the middle candidate = the input pose)
-// with step pair_in[18] and the headings' cos[9] | sin[9] of pair_in, row = this call's best heading.
-struct LatticeChain {
-    const float* cand1 = nullptr;     // this call's candidate table
-    const float* pair_in = nullptr;
-    float* cand2 = nullptr;
-};
 hipError_t launch_lattice(hipStream_t stream, const ScoreGrid& g, const float* bx, const float* by, int nbeams,
                           const int32_t* d_nbeams, const float* cand_xycs /* X[27] Y[27] CT[27] ST[27] */, float* work,
-                          float* out, float* persist, float* host_out, uint32_t* host_flag, uint32_t seq,
-                          const LatticeChain* chain = nullptr);
+                          float* out, float* persist, float* host_out, uint32_t* host_flag, uint32_t seq);
+// FastMatch on g1 followed by FastMatch2 on g2 around its winner, THREE launches and no host in between (engine.hip:
+// slam_engine_fastmatch_pair): the first lattice from cand1 as above; the second lattice's wavefronts work out the first call's
+// winner themselves (strict '<' from +inf over out1's 27 scores, the first of equals; none: the middle candidate = the input
+// pose) and lay their own candidate around it — x, y = the winner's -/+ pair_in[18], heading (cos, sin) = pair_in[3 a + b],
+// pair_in[9 + 3 a + b] for the winner's heading a and the candidate's b —; one merge for both calls: the persistent hit scratch
+// as the two calls one after the other leave it (entry j: the second call's where it has one, else the first call's), scores
+// and counts of both calls to the host (host_out1: 54 words; host_out2: scores, counts, the second call's maxcount), the flag.
+hipError_t launch_lattice_pair(hipStream_t stream, const ScoreGrid& g1, const ScoreGrid& g2, const float* bx, const float* by, int nbeams,
+                               const int32_t* d_nbeams, const float* cand1, const float* pair_in, float* work1, float* work2, float* out1,
+                               float* out2, float* persist, float* host_out1, float* host_out2, uint32_t* host_flag, uint32_t seq);
 
 // ---- mapper_kernels.hip (reference: main.c:71-198, 271-354, 941-953)
 hipError_t launch_clean_scan(hipStream_t s, const float* range, const float* cos_tab, const float* sin_tab, int nbeams,

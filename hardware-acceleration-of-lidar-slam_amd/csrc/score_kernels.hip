@@ -184,14 +184,33 @@ __global__ __launch_bounds__(64) void lattice_kernel(ScoreGrid g, const float* _
                                                      const float* __restrict__ by, int nbeams_max,
                                                      const int32_t* __restrict__ d_nbeams,
                                                      const float* __restrict__ cand, float* __restrict__ work,
-                                                     float* __restrict__ out)
+                                                     float* __restrict__ out, const float* __restrict__ prev_out,
+                                                     const float* __restrict__ pair_in)
 {
     extern __shared__ float s_hit[];
     const int c = blockIdx.x, lane = threadIdx.x;
     // the beam count may live on the device (scan cleaned up there); rows of `work` keep the max stride
     int nbeams = d_nbeams ? *d_nbeams : nbeams_max;
     nbeams = nbeams < nbeams_max ? nbeams : nbeams_max;
-    const float x = cand[c], y = cand[kLatticeN + c], ct = cand[2 * kLatticeN + c], st = cand[3 * kLatticeN + c];
+    float x = cand[c], y = cand[kLatticeN + c], ct = cand[2 * kLatticeN + c], st = cand[3 * kLatticeN + c];
+    if (prev_out) {
+        // the second call of a chained pair (kernels.h: launch_lattice_pair): `cand` is the FIRST call's table, this candidate is
+        // laid out around that call's winner (main.c:549-563: strict '<' keeps the first of equal scores)
+        float best = INFINITY;
+        int bk = -1;
+        for (int k = 0; k < kLatticeN; ++k)
+            if (prev_out[k] < best) {
+                best = prev_out[k];
+                bk = k;
+            }
+        if (bk < 0) bk = kLatticeN / 2;   // nothing below +inf: the input pose = the middle candidate (heading 1, x 1, y 1)
+        const float wx = cand[bk], wy = cand[kLatticeN + bk], t = pair_in[18];
+        const int a = bk / 9, b = c / 9, i = (c / 3) % 3, j = c % 3;
+        x = i == 0 ? wx - t : (i == 1 ? wx : wx + t);
+        y = j == 0 ? wy - t : (j == 1 ? wy : wy + t);
+        ct = pair_in[a * 3 + b];
+        st = pair_in[9 + a * 3 + b];
+    }
     const float nst = -st;
     const float off_x = (x - g.min_x) * g.ipix;
     const float off_y = (y - g.min_y) * g.ipix;
@@ -252,7 +271,7 @@ __global__ __launch_bounds__(64) void lattice_kernel(ScoreGrid g, const float* _
 __global__ __launch_bounds__(256) void lattice_merge_kernel(const float* __restrict__ work, int nbeams,
                                                             float* __restrict__ out, float* __restrict__ persist,
                                                             float* __restrict__ host_out,
-                                                            uint32_t* __restrict__ host_flag, uint32_t seq, LatticeChain chain)
+                                                            uint32_t* __restrict__ host_flag, uint32_t seq)
 {
     __shared__ int s_cnt[kLatticeN];
     const int32_t* cnt = reinterpret_cast<const int32_t*>(out) + kLatticeN;
@@ -268,32 +287,7 @@ __global__ __launch_bounds__(256) void lattice_merge_kernel(const float* __restr
         const float v = work[(size_t)c * nbeams + j];
         merged[j] = v;
         if (persist) persist[j] = v;   // device-resident copy of the caller's persistent hit scratch
-        if (host_out && !chain.cand2) host_out[2 * kLatticeN + 1 + j] = v;
-    }
-    if (chain.cand2) {
-        // the first call of a chained pair (kernels.h: LatticeChain): scores and counts to the host (the second call's launch
-        // releases the flag), the winner, and the next call's lattice around it
-        if (threadIdx.x < 2 * kLatticeN && host_out) host_out[threadIdx.x] = out[threadIdx.x];
-        if (threadIdx.x < kLatticeN) {
-            float best = INFINITY;
-            int bk = -1;
-            for (int k = 0; k < kLatticeN; ++k)   // main.c:549-563: strict '<' keeps the first of equal scores
-                if (out[k] < best) {
-                    best = out[k];
-                    bk = k;
-                }
-            if (bk < 0) bk = kLatticeN / 2;   // nothing below +inf: the input pose = the middle candidate (heading 1, x 1, y 1)
-            const float x = chain.cand1[bk], y = chain.cand1[kLatticeN + bk], t = chain.pair_in[18];
-            const int a = bk / 9, k = threadIdx.x, b = k / 9, i = (k / 3) % 3, j = k % 3;
-            const float xs = i == 0 ? x - t : (i == 1 ? x : x + t);
-            const float ys = j == 0 ? y - t : (j == 1 ? y : y + t);
-            chain.cand2[k] = xs;
-            chain.cand2[kLatticeN + k] = ys;
-            chain.cand2[2 * kLatticeN + k] = chain.pair_in[a * 3 + b];
-            chain.cand2[3 * kLatticeN + k] = chain.pair_in[9 + a * 3 + b];
-        }
-        __threadfence_system();   // (the scores for the host: complete before the launch ends, whatever the memory's caching)
-        return;
+        if (host_out) host_out[2 * kLatticeN + 1 + j] = v;
     }
     if (host_out) {
         if (threadIdx.x < 2 * kLatticeN) host_out[threadIdx.x] = out[threadIdx.x];   // scores and counts (bit copies)
@@ -304,15 +298,69 @@ __global__ __launch_bounds__(256) void lattice_merge_kernel(const float* __restr
     }
 }
 
+// the merge of a chained pair (kernels.h: launch_lattice_pair)
+__global__ __launch_bounds__(256) void lattice_merge_pair_kernel(const float* __restrict__ work1, const float* __restrict__ work2,
+                                                                 int nbeams, float* __restrict__ out1, float* __restrict__ out2,
+                                                                 float* __restrict__ persist, float* __restrict__ host_out1,
+                                                                 float* __restrict__ host_out2, uint32_t* __restrict__ host_flag,
+                                                                 uint32_t seq)
+{
+    __shared__ int s_c1[kLatticeN], s_c2[kLatticeN];
+    if (threadIdx.x < kLatticeN) {
+        s_c1[threadIdx.x] = reinterpret_cast<const int32_t*>(out1)[kLatticeN + threadIdx.x];
+        s_c2[threadIdx.x] = reinterpret_cast<const int32_t*>(out2)[kLatticeN + threadIdx.x];
+    }
+    __syncthreads();
+    int m1 = 0, m2 = 0;
+    for (int c = 0; c < kLatticeN; ++c) {
+        m1 = s_c1[c] > m1 ? s_c1[c] : m1;
+        m2 = s_c2[c] > m2 ? s_c2[c] : m2;
+    }
+    if (threadIdx.x == 0) {
+        reinterpret_cast<int32_t*>(out1)[2 * kLatticeN] = m1;
+        reinterpret_cast<int32_t*>(out2)[2 * kLatticeN] = m2;
+    }
+    // entry j of the shared hit scratch after both sweeps: the LAST candidate of the second call with more than j in-bounds beams
+    // wrote it last; where the second call has none, the first call's last such candidate did (main.c:515)
+    const int top = m1 > m2 ? m1 : m2;
+    if (persist)
+        for (int j = threadIdx.x; j < top; j += 256) {
+            const int* cnt = j < m2 ? s_c2 : s_c1;
+            const float* work = j < m2 ? work2 : work1;
+            int c = kLatticeN - 1;
+            while (cnt[c] <= j) --c;   // terminates: that call has a candidate with count > j
+            persist[j] = work[(size_t)c * nbeams + j];
+        }
+    if (threadIdx.x < 2 * kLatticeN) {
+        host_out1[threadIdx.x] = out1[threadIdx.x];   // scores and counts (bit copies)
+        host_out2[threadIdx.x] = out2[threadIdx.x];
+    }
+    if (threadIdx.x == 0) reinterpret_cast<int32_t*>(host_out2)[2 * kLatticeN] = m2;
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(host_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 }  // namespace
+
+hipError_t launch_lattice_pair(hipStream_t stream, const ScoreGrid& g1, const ScoreGrid& g2, const float* bx, const float* by, int nbeams,
+                               const int32_t* d_nbeams, const float* cand1, const float* pair_in, float* work1, float* work2, float* out1,
+                               float* out2, float* persist, float* host_out1, float* host_out2, uint32_t* host_flag, uint32_t seq)
+{
+    const size_t lds = sizeof(float) * (size_t)(nbeams > 0 ? nbeams : 1);
+    lattice_kernel<<<kLatticeN, 64, lds, stream>>>(g1, bx, by, nbeams, d_nbeams, cand1, work1, out1, nullptr, nullptr);
+    lattice_kernel<<<kLatticeN, 64, lds, stream>>>(g2, bx, by, nbeams, d_nbeams, cand1, work2, out2, out1, pair_in);
+    lattice_merge_pair_kernel<<<1, 256, 0, stream>>>(work1, work2, nbeams, out1, out2, persist, host_out1, host_out2, host_flag, seq);
+    return hipGetLastError();
+}
 
 hipError_t launch_lattice(hipStream_t stream, const ScoreGrid& g, const float* bx, const float* by, int nbeams,
                           const int32_t* d_nbeams, const float* cand_xycs, float* work, float* out, float* persist,
-                          float* host_out, uint32_t* host_flag, uint32_t seq, const LatticeChain* chain)
+                          float* host_out, uint32_t* host_flag, uint32_t seq)
 {
     const size_t lds = sizeof(float) * (size_t)(nbeams > 0 ? nbeams : 1);
-    lattice_kernel<<<kLatticeN, 64, lds, stream>>>(g, bx, by, nbeams, d_nbeams, cand_xycs, work, out);
-    lattice_merge_kernel<<<1, 256, 0, stream>>>(work, nbeams, out, persist, host_out, host_flag, seq, chain ? *chain : LatticeChain());
+    lattice_kernel<<<kLatticeN, 64, lds, stream>>>(g, bx, by, nbeams, d_nbeams, cand_xycs, work, out, nullptr, nullptr);
+    lattice_merge_kernel<<<1, 256, 0, stream>>>(work, nbeams, out, persist, host_out, host_flag, seq);
     return hipGetLastError();
 }
 
