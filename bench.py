@@ -631,10 +631,11 @@ def run_rank(args, ctx, inp, last=True):
     # of the timed region carries it: the kernel's duration is still measured live, inside the timed region, on the kernel's
     # own stream, while the measurement itself costs the frame rate under 1.5 % instead of ~10 %.  `roofline.launches` says how
     # many launches were bracketed; --event-every 1 brackets every frame.
-    # (default: every 8th frame of runs of 80 steps or more — 25 samples in the default 200 —, every 4th from 40 steps, every 2nd
-    # below: 10 samples in the driver's 20 steps; bracketing fewer of those was measured and does not change their rate — a run
-    # that short is dominated by the empty queue at its start and the synchronisation at its end, 0.115 against 0.107 ms per frame)
-    every = max(1, args.event_every if args.event_every > 0 else (8 if args.steps >= 80 else (4 if args.steps >= 40 else 2)))
+    # (default: every 8th frame of runs of 80 steps or more — 25 samples in the default 200 —, every 4th of shorter ones — 5 samples
+    # in the driver's 20 steps.  profiles/short_run.sh, ms per frame on one box: 200 steps 0.1077, without brackets 0.1070; 20 steps
+    # with a bracket in every 2nd frame 0.1176, in 2 of the 20 0.1160, without 0.1144: a region that short pays about 7 % for its
+    # two ends — an empty queue behind the synchronisation in front, the synchronisation behind — whatever is bracketed)
+    every = max(1, args.event_every if args.event_every > 0 else (8 if args.steps >= 80 else (4 if args.steps >= 12 else 2)))
     t0 = time.perf_counter()
     for k in range(args.warmup, args.warmup + args.steps):
         if every > 1:
@@ -1142,7 +1143,7 @@ def parse_args():
                     help="host sleep between set-up and the warm-up frames (see settle(); 0 = none)")
     ap.add_argument("--event-every", type=int, default=0,
                     help="bracket the timed kernels with HIP events in every N-th frame of the timed region (1 = every frame; "
-                         "default 0 = every 8th frame, every 4th when --steps < 80, every 2nd when --steps < 40)")
+                         "default 0 = every 8th frame, every 4th when --steps < 80, every 2nd when --steps < 12)")
     ap.add_argument("--events", choices=["dominant", "all", "none"], default="dominant",
                     help="kernels bracketed by HIP events inside the timed region (a pair costs a few us of stream time)")
     ap.add_argument("--observed", type=int, default=0,
