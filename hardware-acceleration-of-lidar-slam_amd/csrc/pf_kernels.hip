@@ -1539,42 +1539,83 @@ __global__ __launch_bounds__(kBlock) void ancestors_from_scan_kernel(const uint6
         if (blockIdx.x == 0 && threadIdx.x == 0) publish_gate(gate, resample);
     }
     int val = -1;   // this slot's ancestor (-1: no such slot)
-    if (j < n) {
-        if (!resample) {
-            val = j;   // the frame keeps its population
-        } else if (total == 0 || (total >> 63)) {   // see offspring_offsets_kernel: every slot gets the last particle
-            val = n - 1;
-        } else {
+    const bool search = resample && !(total == 0 || (total >> 63));   // the same in every thread of every workgroup
+    if (j < n && !search) val = resample ? n - 1   // see offspring_offsets_kernel: every slot gets the last particle
+                                         : j;      // the frame keeps its population
+    if (search) {
+        const bool in = j < n;
+        const uint64_t N = (uint64_t)n;
+        uint64_t t_lo = 0, t_hi = 0;
+        int tlo = 0;
+        auto below = [&](uint64_t c) {   // N * c <= T, both sides 96-bit quantities compared as (hi, lo) pairs
+            const uint64_t x_lo = c * N, x_hi = __umul64hi(c, N);
+            return x_hi < t_hi || (x_hi == t_hi && x_lo <= t_lo);
+        };
+        if (in) {
             const u32x4 r = philox4x32_10(0u, 0u, frame, 1u /* resample stream */, key0, key1);
             const uint64_t comb_u = __umul64hi((uint64_t)r.v[0] | ((uint64_t)r.v[1] << 32), total);
-            uint64_t t_lo = (uint64_t)j * total, t_hi = __umul64hi((uint64_t)j, total);
+            t_lo = (uint64_t)j * total;
+            t_hi = __umul64hi((uint64_t)j, total);
             t_lo += comb_u;
             t_hi += t_lo < comb_u ? 1ull : 0ull;
-            const uint64_t N = (uint64_t)n;
             // number of k in [0, n-1) with N*C_incl(k) <= T.  First among the tiles, in LDS: the CDF at the end of tile t is
             // the offset of tile t + 1 (the grand total for the last one), so whole tiles below T are counted without
-            // touching memory; then inside the one tile that holds the boundary (each step there is a dependent L2 round trip:
-            // 11 of them instead of log2 n).
-            int tlo = 0, thi = ntiles - 1;   // first tile whose last element lies above T (the last tile if none does)
+            // touching memory; then inside the one tile that holds the boundary.
+            int thi = ntiles - 1;   // first tile whose last element lies above T (the last tile if none does)
             while (tlo < thi) {
                 const int mid = (tlo + thi) >> 1;
-                const uint64_t c = s_off[mid + 1];   // mid + 1 <= ntiles - 1
-                const uint64_t x_lo = c * N, x_hi = __umul64hi(c, N);
-                if (x_hi < t_hi || (x_hi == t_hi && x_lo <= t_lo)) tlo = mid + 1; else thi = mid;
+                if (below(s_off[mid + 1])) tlo = mid + 1; else thi = mid;   // mid + 1 <= ntiles - 1
             }
-            int lo = tlo * kScanTile, hi = (tlo + 1) * kScanTile < n - 1 ? (tlo + 1) * kScanTile : n - 1;
+        }
+        int lo = tlo * kScanTile, hi = (tlo + 1) * kScanTile < n - 1 ? (tlo + 1) * kScanTile : n - 1;
+        const uint64_t off = s_off[tlo];   // (every pivot below lies in tile tlo)
+        // kPer == 1 (n <= 512k): a second level in LDS.  The thresholds rise with the slot, so the workgroup's 256 slots fall
+        // into the tiles of its first and its last slot; when that is at most two tiles, the CDF at the END of each of their
+        // 32-element blocks (64 values per tile: one strided load per thread, one round trip) is staged in LDS, six LDS steps
+        // find the block, and five dependent L2 round trips remain of the eleven (measured: 7.6 -> 7.1 us at 64k slots; staging the
+        // whole window instead, 16-32 KB, was slower: 9.5 us).  The same comparisons on the same values: the block whose last element is the first above T holds the
+        // answer, and if none is, the search ends at the tile's upper bound as it does without the second level.
+        if constexpr (kPer == 1) {
+            constexpr int kSub = 32, kSubPerTile = kScanTile / kSub;
+            __shared__ uint64_t s_sub[2 * kSubPerTile];
+            __shared__ int s_t[2];
+            const int last = (n - 1 - (int)blockIdx.x * kBlock) < kBlock - 1 ? (n - 1 - (int)blockIdx.x * kBlock) : kBlock - 1;
+            if (threadIdx.x == 0) s_t[0] = tlo;
+            if ((int)threadIdx.x == last) s_t[1] = tlo;
+            __syncthreads();
+            const int tmin = s_t[0], tmax = s_t[1];
+            const bool staged = tmax - tmin <= 1;   // (workgroup-uniform)
+            if (staged) {
+                for (int q = threadIdx.x; q < (tmax - tmin + 1) * kSubPerTile; q += kBlock) {
+                    const int idx = tmin * kScanTile + q * kSub + kSub - 1;
+                    s_sub[q] = cdf_local[idx < n ? idx : n - 1];   // (beyond the data: never looked at below)
+                }
+                __syncthreads();
+                if (in) {
+                    // first block b of tile tlo whose last element is above T, among the blocks that end below `hi`
+                    const int nblk = (hi - lo) / kSub;   // whole blocks in [lo, hi): their last elements are < hi
+                    const uint64_t* sub = s_sub + (tlo - tmin) * kSubPerTile;
+                    int blo = 0, bhi = nblk;
+                    while (blo < bhi) {
+                        const int mid = (blo + bhi) >> 1;
+                        if (below(sub[mid] + off)) blo = mid + 1; else bhi = mid;
+                    }
+                    if (blo < nblk) hi = lo + blo * kSub + kSub - 1;   // that element is above T: the answer is at or below it
+                    lo += blo * kSub;
+                }
+            }
+        }
+        if (in) {
             // (an 8-ary search — seven pivots per step side by side — was measured equal: 10.5 us at 64k slots, 62 us at 1M:
             // fewer dependent round trips, but seven times the gathers)
             while (lo < hi) {
                 const int mid = (lo + hi) >> 1;
-                const uint64_t c = cdf_local[mid] + s_off[mid / kScanTile];
-                const uint64_t x_lo = c * N, x_hi = __umul64hi(c, N);
-                if (x_hi < t_hi || (x_hi == t_hi && x_lo <= t_lo)) lo = mid + 1; else hi = mid;
+                if (below(cdf_local[mid] + off)) lo = mid + 1; else hi = mid;
             }
             val = lo;
         }
-        anc[j] = val;
     }
+    if (j < n) anc[j] = val;
     count_heads(heads, val, j < n, n);
 }
 
