@@ -334,7 +334,7 @@ def test_split_pages_map_io():
     eng.close()
 
 
-@pytest.mark.parametrize("world,n_total,L,frames", [(2, 4096, 70, 12), (3, 3072, 100, 14), (4, 8192, 130, 10), (2, 16384, 200, 8)])
+@pytest.mark.parametrize("world,n_total,L,frames", [(2, 4096, 70, 12), (3, 3072, 100, 14), (4, 8192, 130, 10), (2, 16384, 200, 8), (8, 8192, 40, 20)])
 def test_sharded_split_pages_ranks_on_one_card_equal_one_rank_on_rows(world, n_total, L, frames, monkeypatch):
     """Sharded sessions on split pages: a migrating particle is packed from its mean pages and its class's covariance rows and
     unpacked onto fresh mean pages as a class of its own (class numbers recycled from short lists); frames that observe a few
