@@ -1068,7 +1068,8 @@ static int pf_step_impl(slam_pf* pf, int slot, const float dp[3], int use_observ
             // the particles' update (a frame that kept its population runs it out of place all the same: its gather index is
             // the identity) ...
             if (fused && comm) sio.group_filter = 2;   // the groups that waited for the exchange
-            if (!fused || comm)
+            // (no rows received this frame: no group has an ancestor in the staging tail, the launch would find nothing to do)
+            if (!fused || (comm && pf->rows_received > 0))
                 if ((rc = slam_ekf_split_dev(e, pf->mean[sc], pf->mean[1 - sc], 2 * (int64_t)pf->Lp, pf->Lp, L, dst, dst + sn, dst + 2 * sn,
                                              anc, n, pf->cfg.meas_var, &sio)) != SLAM_OK)
                     return rc;
