@@ -1237,10 +1237,18 @@ def main():
     if wants_strong_leg(args):
         try:
             leg = strong_leg(args, ctx)
-        except Exception as ex:   # (single rank: a leg that fails must not cost the headline line)
-            if ctx.world > 1:
-                raise
+        except Exception as ex:   # a leg that fails must not cost the headline line
             leg = {"error": f"{type(ex).__name__}: {ex}"}
+            if ctx.world > 1:
+                # several ranks: the peers may be anywhere (inside a collective of the leg, or past it) — no further collective
+                # is safe.  Rank 0 hands over the headline it already has; every rank that got here leaves without the
+                # process-group teardown (which is collective); ranks still waiting give up at their own time limit.
+                print(f"bench.py: rank {ctx.rank}: north_star_strong failed: {leg['error']}", file=sys.stderr, flush=True)
+                if ctx.rank == 0:
+                    out["north_star_strong"] = leg
+                    print(json.dumps(out), flush=True)
+                sys.stdout.flush()
+                os._exit(0 if ctx.rank == 0 else 1)
         if ctx.rank == 0:
             out["north_star_strong"] = leg
     if ctx.rank == 0:
